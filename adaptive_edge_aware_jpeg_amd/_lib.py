@@ -1,0 +1,159 @@
+"""ctypes binding of libaejpeg_hip.so (include/aej.h) + a small device-context wrapper.
+
+PyTorch-ROCm is used for device memory and streams only: every tensor handed to the library is a
+``torch`` CUDA(=HIP) tensor and the library receives raw device pointers.  There is no CPU fallback: if
+the shared library is missing or no GPU is visible, the calls raise.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaejpeg_hip.so")
+
+SPACE_IDS = {"YCbCr": 0, "YCoCg": 1, "YCoCg-R": 2, "OKLAB": 3, "ICtCp": 4, "ICaCb": 5, "JzAzBz": 6}
+
+AEJ_ERR_ARG, AEJ_ERR_HIP, AEJ_ERR_STATE, AEJ_ERR_CAPACITY, AEJ_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+
+
+class AejError(RuntimeError):
+    pass
+
+
+class AejPlan(ctypes.Structure):
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("layer_h", ctypes.c_int32 * 3), ("layer_w", ctypes.c_int32 * 3), ("root_size", ctypes.c_int32 * 3),
+        ("coeff_off", ctypes.c_int64 * 3), ("coeff_stride", ctypes.c_int64),
+        ("leaf_off", ctypes.c_int64 * 3), ("leaf_stride", ctypes.c_int64),
+        ("state_off", ctypes.c_int64 * 3), ("state_stride", ctypes.c_int64),
+        ("workspace_bytes", ctypes.c_uint64),
+    ]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+# name -> (restype, argtypes); exactly the symbols declared in include/aej.h
+_P, _I, _I64, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
+SIGNATURES = {
+    "aej_abi_version": (_I, []),
+    "aej_create": (_P, [_I, _P]),
+    "aej_destroy": (None, [_P]),
+    "aej_last_error": (ctypes.c_char_p, [_P]),
+    "aej_synchronize": (_I, [_P]),
+    "aej_last_hysteresis_passes": (_I, [_P]),
+    "aej_set_settings": (_I, [_P, _I, _I, _I, _P]),
+    "aej_encode_plan": (_I, [_P, _I, _I, _I, ctypes.POINTER(AejPlan)]),
+    "aej_encode_batch": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _U64]),
+    "aej_color_convert": (_I, [_P, _I, _P, _P, _I64]),
+    "aej_color_planes": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "aej_canny_workspace_bytes": (_U64, [_I, _I]),
+    "aej_canny": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _U64]),
+    "aej_quadtree_workspace_bytes": (_U64, [_I, _I, _I, _I]),
+    "aej_quadtree_capacity": (_I, [_I, _I, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "aej_quadtree": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _U64]),
+    "aej_dct_quant_zigzag": (_I, [_P, _P, _I, _I, _I, _P, _I64, _P, _P]),
+}
+
+
+def load_library():
+    """Load libaejpeg_hip.so and declare every signature.  Raises if the HIP extension is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise AejError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise AejError("no HIP device visible to PyTorch-ROCm: the adaptive-JPEG encode path runs on the GPU only")
+    return torch
+
+
+class Context:
+    """One aej_ctx bound to a device and to that device's current torch stream."""
+
+    def __init__(self, device=0):
+        self.torch = _torch()
+        self.lib = load_library()
+        self.device = self.torch.device("cuda", device if isinstance(device, int) else device.index or 0)
+        with self.torch.cuda.device(self.device):
+            stream = self.torch.cuda.current_stream().cuda_stream
+        self.handle = self.lib.aej_create(self.device.index, ctypes.c_void_p(stream))
+        if not self.handle:
+            raise AejError(self.lib.aej_last_error(None).decode())
+        self.settings_key = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.aej_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- helpers
+    def check(self, rc):
+        if rc == 0:
+            return
+        msg = self.lib.aej_last_error(self.handle).decode()
+        if rc == AEJ_ERR_ARG:
+            raise ValueError(msg)
+        if rc == AEJ_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise AejError(f"aej error {rc}: {msg}")
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+        return self._ws
+
+    def to_device(self, arr, dtype):
+        t = self.torch
+        if isinstance(arr, t.Tensor):
+            return arr.to(device=self.device, dtype=dtype).contiguous()
+        return t.from_numpy(np.ascontiguousarray(arr)).to(device=self.device, dtype=dtype).contiguous()
+
+    def set_settings(self, space, bmin, bmax, qmats):
+        """qmats: int32 numpy array laid out [layer][size][s*s] (see include/aej.h)."""
+        key = (space, bmin, bmax, qmats.tobytes())
+        if key == self.settings_key:
+            return
+        q = np.ascontiguousarray(qmats, dtype=np.int32)
+        self.check(self.lib.aej_set_settings(self.handle, SPACE_IDS[space], bmin, bmax, q.ctypes.data_as(ctypes.c_void_p)))
+        self.settings_key = key
+
+    def plan(self, batch, H, W):
+        p = AejPlan()
+        self.check(self.lib.aej_encode_plan(self.handle, batch, H, W, ctypes.byref(p)))
+        return p
+
+
+_contexts = {}
+
+
+def get_context(device=0):
+    idx = device if isinstance(device, int) else (device.index or 0)
+    ctx = _contexts.get(idx)
+    if ctx is None:
+        ctx = _contexts[idx] = Context(idx)
+    return ctx

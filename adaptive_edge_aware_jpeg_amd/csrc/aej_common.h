@@ -1,0 +1,68 @@
+// aej_common.h -- structures shared by the HIP translation units of libaejpeg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aej {
+
+constexpr int kMaxSizes = 8;      // block sizes 2..256
+constexpr int kClaheTiles = 4;    // tileGridSize (4,4), edge_detection.py:36
+constexpr int kHystTile = 64;     // hysteresis tile edge (pixels)
+constexpr int kBlurTW = 64, kBlurTH = 32;  // output tile of the fused CLAHE/Gauss/bilateral kernel
+constexpr int kQtChunk = 256;     // min-cells per quadtree chunk (16x16, one Morton-aligned square)
+
+// Geometry of one batch: every image has the same H x W; up to 3 layers per image.
+struct Geom {
+    int B;            // images
+    int nl;           // layers in use (3, or 1 for the stand-alone stage entry points)
+    int H, W;         // full-resolution image
+    int h[3], w[3];   // layer shapes (jpeg.py:676-686)
+    int rh[3], rw[3]; // down-sampling ratios (jpeg.py:62-147)
+    long long poff[3];   // element offset of layer l inside one image's plane storage
+    long long pstride;   // plane elements per image = sum h*w
+    // CLAHE tile geometry per layer (clahe.cpp): padded size / 4
+    int ctw[3], cth[3];
+};
+
+// Quadtree geometry per layer.
+struct QtGeom {
+    int bmin, bmax;
+    int cell;          // min(bmin, root) -- edge of a level-0 cell in pixels
+    int root[3];       // root size in pixels
+    int ncell[3];      // root / cell  (cells per side, power of two)
+    int ltot[3];       // log2(ncell)
+    long long pyr_off[3];     // byte offset of layer l's pyramid inside one image's pyramid storage
+    long long pyr_stride;     // pyramid bytes per image
+    int nchunk[3];            // number of 256-cell chunks = max(1, ncell^2/256)
+    long long chunk_off[3];   // offset (in chunks) of layer l inside one image's chunk arrays
+    long long chunk_stride;   // chunks per image
+    // output layout (elements)
+    long long coeff_off[3], coeff_stride;
+    long long leaf_off[3], leaf_stride;
+    long long state_off[3], state_stride;
+    long long coeff_cap[3], leaf_cap[3], state_cap[3];
+};
+
+// One unit of DCT work (a leaf), appended by the quadtree emit kernel.
+struct LeafWork {
+    int plane;      // b * 3 + layer
+    int x, y;       // origin in the layer
+    int coef;       // coefficient offset inside the layer's coefficient array
+};
+
+struct DctTables {
+    // per size index k (size = bmin << k)
+    const float *D[kMaxSizes];        // [s][s] DCT-II basis, float32 (row k = frequency)
+    const int *zzinv[kMaxSizes];      // [s*s] zigzag position of raster index
+    const int *qm[3][kMaxSizes];      // [s*s] quantisation matrix per layer
+};
+
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+
+}  // namespace aej
+
+#define AEJ_HIP_CHECK(expr)                                                       \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) return aej::hip_fail(ctx, _e, #expr, __FILE__, __LINE__); \
+    } while (0)

@@ -1,0 +1,70 @@
+// aej_launch.h -- host-side launch functions exported by the .hip translation units.
+#pragma once
+#include "aej_common.h"
+
+namespace aej {
+
+// color.hip
+int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out, long long n);
+int launch_color_planes(hipStream_t st, int space, const float *rgb, const Geom &g, const float *mid, const float *scale,
+                        float *raw, float *norm, unsigned char *u8, int *tile_hist);
+void launch_plane_u8(hipStream_t st, const float *plane, const Geom &g, unsigned char *u8, int *tile_hist);
+
+// canny.hip
+struct CannyBuffers {
+    unsigned char *u8a;     // [B][pstride] scaled uint8 in; NMS / hysteresis map out
+    unsigned char *u8b;     // [B][pstride] bilateral output
+    int *tile_hist;         // [B][3][16][256]
+    unsigned char *lut;     // [B][3][16][256]
+    int *blur_hist;         // [B][3][256]
+    int *thr;               // [B][3][2]
+    unsigned char *dirty;   // [2][B][hyst tiles per image]
+    int *pass_changed;      // [kMaxHystPasses]
+    const float *space_w;   // [13]
+    const float *color_w;   // [256]
+    // optional stage dumps (stand-alone entry point only)
+    unsigned char *dump_clahe, *dump_gauss;
+};
+constexpr int kMaxHystPasses = 4096;
+long long hyst_tiles_per_image(const Geom &g);
+void launch_clahe_pad_hist(hipStream_t st, const Geom &g, const CannyBuffers &cb);
+void launch_clahe_lut(hipStream_t st, const Geom &g, const CannyBuffers &cb);
+void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb);
+void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb);
+void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb);
+void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass);
+void launch_edge_final(hipStream_t st, const Geom &g, const unsigned char *map, unsigned char *edge01);
+
+// quadtree.hip
+struct QtBuffers {
+    unsigned char *pyr;     // [B][pyr_stride]
+    int *chunk_cnt;         // [B][chunk_stride][4]  (nsym, nleaf, ncoef, pad) then exclusive offsets after scan
+    int *leaves;            // out [B][leaf_stride][4]
+    unsigned char *states;  // out [B][state_stride]
+    long long *counts;      // out [B][3][4]
+    LeafWork *work[kMaxSizes];   // per-size work lists (may be null when no DCT follows)
+    int *work_count;        // [kMaxSizes]
+    long long work_cap[kMaxSizes];
+    int *overflow;          // [1] set to 1 when a capacity would be exceeded
+};
+void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned char *map, int edge_value, const QtBuffers &qb);
+void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb);
+void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb);
+void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb);
+
+// dct.hip
+struct DctArgs {
+    const float *norm;        // [B][pstride] normalised planes
+    int *coeffs;              // out [B][coeff_stride]
+    float *dct_f32;           // optional
+    const LeafWork *work;     // work list for this size
+    const int *work_count;    // device counter for this size
+    const float *D;           // [s][s]
+    const int *zzinv;         // [s*s]
+    const int *qm[3];         // [s*s] per layer
+};
+void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items);
+// builds a work list from a leaf table (stand-alone aej_dct_quant_zigzag)
+void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int bmin, int plane, LeafWork *const *work, int *work_count);
+
+}  // namespace aej

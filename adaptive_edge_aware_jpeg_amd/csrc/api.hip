@@ -1,0 +1,712 @@
+// api.hip -- the C ABI of libaejpeg_hip.so (include/aej.h): context, settings/tables, workspace carving and
+// the kernel sequence of the encode hot path.  Host code only; gfx950 kernels live in the other .hip files.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/aej.h"
+#include "aej_common.h"
+#include "aej_launch.h"
+
+using namespace aej;
+
+struct aej_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool has_settings = false;
+    int space = 0, bmin = 0, bmax = 0, nsizes = 0;
+    void *tables = nullptr;            // one device allocation holding every table below
+    const float *d_D[kMaxSizes] = {};
+    const int *d_zzinv[kMaxSizes] = {};
+    const int *d_qm[3][kMaxSizes] = {};
+    const float *d_space_w = nullptr, *d_color_w = nullptr;
+    int *h_flag = nullptr;             // pinned host word for counter read-backs
+    int last_hyst_passes = 0;
+};
+
+namespace aej {
+static int fail(aej_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+int hip_fail(aej_ctx *ctx, hipError_t e, const char *expr, const char *file, int line)
+{
+    return fail(ctx, AEJ_ERR_HIP, "%s failed: %s (%s:%d)", expr, hipGetErrorString(e), file, line);
+}
+}  // namespace aej
+
+// ---- constant tables ---------------------------------------------------------------------------------
+// down-sampling ratios (rh, rw) per layer: JpegCompressionSettings.COLOR_SPACE_SETTINGS, jpeg.py:62-147
+static const int kRatios[7][3][2] = {
+    { { 1, 1 }, { 2, 2 }, { 2, 2 } },  // YCbCr
+    { { 1, 1 }, { 2, 2 }, { 2, 2 } },  // YCoCg
+    { { 1, 1 }, { 2, 2 }, { 2, 2 } },  // YCoCg-R
+    { { 1, 1 }, { 2, 2 }, { 2, 2 } },  // OKLAB
+    { { 1, 1 }, { 1, 4 }, { 1, 4 } },  // ICtCp
+    { { 1, 1 }, { 1, 4 }, { 1, 4 } },  // ICaCb
+    { { 1, 1 }, { 2, 2 }, { 2, 2 } },  // JzAzBz
+};
+// MIDPOINTS / SCALE_FACTORS: float32 of the Python literals (ycbcr.py:41-42, ycocg.py:41-42,62-63, oklab.py:51-52,
+// ictcp.py:162-163, icacb.py:162-163, jzazbz.py:211-212)
+static const double kMid[7][3] = {
+    { 0.5000000037252903, 7.450580596923828e-09, 0.0 }, { 0.5, 0.0, 0.0 }, { 0.5, 0.0, 0.0 },
+    { 0.4999999, 0.021152213, -0.056563325 }, { 0.07497266, -0.0008235276, 0.023989676 },
+    { 0.07498085, 0.02180194, -0.018250957 }, { 0.0087900255, 0.00048353244, -0.0020741792 },
+};
+static const double kScale[7][3] = {
+    { 253.99999810755253, 254.000003784895, 254.0 }, { 254.0, 254.0, 254.0 }, { 254.0, 127.0, 127.0 },
+    { 254.00005, 497.9055, 497.94604 }, { 1693.9674, 1133.9044, 1694.004 },
+    { 1693.7823, 1838.5665, 1330.3855 }, { 14448.194, 7590.505, 5552.201 },
+};
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+
+// quadtree.py:89-90 + utils.py:36-41: largest_power_of_2(max(H, W)) * 2
+static int root_size_of(int h, int w)
+{
+    int n = h > w ? h : w;
+    int lp;
+    if (n <= 2) lp = n;
+    else { lp = 1; while (lp * 2 < n) lp *= 2; }
+    return lp * 2;
+}
+
+static void fill_clahe_geom(Geom &g)
+{
+    for (int l = 0; l < g.nl; l++) {
+        int w = g.w[l], h = g.h[l];
+        int wp = w, hp = h;
+        if ((w % 4) != 0 || (h % 4) != 0) { wp = w + (4 - w % 4); hp = h + (4 - h % 4); }   // clahe.cpp copyMakeBorder
+        g.ctw[l] = wp / 4;
+        g.cth[l] = hp / 4;
+    }
+}
+
+static int make_geom(aej_ctx *ctx, int space, int B, int H, int W, Geom &g)
+{
+    memset(&g, 0, sizeof g);
+    g.B = B; g.nl = 3; g.H = H; g.W = W;
+    long long off = 0;
+    for (int l = 0; l < 3; l++) {
+        g.rh[l] = kRatios[space][l][0];
+        g.rw[l] = kRatios[space][l][1];
+        g.h[l] = H / g.rh[l];
+        g.w[l] = W / g.rw[l];
+        if (g.h[l] < 1 || g.w[l] < 1) return fail(ctx, AEJ_ERR_ARG, "image %dx%d too small for the down-sampling ratios", H, W);
+        g.poff[l] = off;
+        off += align_up((long long)g.h[l] * g.w[l], 64);
+    }
+    g.pstride = off;
+    fill_clahe_geom(g);
+    return 0;
+}
+
+static void make_plane_geom(int H, int W, Geom &g)   // one stand-alone plane as "layer 0"
+{
+    memset(&g, 0, sizeof g);
+    g.B = 1; g.nl = 1; g.H = H; g.W = W;
+    g.h[0] = H; g.w[0] = W; g.rh[0] = g.rw[0] = 1;
+    g.poff[0] = 0;
+    g.pstride = align_up((long long)H * W, 64);
+    fill_clahe_geom(g);
+}
+
+static int make_qtgeom(aej_ctx *ctx, const Geom &g, int bmin, int bmax, QtGeom &q)
+{
+    memset(&q, 0, sizeof q);
+    if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 1)
+        return fail(ctx, AEJ_ERR_ARG, "block sizes must be powers of two with min <= max (got %d, %d)", bmin, bmax);
+    q.bmin = bmin; q.bmax = bmax; q.cell = bmin;
+    long long pyr = 0, chunks = 0, co = 0, lo = 0, so = 0;
+    for (int l = 0; l < g.nl; l++) {
+        int root = root_size_of(g.h[l], g.w[l]);
+        if (root < bmin) return fail(ctx, AEJ_ERR_UNSUPPORTED, "layer %d (%dx%d): root %d smaller than min block %d", l, g.h[l], g.w[l], root, bmin);
+        q.root[l] = root;
+        q.ncell[l] = root / q.cell;
+        q.ltot[l] = ilog2(q.ncell[l]);
+        if (q.ltot[l] > 14) return fail(ctx, AEJ_ERR_UNSUPPORTED, "quadtree deeper than 14 levels");
+        q.pyr_off[l] = pyr;
+        long long states = 0;
+        for (int j = 0; j <= q.ltot[l]; j++) { long long s = q.ncell[l] >> j; states += s * s; }
+        pyr += align_up(states, 256);
+        long long nc2 = (long long)q.ncell[l] * q.ncell[l];
+        q.nchunk[l] = (int)(nc2 / 256 > 0 ? nc2 / 256 : 1);
+        q.chunk_off[l] = chunks;
+        chunks += q.nchunk[l];
+        int top = bmax < root ? bmax : root;
+        long long wc = align_up(g.w[l], top), hc = align_up(g.h[l], top);
+        if (wc > root) wc = root;
+        if (hc > root) hc = root;
+        q.coeff_cap[l] = wc * hc;
+        q.leaf_cap[l] = (wc / q.cell) * (hc / q.cell);
+        q.state_cap[l] = states;
+        q.coeff_off[l] = co; co += align_up(q.coeff_cap[l], 64);
+        q.leaf_off[l] = lo;  lo += align_up(q.leaf_cap[l], 16);
+        q.state_off[l] = so; so += align_up(q.state_cap[l], 64);
+    }
+    q.pyr_stride = pyr; q.chunk_stride = chunks;
+    q.coeff_stride = co; q.leaf_stride = lo; q.state_stride = so;
+    return 0;
+}
+
+// ---- workspace carving ----------------------------------------------------------------------------------
+struct Carver {
+    char *base;
+    unsigned long long off = 0;
+    explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+    template <typename T> T *take(long long n)
+    {
+        off = (off + 255) & ~255ull;
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += (unsigned long long)n * sizeof(T);
+        return p;
+    }
+};
+
+struct CannyWs {
+    CannyBuffers cb;
+    char *zero_begin, *zero_end;     // region cleared at the start of every call
+    unsigned char *dirty0; long long dirty_n;
+};
+
+static void carve_canny(Carver &c, const Geom &g, CannyWs &w)
+{
+    memset(&w, 0, sizeof w);
+    long long planes = (long long)g.B * g.pstride;
+    long long tiles = hyst_tiles_per_image(g) * g.B;
+    w.cb.u8a = c.take<unsigned char>(planes);
+    w.cb.u8b = c.take<unsigned char>(planes);
+    w.cb.lut = c.take<unsigned char>((long long)g.B * 3 * 16 * 256);
+    w.cb.thr = c.take<int>((long long)g.B * 3 * 2);
+    w.zero_begin = reinterpret_cast<char *>(c.take<int>(0));
+    w.cb.tile_hist = c.take<int>((long long)g.B * 3 * 16 * 256);
+    w.cb.blur_hist = c.take<int>((long long)g.B * 3 * 256);
+    w.cb.pass_changed = c.take<int>(kMaxHystPasses);
+    c.take<int>(0);
+    w.zero_end = c.base ? c.base + c.off : nullptr;
+    w.cb.dirty = c.take<unsigned char>(2 * tiles);
+    w.dirty0 = w.cb.dirty; w.dirty_n = tiles;
+}
+
+struct QtWs {
+    QtBuffers qb;
+    char *zero_begin, *zero_end;
+};
+
+static void carve_qt(Carver &c, const Geom &g, const QtGeom &q, bool with_work, QtWs &w)
+{
+    memset(&w, 0, sizeof w);
+    w.zero_begin = reinterpret_cast<char *>(c.take<int>(0));
+    w.qb.pyr = c.take<unsigned char>((long long)g.B * q.pyr_stride);
+    w.qb.work_count = c.take<int>(kMaxSizes);
+    w.qb.overflow = c.take<int>(1);
+    c.take<int>(0);
+    w.zero_end = c.base ? c.base + c.off : nullptr;
+    w.qb.chunk_cnt = c.take<int>((long long)g.B * q.chunk_stride * 4);
+    if (with_work) {
+        int k = 0;
+        for (int s = q.bmin; s <= q.bmax && k < kMaxSizes; s *= 2, k++) {
+            long long cap = 0;
+            for (int l = 0; l < g.nl; l++) {
+                if (s > q.root[l]) continue;
+                int top = q.bmax < q.root[l] ? q.bmax : q.root[l];
+                long long wc = align_up(g.w[l], top), hc = align_up(g.h[l], top);
+                if (wc > q.root[l]) wc = q.root[l];
+                if (hc > q.root[l]) hc = q.root[l];
+                cap += ((wc + s - 1) / s) * ((hc + s - 1) / s);
+            }
+            cap *= g.B;
+            w.qb.work_cap[k] = cap;
+            w.qb.work[k] = c.take<LeafWork>(cap > 0 ? cap : 1);
+        }
+    } else {
+        w.qb.work_count = nullptr;
+    }
+}
+
+// ---- lifetime ---------------------------------------------------------------------------------------------
+extern "C" int aej_abi_version(void) { return AEJ_ABI_VERSION; }
+
+extern "C" aej_ctx *aej_create(int device, void *hip_stream)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    aej_ctx *ctx = new aej_ctx();
+    ctx->device = device;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
+    return ctx;
+}
+
+extern "C" void aej_destroy(aej_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->tables) (void)hipFree(ctx->tables);
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    delete ctx;
+}
+
+extern "C" const char *aej_last_error(aej_ctx *ctx)
+{
+    if (!ctx) return "aej: no context (aej_create failed: no such HIP device?)";
+    return ctx->err.c_str();
+}
+
+extern "C" int aej_synchronize(aej_ctx *ctx)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- settings ---------------------------------------------------------------------------------------------
+// Jpeg._zigzag_ordering (jpeg.py:726-766) as an anti-diagonal walk: even diagonals run bottom-left -> top-right
+static void zigzag_order(int s, std::vector<int> &zz)
+{
+    zz.resize((size_t)s * s);
+    int i = 0;
+    for (int d = 0; d < 2 * s - 1; d++) {
+        int lo = d - s + 1 > 0 ? d - s + 1 : 0, hi = d < s - 1 ? d : s - 1;
+        if (d % 2) for (int r = lo; r <= hi; r++) zz[i++] = r * s + (d - r);
+        else for (int r = hi; r >= lo; r--) zz[i++] = r * s + (d - r);
+    }
+}
+
+extern "C" int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, const int32_t *qmats_host)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (space < 0 || space > 6) return fail(ctx, AEJ_ERR_ARG, "Unsupported color space id: %d", space);
+    if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 2 || bmax > 128)
+        return fail(ctx, bmax > 128 ? AEJ_ERR_UNSUPPORTED : AEJ_ERR_ARG, "block size range (%d, %d): powers of two in [2, 128] required", bmin, bmax);
+    if (!qmats_host) return fail(ctx, AEJ_ERR_ARG, "qmats_host is NULL");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    int nsizes = 0;
+    for (int s = bmin; s <= bmax; s *= 2) nsizes++;
+    // host image of all tables
+    std::vector<char> blob;
+    auto put = [&](const void *p, size_t bytes) {
+        size_t o = (blob.size() + 255) & ~(size_t)255;
+        blob.resize(o + bytes);
+        memcpy(blob.data() + o, p, bytes);
+        return o;
+    };
+    size_t oD[kMaxSizes], oZ[kMaxSizes], oQ[3][kMaxSizes];
+    int k = 0;
+    size_t qpos = 0;
+    std::vector<size_t> qoff_layer_size;
+    for (int s = bmin; s <= bmax; s *= 2, k++) {
+        std::vector<float> D((size_t)s * s);
+        for (int u = 0; u < s; u++) {
+            double alpha = u == 0 ? sqrt(1.0 / (double)s) : sqrt(2.0 / (double)s);
+            for (int n = 0; n < s; n++) D[(size_t)u * s + n] = (float)(alpha * cos(3.14159265358979323846 * (double)(2 * n + 1) * (double)u / (2.0 * (double)s)));
+        }
+        oD[k] = put(D.data(), D.size() * 4);
+        std::vector<int> zz, inv((size_t)s * s);
+        zigzag_order(s, zz);
+        for (int i = 0; i < s * s; i++) inv[zz[i]] = i;
+        oZ[k] = put(inv.data(), inv.size() * 4);
+    }
+    for (int l = 0; l < 3; l++) {
+        k = 0;
+        for (int s = bmin; s <= bmax; s *= 2, k++) {
+            for (int i = 0; i < s * s; i++)
+                if (qmats_host[qpos + i] < 1) return fail(ctx, AEJ_ERR_ARG, "quantisation matrix entries must be >= 1");
+            oQ[l][k] = put(qmats_host + qpos, (size_t)s * s * 4);
+            qpos += (size_t)s * s;
+        }
+    }
+    // bilateralFilter(d=5, sigmaColor=75, sigmaSpace=75) weights (edge_detection.py:37-39,78; OpenCV bilateral_filter)
+    float sw[16] = { 0 }, cw[256];
+    {
+        double cc = -0.5 / (75.0 * 75.0), sc = -0.5 / (75.0 * 75.0);
+        for (int i = 0; i < 256; i++) cw[i] = (float)exp((double)i * (double)i * cc);
+        int t = 0;
+        for (int i = -2; i <= 2; i++)
+            for (int j = -2; j <= 2; j++) {
+                double r = sqrt((double)i * i + (double)j * j);
+                if (r > 2.0) continue;
+                sw[t++] = (float)exp(r * r * sc);
+            }
+    }
+    size_t oSw = put(sw, sizeof sw), oCw = put(cw, sizeof cw);
+
+    if (ctx->tables) { AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream)); AEJ_HIP_CHECK(hipFree(ctx->tables)); ctx->tables = nullptr; }
+    AEJ_HIP_CHECK(hipMalloc(&ctx->tables, blob.size()));
+    AEJ_HIP_CHECK(hipMemcpy(ctx->tables, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    char *base = static_cast<char *>(ctx->tables);
+    for (int i = 0; i < kMaxSizes; i++) {
+        ctx->d_D[i] = nullptr; ctx->d_zzinv[i] = nullptr;
+        for (int l = 0; l < 3; l++) ctx->d_qm[l][i] = nullptr;
+    }
+    for (int i = 0; i < nsizes; i++) {
+        ctx->d_D[i] = reinterpret_cast<const float *>(base + oD[i]);
+        ctx->d_zzinv[i] = reinterpret_cast<const int *>(base + oZ[i]);
+        for (int l = 0; l < 3; l++) ctx->d_qm[l][i] = reinterpret_cast<const int *>(base + oQ[l][i]);
+    }
+    ctx->d_space_w = reinterpret_cast<const float *>(base + oSw);
+    ctx->d_color_w = reinterpret_cast<const float *>(base + oCw);
+    ctx->space = space; ctx->bmin = bmin; ctx->bmax = bmax; ctx->nsizes = nsizes;
+    ctx->has_settings = true;
+    return 0;
+}
+
+// the bilateral tables are needed by aej_canny even without codec settings
+static int ensure_canny_tables(aej_ctx *ctx)
+{
+    if (ctx->d_color_w) return 0;
+    // default settings of the reference (jpeg.py:150-155) with unit quantisation matrices
+    std::vector<int32_t> q;
+    for (int l = 0; l < 3; l++)
+        for (int s = 4; s <= 64; s *= 2) q.insert(q.end(), (size_t)s * s, 1);
+    int rc = aej_set_settings(ctx, AEJ_YCOCG, 4, 64, q.data());
+    ctx->has_settings = false;
+    return rc;
+}
+
+// ---- Canny chain on a prepared uint8 buffer (cb.u8a) ------------------------------------------------------
+static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, unsigned char *stages_scaled, unsigned char *stages_bilateral,
+                           unsigned char *stages_nms)
+{
+    hipStream_t st = ctx->stream;
+    long long planes = (long long)g.B * g.pstride;
+    if (stages_scaled) AEJ_HIP_CHECK(hipMemcpyAsync(stages_scaled, w.cb.u8a, planes, hipMemcpyDeviceToDevice, st));
+    launch_clahe_pad_hist(st, g, w.cb);
+    launch_clahe_lut(st, g, w.cb);
+    launch_clahe_blur(st, g, w.cb);
+    if (stages_bilateral) AEJ_HIP_CHECK(hipMemcpyAsync(stages_bilateral, w.cb.u8b, planes, hipMemcpyDeviceToDevice, st));
+    launch_thresholds(st, g, w.cb);
+    launch_sobel_nms(st, g, w.cb);
+    if (stages_nms) AEJ_HIP_CHECK(hipMemcpyAsync(stages_nms, w.cb.u8a, planes, hipMemcpyDeviceToDevice, st));
+    // hysteresis: groups of passes, one counter read-back per group
+    const int group = 4;
+    int pass = 0;
+    for (;;) {
+        for (int i = 0; i < group; i++) launch_hyst_pass(st, g, w.cb, pass++);
+        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.cb.pass_changed + (pass - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+        AEJ_HIP_CHECK(hipStreamSynchronize(st));
+        if (*ctx->h_flag == 0) break;
+        if (pass + group > kMaxHystPasses) return fail(ctx, AEJ_ERR_STATE, "hysteresis did not converge in %d passes", pass);
+    }
+    ctx->last_hyst_passes = pass;
+    AEJ_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int clear_canny_ws(aej_ctx *ctx, const CannyWs &w)
+{
+    AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), ctx->stream));
+    AEJ_HIP_CHECK(hipMemsetAsync(w.dirty0, 1, (size_t)w.dirty_n, ctx->stream));
+    AEJ_HIP_CHECK(hipMemsetAsync(w.dirty0 + w.dirty_n, 0, (size_t)w.dirty_n, ctx->stream));
+    return 0;
+}
+
+static int run_quadtree(aej_ctx *ctx, const Geom &g, const QtGeom &q, QtWs &w, const unsigned char *map, int edge_value)
+{
+    hipStream_t st = ctx->stream;
+    AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));
+    launch_qt_cells(st, g, q, map, edge_value, w.qb);
+    launch_qt_count(st, g, q, w.qb);
+    launch_qt_scan(st, g, q, w.qb);
+    launch_qt_emit(st, g, q, w.qb);
+    AEJ_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- whole path ---------------------------------------------------------------------------------------------
+struct EncodeWs {
+    float *norm;
+    CannyWs canny;
+    QtWs qt;
+    unsigned long long bytes;
+};
+
+static void carve_encode(void *base, const Geom &g, const QtGeom &q, EncodeWs &w)
+{
+    Carver c(base);
+    w.norm = c.take<float>((long long)g.B * g.pstride);
+    carve_canny(c, g, w.canny);
+    carve_qt(c, g, q, true, w.qt);
+    w.bytes = (c.off + 255) & ~255ull;
+}
+
+static int check_encode_args(aej_ctx *ctx, int batch, int H, int W)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (!ctx->has_settings) return fail(ctx, AEJ_ERR_STATE, "aej_set_settings has not been called");
+    if (batch < 1 || H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "batch, H, W must be positive");
+    if ((W % 4) != 0 || (H % 2) != 0)
+        return fail(ctx, AEJ_ERR_UNSUPPORTED, "image %dx%d: this build needs W %% 4 == 0 and H %% 2 == 0 (fractional INTER_AREA not built)", H, W);
+    return 0;
+}
+
+extern "C" int aej_encode_plan(aej_ctx *ctx, int batch, int H, int W, aej_plan *plan)
+{
+    int rc = check_encode_args(ctx, batch, H, W);
+    if (rc) return rc;
+    if (!plan) return fail(ctx, AEJ_ERR_ARG, "plan is NULL");
+    Geom g;
+    QtGeom q;
+    if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
+    if ((rc = make_qtgeom(ctx, g, ctx->bmin, ctx->bmax, q))) return rc;
+    EncodeWs w;
+    carve_encode(nullptr, g, q, w);
+    memset(plan, 0, sizeof *plan);
+    plan->batch = batch; plan->H = H; plan->W = W;
+    for (int l = 0; l < 3; l++) {
+        plan->layer_h[l] = g.h[l]; plan->layer_w[l] = g.w[l]; plan->root_size[l] = q.root[l];
+        plan->coeff_off[l] = q.coeff_off[l]; plan->leaf_off[l] = q.leaf_off[l]; plan->state_off[l] = q.state_off[l];
+    }
+    plan->coeff_stride = q.coeff_stride; plan->leaf_stride = q.leaf_stride; plan->state_stride = q.state_stride;
+    plan->workspace_bytes = w.bytes;
+    return 0;
+}
+
+extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                                uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
+{
+    int rc = check_encode_args(ctx, batch, H, W);
+    if (rc) return rc;
+    if (!rgb || !coeffs || !leaves || !states || !counts || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    Geom g;
+    QtGeom q;
+    if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
+    if ((rc = make_qtgeom(ctx, g, ctx->bmin, ctx->bmax, q))) return rc;
+    EncodeWs w;
+    carve_encode(workspace, g, q, w);
+    if (w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", w.bytes, (unsigned long long)workspace_bytes);
+    hipStream_t st = ctx->stream;
+    w.canny.cb.space_w = ctx->d_space_w;
+    w.canny.cb.color_w = ctx->d_color_w;
+    if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
+
+    float mid[3], scale[3];
+    for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
+    if (launch_color_planes(st, ctx->space, rgb, g, mid, scale, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist))
+        return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+    if ((rc = run_canny_chain(ctx, g, w.canny, nullptr, nullptr, nullptr))) return rc;
+
+    w.qt.qb.leaves = leaves;
+    w.qt.qb.states = states;
+    w.qt.qb.counts = reinterpret_cast<long long *>(counts);
+    if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.u8a, 2))) return rc;
+
+    int k = 0;
+    for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
+        DctArgs a;
+        a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
+        a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count + k;
+        a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
+        for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
+        launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k]);
+    }
+    AEJ_HIP_CHECK(hipGetLastError());
+    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qt.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    AEJ_HIP_CHECK(hipStreamSynchronize(st));
+    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
+    return 0;
+}
+
+// ---- stage entry points ---------------------------------------------------------------------------------------
+extern "C" int aej_color_convert(aej_ctx *ctx, int space, const float *rgb, float *out, int64_t n)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (n < 0 || (n > 0 && (!rgb || !out))) return fail(ctx, AEJ_ERR_ARG, "bad buffer");
+    if (n == 0) return 0;
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    if (launch_color_convert(ctx->stream, space, rgb, out, n)) return fail(ctx, AEJ_ERR_ARG, "Invalid color space id %d", space);
+    AEJ_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int aej_color_planes(aej_ctx *ctx, const float *rgb, int batch, int H, int W, float *planes_raw, float *planes_norm,
+                                uint8_t *planes_u8)
+{
+    int rc = check_encode_args(ctx, batch, H, W);
+    if (rc) return rc;
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    Geom g;
+    if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
+    float mid[3], scale[3];
+    for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
+    if (launch_color_planes(ctx->stream, ctx->space, rgb, g, mid, scale, planes_raw, planes_norm, planes_u8, nullptr))
+        return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+    AEJ_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" uint64_t aej_canny_workspace_bytes(int H, int W)
+{
+    if (H < 1 || W < 1) return 0;
+    Geom g;
+    make_plane_geom(H, W, g);
+    Carver c(nullptr);
+    CannyWs w;
+    carve_canny(c, g, w);
+    return (c.off + 255) & ~255ull;
+}
+
+extern "C" int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t *edge, uint8_t *stages, int32_t *thresholds,
+                         void *workspace, uint64_t workspace_bytes)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "Input array must be a 2D.");
+    if (!plane || !edge || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    if (workspace_bytes < aej_canny_workspace_bytes(H, W)) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ensure_canny_tables(ctx);
+    if (rc) return rc;
+    Geom g;
+    make_plane_geom(H, W, g);
+    Carver c(workspace);
+    CannyWs w;
+    carve_canny(c, g, w);
+    w.cb.space_w = ctx->d_space_w;
+    w.cb.color_w = ctx->d_color_w;
+    long long n = (long long)H * W;
+    if (stages) { w.cb.dump_clahe = stages + n; w.cb.dump_gauss = stages + 2 * n; }
+    if ((rc = clear_canny_ws(ctx, w))) return rc;
+    launch_plane_u8(ctx->stream, plane, g, w.cb.u8a, w.cb.tile_hist);
+    // stage dumps are H*W bytes each; the plane buffers are padded to 64, so copy exactly n bytes
+    hipStream_t st = ctx->stream;
+    if (stages) AEJ_HIP_CHECK(hipMemcpyAsync(stages, w.cb.u8a, n, hipMemcpyDeviceToDevice, st));
+    launch_clahe_pad_hist(st, g, w.cb);
+    launch_clahe_lut(st, g, w.cb);
+    launch_clahe_blur(st, g, w.cb);
+    if (stages) AEJ_HIP_CHECK(hipMemcpyAsync(stages + 3 * n, w.cb.u8b, n, hipMemcpyDeviceToDevice, st));
+    launch_thresholds(st, g, w.cb);
+    if (thresholds) AEJ_HIP_CHECK(hipMemcpyAsync(thresholds, w.cb.thr, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
+    launch_sobel_nms(st, g, w.cb);
+    if (stages) AEJ_HIP_CHECK(hipMemcpyAsync(stages + 4 * n, w.cb.u8a, n, hipMemcpyDeviceToDevice, st));
+    const int group = 4;
+    int pass = 0;
+    for (;;) {
+        for (int i = 0; i < group; i++) launch_hyst_pass(st, g, w.cb, pass++);
+        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.cb.pass_changed + (pass - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+        AEJ_HIP_CHECK(hipStreamSynchronize(st));
+        if (*ctx->h_flag == 0) break;
+        if (pass + group > kMaxHystPasses) return fail(ctx, AEJ_ERR_STATE, "hysteresis did not converge in %d passes", pass);
+    }
+    ctx->last_hyst_passes = pass;
+    Geom ge = g;
+    ge.pstride = n;   // edge output is exactly H*W
+    launch_edge_final(st, ge, w.cb.u8a, edge);
+    AEJ_HIP_CHECK(hipGetLastError());
+    AEJ_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int aej_quadtree_capacity(int H, int W, int min_size, int max_size, int64_t *leaf_cap, int64_t *state_cap, int64_t *coeff_cap)
+{
+    if (H < 1 || W < 1) return AEJ_ERR_ARG;
+    Geom g;
+    make_plane_geom(H, W, g);
+    QtGeom q;
+    int rc = make_qtgeom(nullptr, g, min_size, max_size, q);
+    if (rc) return rc;
+    if (leaf_cap) *leaf_cap = q.leaf_cap[0];
+    if (state_cap) *state_cap = q.state_cap[0];
+    if (coeff_cap) *coeff_cap = q.coeff_cap[0];
+    return 0;
+}
+
+extern "C" uint64_t aej_quadtree_workspace_bytes(int H, int W, int min_size, int max_size)
+{
+    if (H < 1 || W < 1) return 0;
+    Geom g;
+    make_plane_geom(H, W, g);
+    QtGeom q;
+    if (make_qtgeom(nullptr, g, min_size, max_size, q)) return 0;
+    Carver c(nullptr);
+    QtWs w;
+    carve_qt(c, g, q, false, w);
+    return (c.off + 255) & ~255ull;
+}
+
+extern "C" int aej_quadtree(aej_ctx *ctx, const uint8_t *edge, int H, int W, int min_size, int max_size, int32_t *leaves,
+                            uint8_t *states, int64_t *counts, void *workspace, uint64_t workspace_bytes)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "Input array must be a 2D with a single channel.");
+    if (!edge || !leaves || !states || !counts || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    Geom g;
+    make_plane_geom(H, W, g);
+    g.pstride = (long long)H * W;
+    QtGeom q;
+    int rc = make_qtgeom(ctx, g, min_size, max_size, q);
+    if (rc) return rc;
+    Carver c(workspace);
+    QtWs w;
+    carve_qt(c, g, q, false, w);
+    if (((c.off + 255) & ~255ull) > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
+    w.qb.leaves = leaves; w.qb.states = states; w.qb.counts = reinterpret_cast<long long *>(counts);
+    if ((rc = run_quadtree(ctx, g, q, w, edge, 1))) return rc;
+    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "leaf/state capacity exceeded");
+    return 0;
+}
+
+extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, int layer, const int32_t *leaves, int64_t n_leaves,
+                                    int32_t *coeffs, float *dct_f32)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (!ctx->has_settings) return fail(ctx, AEJ_ERR_STATE, "aej_set_settings has not been called");
+    if (H < 1 || W < 1 || layer < 0 || layer > 2 || n_leaves < 0) return fail(ctx, AEJ_ERR_ARG, "bad argument");
+    if (n_leaves == 0) return 0;
+    if (!norm || !leaves || !coeffs) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // geometry: a single image whose `layer` is the given plane
+    Geom g;
+    memset(&g, 0, sizeof g);
+    g.B = 1; g.nl = 3; g.H = H; g.W = W;
+    for (int l = 0; l < 3; l++) { g.h[l] = H; g.w[l] = W; g.rh[l] = g.rw[l] = 1; g.poff[l] = 0; }
+    g.pstride = (long long)H * W;
+    QtGeom q;
+    memset(&q, 0, sizeof q);
+    q.bmin = ctx->bmin; q.bmax = ctx->bmax; q.cell = ctx->bmin;
+    // stage-only scratch (not on the hot path): per-size work lists
+    char *scratch = nullptr;
+    size_t list_bytes = (size_t)n_leaves * sizeof(LeafWork);
+    size_t total = 256 + (size_t)ctx->nsizes * ((list_bytes + 255) & ~(size_t)255);
+    AEJ_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&scratch), total));
+    int *work_count = reinterpret_cast<int *>(scratch);
+    LeafWork *work[kMaxSizes] = {};
+    for (int k = 0; k < ctx->nsizes; k++) work[k] = reinterpret_cast<LeafWork *>(scratch + 256 + (size_t)k * ((list_bytes + 255) & ~(size_t)255));
+    hipError_t e = hipMemsetAsync(scratch, 0, 256, st);
+    if (e == hipSuccess) {
+        launch_work_from_leaves(st, leaves, n_leaves, ctx->bmin, layer, work, work_count);
+        int k = 0;
+        for (int s = ctx->bmin; s <= ctx->bmax; s *= 2, k++) {
+            DctArgs a;
+            a.norm = norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
+            a.work = work[k]; a.work_count = work_count + k;
+            a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
+            for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
+            launch_dct(st, s, g, q, a, n_leaves);
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(scratch);
+    if (e != hipSuccess) return fail(ctx, AEJ_ERR_HIP, "aej_dct_quant_zigzag: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int aej_last_hysteresis_passes(aej_ctx *ctx) { return ctx ? ctx->last_hyst_passes : -1; }

@@ -1,0 +1,402 @@
+// color.hip -- colour conversion (a-1), chroma down-sampling (a-2), uint8 scaling (a-3) and the CLAHE
+// tile histograms, fused into one pass over the float32 RGB input.  gfx950 only.
+//
+// Replaces, for the encode path:  color.convert("sRGB", space, x)  (src/color/conversion.py:95-124 and the
+// per-space files), Jpeg._downsample (src/jpeg/jpeg.py:323-338), apply_normalization
+// (src/color/common.py:161-174 via jpeg.py:387-390) and (img*255).astype(uint8) (src/jpeg/edge_detection.py:70).
+//
+// Numerics contract: every float op below is a single IEEE-754 operation in a fixed order
+// (compiled with -ffp-contract=off; fma only where written), so results are bit-identical to the CPU oracle.
+#include "aej_common.h"
+#include "aej_launch.h"
+
+namespace aej {
+
+// ------------------------------------------------------------------------------------------------
+// deterministic pow (same recipe as the contract in DESIGN.md: atanh-series log2, Taylor exp2)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dev_log2(double x)
+{
+    long long b = __double_as_longlong(x);
+    int e = (int)(b >> 52) - 1023;
+    double m = __longlong_as_double((b & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    double z = (m - 1.0) / (m + 1.0);
+    double z2 = z * z;
+    double p = 2.0 / 25.0;
+    p = fma(p, z2, 2.0 / 23.0);
+    p = fma(p, z2, 2.0 / 21.0);
+    p = fma(p, z2, 2.0 / 19.0);
+    p = fma(p, z2, 2.0 / 17.0);
+    p = fma(p, z2, 2.0 / 15.0);
+    p = fma(p, z2, 2.0 / 13.0);
+    p = fma(p, z2, 2.0 / 11.0);
+    p = fma(p, z2, 2.0 / 9.0);
+    p = fma(p, z2, 2.0 / 7.0);
+    p = fma(p, z2, 2.0 / 5.0);
+    p = fma(p, z2, 2.0 / 3.0);
+    p = fma(p, z2, 2.0);
+    double lnm = z * p;
+    return fma(lnm, 1.4426950408889634, (double)e);
+}
+
+__device__ __forceinline__ double dev_exp2(double t)
+{
+    double n = rint(t);
+    double r = (t - n) * 0.6931471805599453;
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    long long ni = (long long)n;
+    if (ni < -1022) return 0.0;
+    if (ni > 1023) return __longlong_as_double(0x7FF0000000000000ll);
+    return p * __longlong_as_double((ni + 1023) << 52);
+}
+
+__device__ __forceinline__ double dev_pow(double x, double y)
+{
+    if (x == 0.0) return 0.0;
+    if (!(x > 0.0)) return __longlong_as_double(0x7FF8000000000000ll);
+    if (x < 2.2250738585072014e-308) return 0.0;
+    return dev_exp2(y * dev_log2(x));
+}
+
+// ------------------------------------------------------------------------------------------------
+// matrices: float32(value) of the Python literals (numpy: np.array([...], dtype=np.float32))
+// ------------------------------------------------------------------------------------------------
+#define F(x) ((float)(x))
+__device__ __forceinline__ float dot3(float m0, float m1, float m2, float a, float b, float c)
+{
+    float acc = a * m0;               // np.dot float32: k-ordered fma chain (OpenBLAS sgemm)
+    acc = __builtin_fmaf(b, m1, acc);
+    return __builtin_fmaf(c, m2, acc);
+}
+__device__ __forceinline__ float lin3(float m0, float m1, float m2, float X, float Y, float Z)
+{
+    float t = m0 * X;
+    float u = m1 * Y;
+    t = t + u;
+    u = m2 * Z;
+    return t + u;
+}
+__device__ __forceinline__ double lin3d(float m0, float m1, float m2, double a, double b, double c)
+{
+    double t = (double)m0 * a;
+    double u = (double)m1 * b;
+    t = t + u;
+    u = (double)m2 * c;
+    return t + u;
+}
+__device__ __forceinline__ float srgb_to_linear(float v)   // common.py:34-60 (float64 under numba typing)
+{
+    double d = (double)v;
+    if (d <= 0.04045) return (float)(d / 12.92);
+    return (float)dev_pow((d + 0.055) / 1.055, 2.4);
+}
+__device__ __forceinline__ double pq_inverse_eotf(double v, double m2)   // common.py:131-159
+{
+    const double c1 = 3424.0 / 4096.0, c2 = 2413.0 / 128.0, c3 = 2392.0 / 128.0, m1 = 2610.0 / 16384.0;
+    double tmp = dev_pow(v / 10000.0, m1);
+    double num = c1 + c2 * tmp;
+    double den = 1.0 + c3 * tmp;
+    return dev_pow(num / den, m2);
+}
+
+__device__ __forceinline__ void to_xyz(float r, float g, float b, float &X, float &Y, float &Z)   // xyz.py:27-32, 63-64
+{
+    float lr = srgb_to_linear(r), lg = srgb_to_linear(g), lb = srgb_to_linear(b);
+    X = dot3(F(0.4124564), F(0.3575761), F(0.1804375), lr, lg, lb);
+    Y = dot3(F(0.2126729), F(0.7151522), F(0.0721750), lr, lg, lb);
+    Z = dot3(F(0.0193339), F(0.1191920), F(0.9503041), lr, lg, lb);
+}
+
+template <int SPACE>
+__device__ __forceinline__ void color_px(float r, float g, float b, float &o0, float &o1, float &o2)
+{
+    if constexpr (SPACE == 0) {          // YCbCr, ycbcr.py:25-30, 61
+        o0 = dot3(F(0.299000), F(0.587000), F(0.114000), r, g, b);
+        o1 = dot3(F(-0.168736), F(-0.331264), F(0.500000), r, g, b);
+        o2 = dot3(F(0.500000), F(-0.418688), F(-0.081312), r, g, b);
+    } else if constexpr (SPACE == 1) {   // YCoCg, ycocg.py:25-30, 82
+        o0 = dot3(F(0.25), F(0.50), F(0.25), r, g, b);
+        o1 = dot3(F(0.50), F(0.00), F(-0.50), r, g, b);
+        o2 = dot3(F(-0.25), F(0.50), F(-0.25), r, g, b);
+    } else if constexpr (SPACE == 2) {   // YCoCg-R, ycocg.py:46-51, 121
+        o0 = dot3(F(0.25), F(0.50), F(0.25), r, g, b);
+        o1 = dot3(F(1.00), F(0.00), F(-1.00), r, g, b);
+        o2 = dot3(F(-0.50), F(1.00), F(-0.50), r, g, b);
+    } else if constexpr (SPACE == 3) {   // OKLAB, oklab.py:27-44, 71-75
+        float X, Y, Z;
+        to_xyz(r, g, b, X, Y, Z);
+        float l = dot3(F(0.8189330101), F(0.3618667424), F(-0.1288597137), X, Y, Z);
+        float m = dot3(F(0.0329845436), F(0.9293118715), F(0.0361456387), X, Y, Z);
+        float s = dot3(F(0.0482003018), F(0.2643662691), F(0.6338517070), X, Y, Z);
+        const double third = (double)(float)(1.0 / 3.0);
+        float lp = (float)dev_pow((double)l, third), mp = (float)dev_pow((double)m, third), sp = (float)dev_pow((double)s, third);
+        o0 = dot3(F(0.2104542553), F(0.7936177850), F(-0.0040720468), lp, mp, sp);
+        o1 = dot3(F(1.9779984951), F(-2.4285922050), F(0.4505937099), lp, mp, sp);
+        o2 = dot3(F(0.0259040371), F(0.7827717662), F(-0.8086757660), lp, mp, sp);
+    } else if constexpr (SPACE == 4 || SPACE == 5) {   // ICtCp ictcp.py:45-81,142-157 / ICaCb icacb.py:45-81,142-157
+        float X, Y, Z;
+        to_xyz(r, g, b, X, Y, Z);
+        float L, M, S;
+        if constexpr (SPACE == 4) {
+            L = lin3(F(0.3592), F(0.6976), F(-0.0358), X, Y, Z);
+            M = lin3(F(-0.1922), F(1.1004), F(0.0755), X, Y, Z);
+            S = lin3(F(0.0070), F(0.0749), F(0.8434), X, Y, Z);
+        } else {
+            L = lin3(F(0.37613), F(0.70431), F(-0.05675), X, Y, Z);
+            M = lin3(F(-0.21649), F(1.14744), F(0.05356), X, Y, Z);
+            S = lin3(F(0.02567), F(0.16713), F(0.74235), X, Y, Z);
+        }
+        const double pm2 = 2523.0 / 32.0;
+        double Lp = pq_inverse_eotf((double)L, pm2), Mp = pq_inverse_eotf((double)M, pm2), Sp = pq_inverse_eotf((double)S, pm2);
+        if constexpr (SPACE == 4) {
+            o0 = (float)lin3d(F(0.5000), F(0.5000), F(0.0000), Lp, Mp, Sp);
+            o1 = (float)lin3d(F(1.6137), F(-3.3234), F(1.7097), Lp, Mp, Sp);
+            o2 = (float)lin3d(F(4.3781), F(-4.2455), F(-0.1325), Lp, Mp, Sp);
+        } else {
+            o0 = (float)lin3d(F(0.4949), F(0.5037), F(0.0015), Lp, Mp, Sp);
+            o1 = (float)lin3d(F(4.2854), F(-4.5462), F(0.2609), Lp, Mp, Sp);
+            o2 = (float)lin3d(F(0.3605), F(1.1499), F(-1.5105), Lp, Mp, Sp);
+        }
+    } else {                              // JzAzBz, jzazbz.py:54-99, 178-206
+        float X, Y, Z;
+        to_xyz(r, g, b, X, Y, Z);
+        const double bb = 1.15, gg = 0.66, d = -0.56, d0 = 1.6295499532821566e-11, p = 1.7 * 2523.0 / 32.0;
+        double Xp = bb * (double)X - (bb - 1.0) * (double)Z;
+        double Yp = gg * (double)Y - (gg - 1.0) * (double)X;
+        // numba typing: M[i,2] * Z_p is float32*float32 -> float32; the other products are float64
+        double L = ((double)F(0.41478972) * Xp + (double)F(0.579999) * Yp) + (double)(F(0.0146480) * Z);
+        double M = ((double)F(-0.2015100) * Xp + (double)F(1.120649) * Yp) + (double)(F(0.0531008) * Z);
+        double S = ((double)F(-0.0166008) * Xp + (double)F(0.264800) * Yp) + (double)(F(0.6684799) * Z);
+        double Lp = pq_inverse_eotf(L, p), Mp = pq_inverse_eotf(M, p), Sp = pq_inverse_eotf(S, p);
+        double Iz = lin3d(F(0.500000), F(0.500000), F(0.000000), Lp, Mp, Sp);
+        double Az = lin3d(F(3.524000), F(-4.066708), F(0.542708), Lp, Mp, Sp);
+        double Bz = lin3d(F(0.199076), F(1.096799), F(-1.295875), Lp, Mp, Sp);
+        double Jz = ((1.0 + d) * Iz) / (1.0 + d * Iz) - d0;
+        o0 = (float)Jz; o1 = (float)Az; o2 = (float)Bz;
+    }
+}
+
+// a-3: (v*255).astype(uint8): float32 multiply, truncate toward zero, keep the low byte
+__device__ __forceinline__ unsigned char scale_u8(float v)
+{
+    float s = v * 255.0f;
+    int t = (int)s;
+    return (unsigned char)(t & 0xFF);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone colour conversion: [n][3] -> [n][3]
+// ------------------------------------------------------------------------------------------------
+template <int SPACE>
+__global__ __launch_bounds__(256) void k_color_convert(const float *__restrict__ rgb, float *__restrict__ out, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        float o0, o1, o2;
+        color_px<SPACE>(r, g, b, o0, o1, o2);
+        out[3 * i] = o0; out[3 * i + 1] = o1; out[3 * i + 2] = o2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused: RGB -> 3 layers (normalised float32 + uint8 + optional raw float32) + CLAHE tile histograms.
+// One thread = a 4 (wide) x 2 (tall) pixel patch; a 256-thread block = 128 x 16 pixels.
+// Layout: lanes run along x, so a wave reads 32 x 48 B = 1.5 KiB contiguous bytes per image row.
+// ------------------------------------------------------------------------------------------------
+struct NormConst { float mid[3]; float scale[3]; };
+
+__device__ __forceinline__ void hist_add(int *lds_hist, int *__restrict__ ghist, int layer, int tx0, int ty0, int tx, int ty, int v)
+{
+    int dx = tx - tx0, dy = ty - ty0;
+    if ((unsigned)dx < 2u && (unsigned)dy < 2u) atomicAdd(&lds_hist[((layer * 4) + dy * 2 + dx) * 256 + v], 1);
+    else atomicAdd(&ghist[((layer * 16) + ty * 4 + tx) * 256 + v], 1);
+}
+
+template <int SPACE, int RH, int RW>
+__global__ __launch_bounds__(256) void k_color_planes(const float *__restrict__ rgb, Geom g, NormConst nc,
+                                                      float *__restrict__ planes_raw, float *__restrict__ planes_norm,
+                                                      unsigned char *__restrict__ planes_u8, int *__restrict__ tile_hist)
+{
+    __shared__ int s_hist[3 * 4 * 256];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int px = (blockIdx.x * 32 + (tid & 31)) * 4;
+    const int py = (blockIdx.y * 8 + (tid >> 5)) * 2;
+    const bool do_hist = tile_hist != nullptr;
+    if (do_hist) {
+        for (int i = tid; i < 3 * 4 * 256; i += 256) s_hist[i] = 0;
+        __syncthreads();
+    }
+    // first CLAHE tile touched by this block, per layer
+    const int bx0 = blockIdx.x * 128, by0 = blockIdx.y * 16;
+    const int tx0_l = bx0 / g.ctw[0], ty0_l = by0 / g.cth[0];
+    const int tx0_c = (bx0 / RW) / g.ctw[1], ty0_c = (by0 / RH) / g.cth[1];
+    int *ghist = do_hist ? tile_hist + (long long)b * 3 * 16 * 256 : nullptr;
+
+    if (px < g.W && py < g.H) {
+        float c0[2][4], c1[2][4], c2[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const float4 *p = reinterpret_cast<const float4 *>(rgb + (((long long)b * g.H + (py + r)) * g.W + px) * 3);
+            float4 a = p[0], bq = p[1], c = p[2];
+            float in[12] = { a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x, c.y, c.z, c.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) color_px<SPACE>(in[3 * k], in[3 * k + 1], in[3 * k + 2], c0[r][k], c1[r][k], c2[r][k]);
+        }
+        const long long ibase = (long long)b * g.pstride;
+        // ---- layer 0 (luma): ratio 1x1 => copy
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            long long o = ibase + g.poff[0] + (long long)(py + r) * g.w[0] + px;
+            float4 nv;
+            nv.x = (c0[r][0] - nc.mid[0]) * nc.scale[0];
+            nv.y = (c0[r][1] - nc.mid[0]) * nc.scale[0];
+            nv.z = (c0[r][2] - nc.mid[0]) * nc.scale[0];
+            nv.w = (c0[r][3] - nc.mid[0]) * nc.scale[0];
+            if (planes_norm) *reinterpret_cast<float4 *>(planes_norm + o) = nv;
+            if (planes_raw) *reinterpret_cast<float4 *>(planes_raw + o) = make_float4(c0[r][0], c0[r][1], c0[r][2], c0[r][3]);
+            uchar4 u;
+            u.x = scale_u8(c0[r][0]); u.y = scale_u8(c0[r][1]); u.z = scale_u8(c0[r][2]); u.w = scale_u8(c0[r][3]);
+            if (planes_u8) *reinterpret_cast<uchar4 *>(planes_u8 + o) = u;
+            if (do_hist) {
+                int ty = (py + r) / g.cth[0];
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 0) / g.ctw[0], ty, u.x);
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 1) / g.ctw[0], ty, u.y);
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 2) / g.ctw[0], ty, u.z);
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 3) / g.ctw[0], ty, u.w);
+            }
+        }
+        // ---- layers 1, 2 (chroma): INTER_AREA box mean
+#pragma unroll
+        for (int ch = 1; ch < 3; ch++) {
+            float(*cc)[4] = ch == 1 ? c1 : c2;
+            float v[2];
+            int cx, cy[2];
+            if constexpr (RH == 2 && RW == 2) {      // ((r0e+r0o)+(r1e+r1o))*0.25f
+                v[0] = ((cc[0][0] + cc[0][1]) + (cc[1][0] + cc[1][1])) * 0.25f;
+                v[1] = ((cc[0][2] + cc[0][3]) + (cc[1][2] + cc[1][3])) * 0.25f;
+                cx = px / 2; cy[0] = cy[1] = py / 2;
+            } else {                                  // RH == 1, RW == 4: sequential sum * (1/4)
+                v[0] = (((cc[0][0] + cc[0][1]) + cc[0][2]) + cc[0][3]) * 0.25f;
+                v[1] = (((cc[1][0] + cc[1][1]) + cc[1][2]) + cc[1][3]) * 0.25f;
+                cx = px / 4; cy[0] = py; cy[1] = py + 1;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                int x = (RH == 2) ? cx + q : cx;
+                int y = cy[q];
+                long long o = ibase + g.poff[ch] + (long long)y * g.w[ch] + x;
+                if (planes_norm) planes_norm[o] = (v[q] - nc.mid[ch]) * nc.scale[ch];
+                if (planes_raw) planes_raw[o] = v[q];
+                unsigned char u = scale_u8(v[q]);
+                if (planes_u8) planes_u8[o] = u;
+                if (do_hist) hist_add(s_hist, ghist, ch, tx0_c, ty0_c, x / g.ctw[ch], y / g.cth[ch], u);
+            }
+        }
+    }
+    if (do_hist) {
+        __syncthreads();
+        for (int i = tid; i < 3 * 4 * 256; i += 256) {
+            int c = s_hist[i];
+            if (c) {
+                int layer = i / 1024, t = (i >> 8) & 3, v = i & 255;
+                int tx = (layer == 0 ? tx0_l : tx0_c) + (t & 1), ty = (layer == 0 ? ty0_l : ty0_c) + (t >> 1);
+                if (tx < 4 && ty < 4) atomicAdd(&ghist[((layer * 16) + ty * 4 + tx) * 256 + v], c);
+            }
+        }
+    }
+}
+
+// stand-alone a-3 for one float32 plane (EdgeDetection.canny entry): uint8 + CLAHE tile histograms
+__global__ __launch_bounds__(256) void k_plane_u8(const float *__restrict__ plane, Geom g, unsigned char *__restrict__ u8,
+                                                  int *__restrict__ tile_hist)
+{
+    long long n = (long long)g.h[0] * g.w[0];
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned char v = scale_u8(plane[i]);
+        u8[i] = v;
+        int y = (int)(i / g.w[0]), x = (int)(i - (long long)y * g.w[0]);
+        atomicAdd(&tile_hist[((y / g.cth[0]) * 4 + (x / g.ctw[0])) * 256 + v], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <int SPACE>
+static void launch_convert_t(hipStream_t st, const float *rgb, float *out, long long n)
+{
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_color_convert<SPACE>, dim3(blocks), dim3(256), 0, st, rgb, out, n);
+}
+
+int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out, long long n)
+{
+    switch (space) {
+    case 0: launch_convert_t<0>(st, rgb, out, n); break;
+    case 1: launch_convert_t<1>(st, rgb, out, n); break;
+    case 2: launch_convert_t<2>(st, rgb, out, n); break;
+    case 3: launch_convert_t<3>(st, rgb, out, n); break;
+    case 4: launch_convert_t<4>(st, rgb, out, n); break;
+    case 5: launch_convert_t<5>(st, rgb, out, n); break;
+    case 6: launch_convert_t<6>(st, rgb, out, n); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+template <int SPACE, int RH, int RW>
+static void launch_planes_t(hipStream_t st, const float *rgb, const Geom &g, const NormConst &nc, float *raw, float *norm,
+                            unsigned char *u8, int *hist)
+{
+    dim3 grid((g.W + 127) / 128, (g.H + 15) / 16, g.B);
+    hipLaunchKernelGGL((k_color_planes<SPACE, RH, RW>), grid, dim3(256), 0, st, rgb, g, nc, raw, norm, u8, hist);
+}
+
+int launch_color_planes(hipStream_t st, int space, const float *rgb, const Geom &g, const float *mid, const float *scale,
+                        float *raw, float *norm, unsigned char *u8, int *hist)
+{
+    NormConst nc;
+    for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
+    switch (space) {
+    case 0: launch_planes_t<0, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    case 1: launch_planes_t<1, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    case 2: launch_planes_t<2, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    case 3: launch_planes_t<3, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    case 4: launch_planes_t<4, 1, 4>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    case 5: launch_planes_t<5, 1, 4>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    case 6: launch_planes_t<6, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+void launch_plane_u8(hipStream_t st, const float *plane, const Geom &g, unsigned char *u8, int *hist)
+{
+    long long n = (long long)g.h[0] * g.w[0];
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_plane_u8, dim3(blocks), dim3(256), 0, st, plane, g, u8, hist);
+}
+
+}  // namespace aej

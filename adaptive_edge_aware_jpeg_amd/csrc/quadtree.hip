@@ -1,0 +1,317 @@
+// quadtree.hip -- QuadTree._build_tree + get_leaves_and_states (src/jpeg/quadtree.py:93-165) without a
+// tree walk.  gfx950 only.
+//
+// The reference splits top-down with an explicit stack; a node (x, y, s) splits iff
+//     s > max_size  or  (s > min_size and any(edge[y:y+s, x:x+s])).
+// Order-free restatement used here (equivalence is checked against the reference-generated golden cases):
+//   * "any(edge)" over aligned squares is an OR-pyramid over min-size cells;
+//   * the pre-order DFS sequence of (internal '01' / leaf '00' / out-of-bounds child '10') symbols is the
+//     sequence of all existing nodes sorted by (Morton code of origin, descending size), so a cell in Morton
+//     order emits the nodes that *originate* at it, largest first;
+//   * leaves in DFS order are therefore in ascending Morton order of their origin cell.
+// Three passes over 256-cell (16x16, Morton-aligned) chunks: OR-pyramid, per-chunk counts, prefix sums, emit.
+#include "aej_common.h"
+#include "aej_launch.h"
+
+namespace aej {
+
+__device__ __forceinline__ unsigned compact1by1(unsigned v)
+{
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    v = (v | (v >> 8)) & 0x0000FFFFu;
+    return v;
+}
+// Morton code with x in the even bits, y in the odd bits (children order TL, TR, BL, BR: quadtree.py:123-131)
+__device__ __forceinline__ void morton_decode(unsigned m, int &x, int &y) { x = (int)compact1by1(m); y = (int)compact1by1(m >> 1); }
+
+__device__ __forceinline__ long long lvl_off(int ncell, int lv)
+{
+    long long o = 0;
+    for (int j = 0; j < lv; j++) { long long s = ncell >> j; o += s * s; }
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: OR-pyramid.  One block per chunk of 16x16 cells; levels 0..4 reduced in LDS, higher levels
+// (only those that can still matter, cell<<lv <= bmax) are set with idempotent stores of 1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_qt_cells(Geom g, QtGeom q, const unsigned char *__restrict__ map, int edge_value,
+                                                  unsigned char *__restrict__ pyr_all)
+{
+    __shared__ unsigned char lv[5][256];
+    const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
+    const int ncell = q.ncell[l], ltot = q.ltot[l], cell = q.cell;
+    const long long ncell2 = (long long)ncell * ncell;
+    if ((long long)blockIdx.x * 256 >= ncell2) return;
+    const int w = g.w[l], h = g.h[l];
+    int ccx, ccy;
+    morton_decode(blockIdx.x, ccx, ccy);
+    ccx *= 16; ccy *= 16;
+    if (ccx * cell >= w || ccy * cell >= h) return;   // chunk origin out of bounds => whole chunk is
+    int lx, ly;
+    morton_decode(tid, lx, ly);
+    const int cx = ccx + lx, cy = ccy + ly;
+    const unsigned char *src = map + (long long)b * g.pstride + g.poff[l];
+    unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
+    const bool valid = (long long)tid < ncell2;
+    unsigned char e = 0;
+    if (valid) {
+        int x0 = cx * cell, y0 = cy * cell;
+        int x1 = min(x0 + cell, w), y1 = min(y0 + cell, h);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) e |= (src[(long long)y * w + x] == edge_value) ? 1 : 0;
+        pyr[(long long)cy * ncell + cx] = e;
+    }
+    lv[0][tid] = e;
+    __syncthreads();
+    const int lmax_in = ltot < 4 ? ltot : 4;
+    for (int k = 1; k <= lmax_in; k++) {
+        int n = 256 >> (2 * k);
+        if (tid < n) {
+            unsigned char v = lv[k - 1][4 * tid] | lv[k - 1][4 * tid + 1] | lv[k - 1][4 * tid + 2] | lv[k - 1][4 * tid + 3];
+            lv[k][tid] = v;
+            int mx, my;
+            morton_decode(tid, mx, my);
+            int side = ncell >> k;
+            int px = (ccx >> k) + mx, py = (ccy >> k) + my;
+            if (px < side && py < side) pyr[lvl_off(ncell, k) + (long long)py * side + px] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && ltot > 4 && lv[4][0]) {
+        for (int k = 5; k <= ltot && (cell << k) <= q.bmax; k++) {
+            int side = ncell >> k;
+            pyr[lvl_off(ncell, k) + (long long)(ccy >> k) * side + (ccx >> k)] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-cell node evaluation shared by the count and emit passes
+// ------------------------------------------------------------------------------------------------
+struct CellNodes {
+    int nsym;        // number of symbols originating at this cell
+    unsigned syms;   // 2 bits per symbol, first emitted in the low bits
+    int leaf_lvl;    // level of the leaf originating here, or -1
+};
+
+__device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, int h, const unsigned char *__restrict__ pyr, unsigned gidx)
+{
+    CellNodes r;
+    r.nsym = 0; r.syms = 0; r.leaf_lvl = -1;
+    const int ncell = q.ncell[l], ltot = q.ltot[l], cell = q.cell;
+    int cx, cy;
+    morton_decode(gidx, cx, cy);
+    int a = gidx == 0 ? ltot : min((int)(__ffs(gidx) - 1) >> 1, ltot);
+    if (a < ltot) {
+        // the level-a node exists only if its parent is in bounds and splits
+        int mask = ~((2 << a) - 1);
+        int pcx = cx & mask, pcy = cy & mask;
+        if (pcx * cell >= w || pcy * cell >= h) return r;
+        int psize = cell << (a + 1);
+        bool psplit = psize > q.bmax;
+        if (!psplit && psize > q.bmin) {
+            int side = ncell >> (a + 1);
+            psplit = pyr[lvl_off(ncell, a + 1) + (long long)(cy >> (a + 1)) * side + (cx >> (a + 1))] != 0;
+        }
+        if (!psplit) return r;
+    }
+    if (cx * cell >= w || cy * cell >= h) {   // quadtree.py:109-110, 153-155: absent child
+        r.nsym = 1; r.syms = 2u;
+        return r;
+    }
+    for (int lvn = a; lvn >= 0; lvn--) {
+        int size = cell << lvn;
+        bool split = size > q.bmax;
+        if (!split && size > q.bmin) {
+            int side = ncell >> lvn;
+            split = pyr[lvl_off(ncell, lvn) + (long long)(cy >> lvn) * side + (cx >> lvn)] != 0;
+        }
+        if (split) {
+            r.syms |= 1u << (2 * r.nsym);
+            r.nsym++;
+        } else {
+            r.nsym++;          // '00'
+            r.leaf_lvl = lvn;
+            break;
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int tid, int &total)
+{
+    // 256-thread exclusive scan via LDS
+    s_tmp[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int t = tid >= o ? s_tmp[tid - o] : 0;
+        __syncthreads();
+        s_tmp[tid] += t;
+        __syncthreads();
+    }
+    int incl = s_tmp[tid];
+    total = s_tmp[255];
+    __syncthreads();
+    return incl - v;
+}
+
+// pass 2: per-chunk totals
+__global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsigned char *__restrict__ pyr_all, int *__restrict__ chunk_cnt)
+{
+    __shared__ int s_red[3][4];
+    const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
+    const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
+    if ((long long)blockIdx.x >= q.nchunk[l]) return;
+    const unsigned gidx = blockIdx.x * 256u + tid;
+    const unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
+    int nsym = 0, nleaf = 0, ncoef = 0;
+    if ((long long)gidx < ncell2) {
+        CellNodes c = eval_cell(q, l, g.w[l], g.h[l], pyr, gidx);
+        nsym = c.nsym;
+        if (c.leaf_lvl >= 0) { nleaf = 1; int s = q.cell << c.leaf_lvl; ncoef = s * s; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nsym += __shfl_down(nsym, o);
+        nleaf += __shfl_down(nleaf, o);
+        ncoef += __shfl_down(ncoef, o);
+    }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = nsym; s_red[1][tid >> 6] = nleaf; s_red[2][tid >> 6] = ncoef; }
+    __syncthreads();
+    if (tid < 3) {
+        int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * 4;
+        o[tid] = s_red[tid][0] + s_red[tid][1] + s_red[tid][2] + s_red[tid][3];
+    }
+}
+
+// pass 3: exclusive scan of the chunk totals per (image, layer); totals -> counts
+__global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restrict__ chunk_cnt, long long *__restrict__ counts)
+{
+    __shared__ int s[3][1024];
+    __shared__ int carry[3];
+    const int tid = threadIdx.x, l = blockIdx.x, b = blockIdx.y;
+    int *base = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l]) * 4;
+    const int n = q.nchunk[l];
+    if (tid < 3) carry[tid] = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        int i = start + tid;
+        int v[3] = { 0, 0, 0 };
+        if (i < n) { v[0] = base[i * 4 + 0]; v[1] = base[i * 4 + 1]; v[2] = base[i * 4 + 2]; }
+        for (int c = 0; c < 3; c++) s[c][tid] = v[c];
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int t[3];
+            for (int c = 0; c < 3; c++) t[c] = tid >= o ? s[c][tid - o] : 0;
+            __syncthreads();
+            for (int c = 0; c < 3; c++) s[c][tid] += t[c];
+            __syncthreads();
+        }
+        if (i < n)
+            for (int c = 0; c < 3; c++) base[i * 4 + c] = carry[c] + s[c][tid] - v[c];
+        __syncthreads();
+        if (tid == 1023)
+            for (int c = 0; c < 3; c++) carry[c] += s[c][1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        long long *o = counts + ((long long)b * 3 + l) * 4;
+        o[0] = carry[2];      // n_coeffs
+        o[1] = carry[1];      // n_leaves
+        o[2] = carry[0];      // n_states
+        o[3] = q.root[l];
+    }
+}
+
+// pass 4: emit symbols, leaf table and the per-size DCT work lists
+__global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
+{
+    __shared__ int s_tmp[256];
+    __shared__ int s_cnt[kMaxSizes], s_base[kMaxSizes];
+    const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
+    const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
+    if ((long long)blockIdx.x >= q.nchunk[l]) return;
+    const unsigned gidx = blockIdx.x * 256u + tid;
+    const unsigned char *pyr = qb.pyr + (long long)b * q.pyr_stride + q.pyr_off[l];
+    const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * 4;
+    const int sym_base = coff[0], leaf_base = coff[1], coef_base = coff[2];
+    if (tid < kMaxSizes) s_cnt[tid] = 0;
+
+    CellNodes c;
+    c.nsym = 0; c.syms = 0; c.leaf_lvl = -1;
+    if ((long long)gidx < ncell2) c = eval_cell(q, l, g.w[l], g.h[l], pyr, gidx);
+    const int size = c.leaf_lvl >= 0 ? (q.cell << c.leaf_lvl) : 0;
+    int tot;
+    const int sym_pos = sym_base + block_excl_scan(c.nsym, s_tmp, tid, tot);
+    const int leaf_pos = leaf_base + block_excl_scan(c.leaf_lvl >= 0 ? 1 : 0, s_tmp, tid, tot);
+    const int coef_pos = coef_base + block_excl_scan(size * size, s_tmp, tid, tot);
+
+    unsigned char *st = qb.states + (long long)b * q.state_stride + q.state_off[l];
+    for (int k = 0; k < c.nsym; k++) {
+        if (sym_pos + k < q.state_cap[l]) st[sym_pos + k] = (unsigned char)((c.syms >> (2 * k)) & 3u);
+        else *qb.overflow = 1;
+    }
+    int widx = -1, kidx = 0;
+    if (c.leaf_lvl >= 0) {
+        int cx, cy;
+        morton_decode(gidx, cx, cy);
+        if (leaf_pos < q.leaf_cap[l] && (long long)coef_pos + (long long)size * size <= q.coeff_cap[l]) {
+            int *lf = qb.leaves + ((long long)b * q.leaf_stride + q.leaf_off[l] + leaf_pos) * 4;
+            reinterpret_cast<int4 *>(lf)[0] = make_int4(cx * q.cell, cy * q.cell, size, coef_pos);
+            if (qb.work_count) {
+                kidx = c.leaf_lvl;     // size == bmin << kidx (host guarantees cell == bmin here)
+                widx = atomicAdd(&s_cnt[kidx], 1);
+            }
+        } else {
+            *qb.overflow = 1;
+        }
+    }
+    if (!qb.work_count) return;
+    __syncthreads();
+    if (tid < kMaxSizes && s_cnt[tid] > 0) s_base[tid] = atomicAdd(&qb.work_count[tid], s_cnt[tid]);
+    __syncthreads();
+    if (widx >= 0) {
+        long long pos = (long long)s_base[kidx] + widx;
+        if (pos < qb.work_cap[kidx]) {
+            int cx, cy;
+            morton_decode(gidx, cx, cy);
+            LeafWork wk;
+            wk.plane = b * 3 + l; wk.x = cx * q.cell; wk.y = cy * q.cell; wk.coef = coef_pos;
+            reinterpret_cast<int4 *>(qb.work[kidx])[pos] = make_int4(wk.plane, wk.x, wk.y, wk.coef);
+        } else {
+            *qb.overflow = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int max_chunks(const Geom &g, const QtGeom &q)
+{
+    int m = 1;
+    for (int l = 0; l < g.nl; l++) if (q.nchunk[l] > m) m = q.nchunk[l];
+    return m;
+}
+
+void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned char *map, int edge_value, const QtBuffers &qb)
+{
+    hipLaunchKernelGGL(k_qt_cells, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, map, edge_value, qb.pyr);
+}
+void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
+{
+    hipLaunchKernelGGL(k_qt_count, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, qb.pyr, qb.chunk_cnt);
+}
+void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
+{
+    hipLaunchKernelGGL(k_qt_scan, dim3(g.nl, g.B), dim3(1024), 0, st, g, q, qb.chunk_cnt, qb.counts);
+}
+void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
+{
+    hipLaunchKernelGGL(k_qt_emit, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, qb);
+}
+
+}  // namespace aej

@@ -1,0 +1,192 @@
+"""``Jpeg`` -- the reference's codec object (src/jpeg/jpeg.py:177-800) with the encode hot path on the GPU.
+
+``compress(img)`` keeps the reference signature (Image -> .ajpg bytes).  Stages a-1 ... a-15 of SURVEY.md
+section 8 (colour convert, down-sample, Canny, quadtree, normalise, DCT, quantise, zigzag) run as HIP kernels
+behind ``aej_encode_batch``; the ``.ajpg`` container (JSON header, 2-bit state packing, per-layer zlib-9;
+jpeg.py:531-597) is written on the host from the kernel outputs.  ``compress_batch`` is the throughput entry:
+a device-resident float32 [B, H, W, 3] batch in, device-resident coefficient / leaf / state arrays out.
+"""
+import ctypes
+import json
+import zlib
+from io import BytesIO
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import tables
+from ._lib import get_context
+from .image import Image
+from .settings import JpegCompressionSettings
+
+
+class EncodedBatch:
+    """Device-resident result of the encode hot path for a batch (layout: include/aej.h, aej_plan)."""
+
+    def __init__(self, plan, coeffs, leaves, states, counts, dct=None):
+        self.plan, self.coeffs, self.leaves, self.states, self.counts, self.dct = plan, coeffs, leaves, states, counts, dct
+        self._counts_host = None
+
+    @property
+    def counts_host(self) -> np.ndarray:
+        if self._counts_host is None:
+            self._counts_host = self.counts.cpu().numpy()
+        return self._counts_host
+
+    def layer(self, b: int, l: int, want_dct: bool = False):
+        """-> dict(root_size, states uint8[n], leaves int32[n,3] (x,y,size), coeffs int32[sum s*s])"""
+        p = self.plan
+        n_coef, n_leaf, n_state, root = (int(v) for v in self.counts_host[b, l])
+        co = b * p.coeff_stride + p.coeff_off[l]
+        lo = b * p.leaf_stride + p.leaf_off[l]
+        so = b * p.state_stride + p.state_off[l]
+        out = {
+            "root_size": root,
+            "coeffs": self.coeffs[co:co + n_coef].cpu().numpy(),
+            "leaves": self.leaves[lo:lo + n_leaf, :3].cpu().numpy(),
+            "leaf_coeff_offsets": self.leaves[lo:lo + n_leaf, 3].cpu().numpy(),
+            "states": self.states[so:so + n_state].cpu().numpy(),
+        }
+        if want_dct and self.dct is not None:
+            out["dct"] = self.dct[co:co + n_coef].cpu().numpy()
+        return out
+
+
+class Jpeg:
+    """JPEG compression and decompression implementation with adaptive blocking."""
+
+    def __init__(self, settings: JpegCompressionSettings, device: int = 0) -> None:
+        self._device = device
+        self.update_settings(settings)
+
+    # ------------------------------------------------------------------ settings / caches (jpeg.py:189-238)
+    def update_settings(self, settings: JpegCompressionSettings, layer_shape: Optional[Tuple[int, int]] = None) -> None:
+        self.settings = settings
+        if layer_shape is not None:
+            self.update_layer_shapes(layer_shape)
+        self.precompute_caches()
+
+    def update_layer_shapes(self, layer_shape: Tuple[int, int]) -> None:
+        self.layer_shape = layer_shape
+        self.layer_shapes = self._compute_downsampled_shapes(self.layer_shape)
+
+    def precompute_caches(self) -> None:
+        sizes = tables.block_sizes(self.settings.block_size_range)
+        if not hasattr(self, "zigzag_cache"):
+            self.zigzag_cache = {}
+        for size in sizes:
+            if size not in self.zigzag_cache:
+                self.zigzag_cache[size] = Jpeg._zigzag_ordering(size)
+        self.quantization_matrix_cache = {}
+        for i, qm in enumerate(self.settings.quantization_matrices):
+            self.quantization_matrix_cache[i] = {
+                size: Jpeg._get_quantization_matrix(qm, size, self._get_quality_factor(size)) for size in sizes}
+        self._block_sizes = sizes
+
+    def _qmats_blob(self) -> np.ndarray:
+        """[layer][size][s*s] int32, the layout aej_set_settings expects."""
+        return np.concatenate([self.quantization_matrix_cache[l][s].ravel() for l in range(3) for s in self._block_sizes]).astype(np.int32)
+
+    def _bind(self):
+        ctx = get_context(self._device)
+        bmin, bmax = self._block_sizes[0], self._block_sizes[-1]
+        ctx.set_settings(self.settings.color_space, bmin, bmax, self._qmats_blob())
+        return ctx
+
+    # ------------------------------------------------------------------ encode
+    def compress_batch(self, batch, want_dct: bool = False) -> EncodedBatch:
+        """batch: float32 [B, H, W, 3] in [0, 1] -- a torch tensor already on the GPU (throughput path) or a
+        numpy array (copied).  Returns device-resident outputs; nothing is copied back."""
+        ctx = self._bind()
+        t = ctx.torch
+        x = ctx.to_device(batch, t.float32)
+        if x.ndim != 4 or x.shape[3] != 3:
+            raise ValueError("Input batch must be [B, H, W, 3].")
+        B, H, W, _ = x.shape
+        plan = ctx.plan(B, H, W)
+        coeffs = ctx.empty((B * plan.coeff_stride,), t.int32)
+        leaves = ctx.empty((B * plan.leaf_stride, 4), t.int32)
+        states = ctx.empty((B * plan.state_stride,), t.uint8)
+        counts = ctx.empty((B, 3, 4), t.int64)
+        dct = ctx.empty((B * plan.coeff_stride,), t.float32) if want_dct else None
+        self.encode_into(ctx, x, plan, coeffs, leaves, states, counts, dct)
+        return EncodedBatch(plan, coeffs, leaves, states, counts, dct)
+
+    def encode_into(self, ctx, x, plan, coeffs, leaves, states, counts, dct=None) -> None:
+        """One pass of the hot path into caller-owned device buffers (what bench.py times)."""
+        ws = ctx.workspace(plan.workspace_bytes)
+        ctx.check(ctx.lib.aej_encode_batch(
+            ctx.handle, x.data_ptr(), plan.batch, plan.H, plan.W, coeffs.data_ptr(), leaves.data_ptr(), states.data_ptr(),
+            counts.data_ptr(), dct.data_ptr() if dct is not None else None, ws.data_ptr(), ctypes.c_uint64(plan.workspace_bytes)))
+
+    def compress(self, img: Image) -> bytes:
+        """Compresses the input image (jpeg.py:240-272)."""
+        if not isinstance(img, Image):
+            raise TypeError("Input must be an Image object.")
+        if img.data.ndim != 3:
+            raise ValueError("Input array must be a 3D.")
+        self.update_layer_shapes(img.original_shape[:2])
+        self.extension = img.extension
+        data = np.ascontiguousarray(img.data, dtype=np.float32).reshape(img.original_shape)
+        enc = self.compress_batch(data[None])
+        layers = [enc.layer(0, l) for l in range(3)]
+        return self._entropy_encode(layers)
+
+    def decompress(self, img_encoded: bytes) -> Image:
+        raise NotImplementedError("decode path (jpeg.py:274-297) is the next scope row (SURVEY.md 8f-2); not built yet")
+
+    # ------------------------------------------------------------------ .ajpg container (jpeg.py:531-597)
+    def _entropy_encode(self, layers) -> bytes:
+        out = BytesIO()
+        metadata = {
+            "height": int(self.layer_shape[0]), "width": int(self.layer_shape[1]), "num_layers": len(layers),
+            "color_space": self.settings.color_space,
+            "quality_min": self.settings.quality_range[0], "quality_max": self.settings.quality_range[1],
+            "block_size_min": self.settings.block_size_range[0], "block_size_max": self.settings.block_size_range[1],
+            "extension": self.extension,
+        }
+        mb = json.dumps(metadata).encode("utf-8")
+        out.write(len(mb).to_bytes(4, byteorder="big"))
+        out.write(mb)
+        for L in layers:
+            st = L["states"]
+            bits_len = 2 * len(st)
+            pad = (-len(st)) % 4
+            quad = np.concatenate([st, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+            packed = ((quad[:, 0] << 6) | (quad[:, 1] << 4) | (quad[:, 2] << 2) | quad[:, 3]).astype(np.uint8)
+            out.write(bits_len.to_bytes(4, byteorder="big"))
+            out.write(int(L["root_size"]).to_bytes(4, byteorder="big"))
+            out.write(packed.tobytes())
+            comp = zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=9)
+            out.write(len(comp).to_bytes(4, byteorder="big"))
+            out.write(comp)
+        return out.getvalue()
+
+    # ------------------------------------------------------------------ small helpers, reference names kept
+    def _compute_downsampled_shapes(self, layer_shapes) -> np.ndarray:
+        return np.asarray(layer_shapes) // self.settings.downsampling_ratios      # jpeg.py:676-686
+
+    def _get_quality_factor(self, block_size: int) -> int:
+        return tables.quality_factor(block_size, self.settings.block_size_range, self.settings.quality_range)
+
+    @staticmethod
+    def _get_quantization_matrix(default_matrix: np.ndarray, size: int, quality: int) -> np.ndarray:
+        return tables.quantization_matrix(default_matrix, size, quality)
+
+    @staticmethod
+    def _zigzag_ordering(size: int) -> np.ndarray:
+        return tables.zigzag_ordering(size)
+
+    @staticmethod
+    def _decode_leaf_sizes(states: List[int], root_size: int) -> List[int]:
+        """jpeg.py:768-800"""
+        sizes, stack, i = [], [root_size], 0
+        while stack and i < len(states):
+            size = stack.pop()
+            s = states[i]
+            i += 1
+            if s == 0:
+                sizes.append(size)
+            elif s == 1:
+                stack.extend([size // 2] * 4)
+        return sizes

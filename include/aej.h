@@ -1,0 +1,130 @@
+/*
+ * aej.h -- C ABI of libaejpeg_hip.so: the MI355X (gfx950) implementation of the adaptive-JPEG
+ * ENCODE hot path of fevzibabaoglu/adaptive-edge-aware-jpeg.
+ *
+ * The reference is pure Python and has no FFI; its boundary for this path is the Python API
+ * (src/jpeg/jpeg.py:240-272 Jpeg.compress, src/jpeg/edge_detection.py:28 EdgeDetection.canny,
+ * src/jpeg/quadtree.py:71 QuadTree, src/color/conversion.py:95 convert).  Each entry point below
+ * names the reference interface it replaces; INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.  Citations are path:line under the reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP) unless the name ends in _host;
+ *   - every function returns 0 on success or a negative aej_status; aej_last_error() gives the text;
+ *   - no exceptions cross the ABI; nothing here allocates device memory after aej_create()
+ *     except aej_set_settings() (tables) -- the caller owns inputs, outputs and the workspace;
+ *   - a context is bound to one HIP device and one stream and is NOT thread-safe (like the
+ *     reference's stateful Jpeg object, jpeg.py:256-259); distinct contexts are independent;
+ *   - work is enqueued on the context's stream; calls that must read a device counter
+ *     (aej_canny / aej_encode_batch: hysteresis convergence) synchronise that stream internally.
+ */
+#ifndef AEJ_H
+#define AEJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AEJ_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define AEJ_API __attribute__((visibility("default")))
+#else
+#define AEJ_API
+#endif
+
+typedef struct aej_ctx aej_ctx;
+
+typedef enum aej_status {
+    AEJ_OK = 0,
+    AEJ_ERR_ARG = -1,        /* bad argument (ValueError on the Python side)          */
+    AEJ_ERR_HIP = -2,        /* a HIP runtime call failed                             */
+    AEJ_ERR_STATE = -3,      /* settings not set / plan mismatch                      */
+    AEJ_ERR_CAPACITY = -4,   /* an output or the workspace is too small               */
+    AEJ_ERR_UNSUPPORTED = -5 /* shape/ratio combination not built     */
+} aej_status;
+
+/* colour spaces: keys of JpegCompressionSettings.COLOR_SPACE_SETTINGS (jpeg.py:62-147) */
+typedef enum aej_space {
+    AEJ_YCBCR = 0, AEJ_YCOCG = 1, AEJ_YCOCG_R = 2, AEJ_OKLAB = 3, AEJ_ICTCP = 4, AEJ_ICACB = 5, AEJ_JZAZBZ = 6
+} aej_space;
+
+#define AEJ_MAX_SIZES 8 /* block sizes 2,4,...,256 (GUI range, src/gui/main_frame.py:41-45) */
+
+/* Shapes and capacities for one (batch, H, W) under the current settings.  Layer l of image b lives at
+ * element offset  b*<x>_stride + <x>_off[l]  of the corresponding output array. */
+typedef struct aej_plan {
+    int32_t batch, H, W;
+    int32_t layer_h[3], layer_w[3]; /* Jpeg._compute_downsampled_shapes, jpeg.py:676-686          */
+    int32_t root_size[3];           /* QuadTree root size, quadtree.py:89-90                         */
+    int64_t coeff_off[3], coeff_stride; /* int32 coefficients, capacity per layer = coeff_off[l+1]-coeff_off[l] */
+    int64_t leaf_off[3], leaf_stride;   /* leaves, 4 x int32 each: x, y, size, coeff offset in layer  */
+    int64_t state_off[3], state_stride; /* state symbols, one uint8 each: 0 leaf, 1 internal, 2 absent */
+    uint64_t workspace_bytes;
+} aej_plan;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+AEJ_API int aej_abi_version(void);
+AEJ_API aej_ctx *aej_create(int device, void *hip_stream /* hipStream_t or NULL = null stream */);
+AEJ_API void aej_destroy(aej_ctx *ctx);
+AEJ_API const char *aej_last_error(aej_ctx *ctx); /* host string owned by ctx (or a static one if ctx==NULL) */
+AEJ_API int aej_synchronize(aej_ctx *ctx);
+AEJ_API int aej_last_hysteresis_passes(aej_ctx *ctx); /* diagnostic: passes enqueued by the last Canny run */
+
+/* ---- settings: JpegCompressionSettings + Jpeg.precompute_caches (jpeg.py:150-174, 216-238) ------
+ * qmats_host: the integer quantisation matrices of Jpeg._get_quantization_matrix (jpeg.py:707-724),
+ * built by the Python host, laid out [layer 0..2][size = bmin, 2*bmin, ..., bmax][size*size] int32.
+ * Zigzag orders (jpeg.py:726-766) and DCT bases are derived inside the library. */
+AEJ_API int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, const int32_t *qmats_host);
+
+/* ---- whole path: Jpeg.compress up to and including the zigzag gather (jpeg.py:262-270, 579-588) -- */
+AEJ_API int aej_encode_plan(aej_ctx *ctx, int batch, int H, int W, aej_plan *plan_host);
+
+/* rgb: [batch][H][W][3] float32 in [0,1] (Image.data, image.py:26-36).
+ * coeffs / leaves / states: laid out as the plan says.  counts: [batch][3][4] int64 =
+ * {n_coeffs, n_leaves, n_states, root_size}.  dct_f32 (optional, may be NULL): pre-quantisation
+ * DCT values in raster order per leaf, same offsets as coeffs. */
+AEJ_API int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H, int W,
+                     int32_t *coeffs, int32_t *leaves, uint8_t *states, int64_t *counts,
+                     float *dct_f32, void *workspace, uint64_t workspace_bytes);
+
+/* ---- stage entry points (same kernels; used by the Python mirrors and the parity tests) -------- */
+
+/* color.convert("sRGB", space, x)  (conversion.py:95-124): rgb [n][3] -> out [n][3], float32 */
+AEJ_API int aej_color_convert(aej_ctx *ctx, int space, const float *rgb, float *out, int64_t n);
+
+/* Jpeg._convert_color_space + _downsample (jpeg.py:262-267): raw (un-normalised) float32 planes,
+ * planes[l] has layer_h[l]*layer_w[l] elements at offset plane_off[l]; total = plane_stride per image */
+AEJ_API int aej_color_planes(aej_ctx *ctx, const float *rgb, int batch, int H, int W, float *planes_raw,
+                     float *planes_norm, uint8_t *planes_u8);
+
+/* EdgeDetection.canny(img2d) (edge_detection.py:28-86): plane float32 [H][W] -> edge uint8 {0,1}.
+ * stages (optional): 5*H*W uint8 = scaled, CLAHE, Gaussian, bilateral, NMS map (0 weak,1 none,2 strong);
+ * thresholds (optional): 2 int32 = the integer low/high passed to the NMS test. */
+AEJ_API uint64_t aej_canny_workspace_bytes(int H, int W);
+AEJ_API int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t *edge, uint8_t *stages,
+              int32_t *thresholds, void *workspace, uint64_t workspace_bytes);
+
+/* QuadTree(edge, max_size, min_size).get_leaves_and_states() (quadtree.py:71-165).
+ * edge: uint8 [H][W], non-zero == edge.  leaves: [cap][4] int32 (x, y, size, coeff offset);
+ * states: uint8 symbols; counts: 4 int64 = {n_coeffs, n_leaves, n_states, root_size}. */
+AEJ_API uint64_t aej_quadtree_workspace_bytes(int H, int W, int min_size, int max_size);
+AEJ_API int aej_quadtree_capacity(int H, int W, int min_size, int max_size, int64_t *leaf_cap, int64_t *state_cap,
+                          int64_t *coeff_cap);
+AEJ_API int aej_quadtree(aej_ctx *ctx, const uint8_t *edge, int H, int W, int min_size, int max_size,
+                 int32_t *leaves, uint8_t *states, int64_t *counts, void *workspace, uint64_t workspace_bytes);
+
+/* gather + reflect pad + DCT + quantise + zigzag (jpeg.py:393-404, 471, 499-502, 579-588) for the leaves
+ * of one layer.  norm: normalised plane [H][W]; leaves: [n][4] as produced by aej_quadtree;
+ * coeffs: sum(size^2) int32; dct_f32 optional. Uses the quantisation matrices of `layer` from the
+ * current settings. */
+AEJ_API int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, int layer, const int32_t *leaves,
+                         int64_t n_leaves, int32_t *coeffs, float *dct_f32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEJ_H */

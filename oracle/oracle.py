@@ -1,0 +1,378 @@
+"""CPU ORACLE (numpy + C) for the adaptive-JPEG encode hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package never does.  The arithmetic lives in aej_oracle.c (scalar, order-defined C); this
+file holds the ctypes binding plus the tiny host-side tables the reference builds in Python
+(zigzag order, quality law, quantisation matrices, layer shapes) and the orchestration of
+``Jpeg.compress`` (src/jpeg/jpeg.py:240-272).  Parity status per stage: header of aej_oracle.c.
+
+Citations are path:line under /root/reference/.
+"""
+import ctypes
+import json
+import math
+import os
+import subprocess
+import zlib
+from io import BytesIO
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_SRC = os.path.join(_HERE, "aej_oracle.c")
+
+SPACES = {"YCbCr": 0, "YCoCg": 1, "YCoCg-R": 2, "OKLAB": 3, "ICtCp": 4, "ICaCb": 5, "JzAzBz": 6}
+
+# jpeg.py:62-147 -- (rh, rw) per layer
+RATIOS = {
+    "ICaCb": [(1, 1), (1, 4), (1, 4)], "ICtCp": [(1, 1), (1, 4), (1, 4)],
+    "JzAzBz": [(1, 1), (2, 2), (2, 2)], "OKLAB": [(1, 1), (2, 2), (2, 2)], "YCbCr": [(1, 1), (2, 2), (2, 2)],
+    "YCoCg": [(1, 1), (2, 2), (2, 2)], "YCoCg-R": [(1, 1), (2, 2), (2, 2)],
+}
+
+# MIDPOINTS / SCALE_FACTORS: np.array([...python doubles...], dtype=np.float32) in each colour file
+NORM = {
+    "YCbCr": ([0.5000000037252903, 7.450580596923828e-09, 0.0], [253.99999810755253, 254.000003784895, 254.0]),  # ycbcr.py:41-42
+    "YCoCg": ([0.5, 0.0, 0.0], [254.0, 254.0, 254.0]),                                                             # ycocg.py:41-42
+    "YCoCg-R": ([0.5, 0.0, 0.0], [254.0, 127.0, 127.0]),                                                           # ycocg.py:62-63
+    "OKLAB": ([0.4999999, 0.021152213, -0.056563325], [254.00005, 497.9055, 497.94604]),                         # oklab.py:51-52
+    "ICtCp": ([0.07497266, -0.0008235276, 0.023989676], [1693.9674, 1133.9044, 1694.004]),                       # ictcp.py:162-163
+    "ICaCb": ([0.07498085, 0.02180194, -0.018250957], [1693.7823, 1838.5665, 1330.3855]),                        # icacb.py:162-163
+    "JzAzBz": ([0.0087900255, 0.00048353244, -0.0020741792], [14448.194, 7590.505, 5552.201]),                   # jzazbz.py:211-212
+}
+
+LUM = np.array([[16, 11, 10, 16, 24, 40, 51, 61], [12, 12, 14, 19, 26, 58, 60, 55], [14, 13, 16, 24, 40, 57, 69, 56],
+                [14, 17, 22, 29, 51, 87, 80, 62], [18, 22, 37, 56, 68, 109, 103, 77], [24, 35, 55, 64, 81, 104, 113, 92],
+                [49, 64, 78, 87, 103, 121, 120, 101], [72, 92, 95, 98, 112, 100, 103, 99]], dtype=np.float32)  # jpeg.py:40-49
+CHR = np.array([[17, 18, 24, 47, 99, 99, 99, 99], [18, 21, 26, 66, 99, 99, 99, 99], [24, 26, 56, 99, 99, 99, 99, 99],
+                [47, 66, 99, 99, 99, 99, 99, 99]] + [[99] * 8] * 4, dtype=np.float32)                          # jpeg.py:50-59
+
+
+def build(force=False):
+    """Compile aej_oracle.c -> liboracle.so (gcc, no contraction, no fast-math)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                               "-fvisibility=hidden", "-mfma", "-mavx2", "-o", _SO, _SRC, "-lm"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_root_size.restype = ctypes.c_int
+        for name in ("orc_downsample", "orc_quadtree", "orc_blocks_encode"):
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def _p(a, t=ctypes.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+# ------------------------------------------------------------------ stage wrappers
+def color_forward(space, rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32).reshape(-1, 3)
+    out = np.empty_like(rgb)
+    lib().orc_color_forward(ctypes.c_int(SPACES[space]), _p(rgb), _p(out), ctypes.c_int64(rgb.shape[0]))
+    return out
+
+
+def pow_array(x, y):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_pow_array(_p(x), ctypes.c_double(y), _p(out), ctypes.c_int64(x.size))
+    return out
+
+
+def downsample(conv_hw3, ch, rh, rw):
+    conv = np.ascontiguousarray(conv_hw3, dtype=np.float32)
+    H, W, _ = conv.shape
+    out = np.empty((H // rh, W // rw), dtype=np.float32)
+    rc = lib().orc_downsample(_p(conv), H, W, ch, rh, rw, _p(out))
+    if rc != 0:
+        raise ValueError("oracle: fractional INTER_AREA ratios are not restated (H, W must divide by the ratios)")
+    return out
+
+
+def to_u8(plane):
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    out = np.empty(plane.shape, dtype=np.uint8)
+    lib().orc_to_u8(_p(plane), _p(out), ctypes.c_int64(plane.size))
+    return out
+
+
+def _u8_stage(fn, img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    getattr(lib(), fn)(_p(img), _p(out), img.shape[0], img.shape[1])
+    return out
+
+
+def clahe(img):
+    return _u8_stage("orc_clahe", img)
+
+
+def gauss3(img):
+    return _u8_stage("orc_gauss3", img)
+
+
+def bilateral5(img):
+    return _u8_stage("orc_bilateral5", img)
+
+
+def bilateral_tables():
+    sw = np.empty(13, np.float32)
+    dy = np.empty(13, np.int32)
+    dx = np.empty(13, np.int32)
+    cw = np.empty(256, np.float32)
+    lib().orc_bilateral_tables(_p(sw), _p(dy), _p(dx), _p(cw))
+    return sw, dy, dx, cw
+
+
+def percentiles(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    lo, hi = ctypes.c_double(), ctypes.c_double()
+    lib().orc_percentiles(_p(img), ctypes.c_int64(img.size), ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+def canny_thresholds(lo, hi):
+    a, b = ctypes.c_int(), ctypes.c_int()
+    lib().orc_canny_thresholds(ctypes.c_double(lo), ctypes.c_double(hi), ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
+def canny(img, lo, hi, return_nms=False):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    nms = np.empty_like(img) if return_nms else None
+    lib().orc_canny(_p(img), _p(out), _p(nms) if return_nms else None, img.shape[0], img.shape[1],
+                    ctypes.c_double(lo), ctypes.c_double(hi))
+    return (out, nms) if return_nms else out
+
+
+def edge_pipeline(plane, return_stages=False):
+    """EdgeDetection.canny (edge_detection.py:70-86) -> uint8 {0,1}; optionally the 4 u8 stages + thresholds."""
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    H, W = plane.shape
+    edge = np.empty((H, W), np.uint8)
+    stages = np.empty((4, H, W), np.uint8) if return_stages else None
+    thr = (ctypes.c_double * 2)()
+    lib().orc_edge_pipeline(_p(plane), _p(edge), H, W, _p(stages) if return_stages else None, thr)
+    if return_stages:
+        return edge, stages, (thr[0], thr[1])
+    return edge
+
+
+def root_size(H, W):
+    return lib().orc_root_size(H, W)
+
+
+def quadtree(edge, min_size, max_size):
+    """-> leaves (n,3) int32 [x,y,s], states (m,) uint8 {0 leaf,1 internal,2 absent}, root_size."""
+    edge = np.ascontiguousarray(edge != 0, dtype=np.uint8)
+    H, W = edge.shape
+    root = root_size(H, W)
+    cells = max(1, root // max(1, min(min_size, root)))
+    cap = 2 * cells * cells + 64
+    leaves = np.empty((cap, 3), np.int32)
+    states = np.empty(2 * cap, np.uint8)
+    nl, ns, r = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    rc = lib().orc_quadtree(_p(edge), H, W, min_size, max_size, _p(leaves), ctypes.c_int64(cap), _p(states),
+                            ctypes.c_int64(2 * cap), ctypes.byref(nl), ctypes.byref(ns), ctypes.byref(r))
+    if rc != 0:
+        raise RuntimeError("oracle quadtree capacity")
+    return leaves[:nl.value].copy(), states[:ns.value].copy(), r.value
+
+
+def normalize(plane, space, layer):
+    mid = np.array(NORM[space][0], dtype=np.float32)[layer]
+    sc = np.array(NORM[space][1], dtype=np.float32)[layer]
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    out = np.empty_like(plane)
+    lib().orc_normalize(_p(plane), _p(out), ctypes.c_int64(plane.size), ctypes.c_float(mid), ctypes.c_float(sc))
+    return out
+
+
+def dct_matrix(s):
+    D = np.empty((s, s), np.float32)
+    lib().orc_dct_matrix(s, _p(D))
+    return D
+
+
+def blocks_encode(norm, leaves, qm_by_size, zz_by_size, want_dct=False):
+    """gather+reflect pad, DCT, quantise, zigzag for every leaf in order -> int32 coefficients (and raw DCT)."""
+    norm = np.ascontiguousarray(norm, dtype=np.float32)
+    leaves = np.ascontiguousarray(leaves, dtype=np.int32).reshape(-1, 3)
+    H, W = norm.shape
+    total = int((leaves[:, 2].astype(np.int64) ** 2).sum())
+    coeffs = np.empty(total, np.int32)
+    dct = np.empty(total, np.float32) if want_dct else None
+    qarr = (ctypes.c_void_p * 16)()
+    zarr = (ctypes.c_void_p * 16)()
+    keep = []
+    for s, q in qm_by_size.items():
+        q = np.ascontiguousarray(q, dtype=np.int32)
+        z = np.ascontiguousarray(zz_by_size[s], dtype=np.int32)
+        keep += [q, z]
+        lg = int(math.log2(s))
+        qarr[lg] = q.ctypes.data
+        zarr[lg] = z.ctypes.data
+    rc = lib().orc_blocks_encode(_p(norm), H, W, _p(leaves), ctypes.c_int64(leaves.shape[0]), qarr, zarr,
+                                 _p(coeffs), _p(dct) if want_dct else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle blocks_encode rc={rc}")
+    return (coeffs, dct) if want_dct else coeffs
+
+
+# ------------------------------------------------------------------ host tables (a-14, a-15)
+def zigzag(size):
+    """Jpeg._zigzag_ordering (jpeg.py:726-766) restated as an anti-diagonal walk."""
+    out = np.empty(size * size, np.int32)
+    i = 0
+    for d in range(2 * size - 1):
+        lo, hi = max(0, d - size + 1), min(d, size - 1)
+        rows = range(lo, hi + 1) if d % 2 else range(hi, lo - 1, -1)
+        for r in rows:
+            out[i] = r * size + (d - r)
+            i += 1
+    return out
+
+
+def block_sizes(brange):
+    return [2 ** i for i in range(int(math.log2(brange[0])), int(math.log2(brange[1])) + 1)]  # jpeg.py:219
+
+
+def quality_factor(size, brange, qrange):
+    """jpeg.py:688-705"""
+    bmin, bmax = brange
+    qmin, qmax = qrange
+    if bmin == bmax:
+        return int((qmin + qmax) / 2)
+    return int(qmin + (qmax - qmin) * (1 - math.log(size / bmin) / math.log(bmax / bmin)))
+
+
+def resize_linear_f32(src, size):
+    """cv.resize(src f32 8x8, (size,size), INTER_LINEAR) as OpenCV 4.x computes it (resize.cpp):
+    exact 2x shrink -> 2x2 box mean (INTER_AREA fast path); otherwise half-pixel-centre bilinear with
+    the source index clamped at both ends, horizontal pass then vertical pass in float32."""
+    src = np.asarray(src, dtype=np.float32)
+    n = src.shape[0]
+    if size == n:
+        return src.copy()
+    if n == 2 * size:
+        return ((src[0::2, 0::2] + src[0::2, 1::2]) + (src[1::2, 0::2] + src[1::2, 1::2])) * np.float32(0.25)
+    scale = n / size
+    idx = np.empty(size, np.int64)
+    fr = np.empty(size, np.float32)
+    for d in range(size):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        s = int(math.floor(f))
+        f = np.float32(f - np.float32(s))
+        if s < 0:
+            s, f = 0, np.float32(0)
+        if s >= n - 1:
+            s, f = n - 1, np.float32(0)
+        idx[d], fr[d] = s, f
+    idx1 = np.minimum(idx + 1, n - 1)
+    a0 = (np.float32(1) - fr).astype(np.float32)
+    hor = src[:, idx] * a0[None, :] + src[:, idx1] * fr[None, :]
+    out = hor[idx, :] * a0[:, None] + hor[idx1, :] * fr[:, None]
+    return out.astype(np.float32)
+
+
+def quant_matrix(table, size, quality):
+    """Jpeg._get_quantization_matrix (jpeg.py:707-724)"""
+    scale_factor = 5000 / quality if quality < 50 else 200 - 2 * quality
+    scaled = np.floor((scale_factor * table + 50) / 100)
+    resized = resize_linear_f32(scaled, size)
+    return np.clip(resized, 1, None).astype(np.int32)
+
+
+def layer_shapes(H, W, space):
+    return [(H // rh, W // rw) for rh, rw in RATIOS[space]]  # jpeg.py:676-686
+
+
+def tables(space, qrange, brange):
+    sizes = block_sizes(brange)
+    zz = {s: zigzag(s) for s in sizes}
+    qm = []
+    for layer in range(3):
+        t = LUM if layer == 0 else CHR
+        qm.append({s: quant_matrix(t, s, quality_factor(s, brange, qrange)) for s in sizes})
+    return sizes, zz, qm
+
+
+# ------------------------------------------------------------------ whole path (jpeg.py:240-272)
+def encode_image(rgb, space="YCoCg", qrange=(40, 80), brange=(4, 64), keep=False):
+    """rgb: (H,W,3) float32 in [0,1].  Returns per-layer dicts: root_size, states, leaves, coeffs."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    H, W, _ = rgb.shape
+    conv = color_forward(space, rgb.reshape(-1, 3)).reshape(H, W, 3)
+    _, zz, qm = tables(space, qrange, brange)
+    layers = []
+    for i, (rh, rw) in enumerate(RATIOS[space]):
+        plane = downsample(conv, i, rh, rw)
+        edge = edge_pipeline(plane)
+        leaves, states, root = quadtree(edge, brange[0], brange[1])
+        norm = normalize(plane, space, i)
+        coeffs = blocks_encode(norm, leaves, qm[i], zz)
+        d = {"root_size": root, "states": states, "leaves": leaves, "coeffs": coeffs}
+        if keep:
+            d.update(plane=plane, edge=edge, norm=norm)
+        layers.append(d)
+    return layers
+
+
+def write_ajpg(layers, H, W, space, qrange, brange, extension):
+    """Jpeg._entropy_encode (jpeg.py:531-597) -- next-scope bitstream writer, restated for fixtures."""
+    out = BytesIO()
+    meta = {"height": H, "width": W, "num_layers": len(layers), "color_space": space,
+            "quality_min": qrange[0], "quality_max": qrange[1],
+            "block_size_min": brange[0], "block_size_max": brange[1], "extension": extension}
+    mb = json.dumps(meta).encode("utf-8")
+    out.write(len(mb).to_bytes(4, "big"))
+    out.write(mb)
+    for L in layers:
+        st = np.asarray(L["states"], dtype=np.uint8)
+        bits_len = 2 * len(st)
+        pad = (-len(st)) % 4
+        sp = np.concatenate([st, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+        packed = ((sp[:, 0] << 6) | (sp[:, 1] << 4) | (sp[:, 2] << 2) | sp[:, 3]).astype(np.uint8)
+        out.write(bits_len.to_bytes(4, "big"))
+        out.write(int(L["root_size"]).to_bytes(4, "big"))
+        out.write(packed.tobytes())
+        comp = zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=9)
+        out.write(len(comp).to_bytes(4, "big"))
+        out.write(comp)
+    return out.getvalue()
+
+
+def synth_image(H, W, seed, kind="mixed"):
+    """The synthetic benchmark image of SURVEY.md section 8d (uint8 HxWx3)."""
+    rng = np.random.default_rng(seed)
+    if kind == "flat":
+        return np.full((H, W, 3), 128, np.uint8)
+    if kind == "noise":
+        return rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    yy = np.arange(H, dtype=np.float64)[:, None] / H
+    xx = np.arange(W, dtype=np.float64)[None, :] / W
+    img = np.empty((H, W, 3), np.float64)
+    for c in range(3):
+        fx, fy = rng.integers(1, 4, size=2)
+        phi, psi = rng.uniform(0, 2 * np.pi, size=2)
+        img[:, :, c] = 127.5 + 80.0 * np.sin(2 * np.pi * fx * xx + phi) * np.cos(2 * np.pi * fy * yy + psi)
+    K = -(-(H * W) // 32768)
+    for _ in range(K):
+        x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+        w, h = int(rng.integers(16, 257)), int(rng.integers(16, 257))
+        col = rng.integers(0, 256, size=3)
+        img[y0:y0 + h, x0:x0 + w, :] = col
+    img += rng.normal(0.0, 1.5, size=img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
