@@ -45,6 +45,9 @@ SIGNATURES = {
     "aej_last_error": (ctypes.c_char_p, [_P]),
     "aej_synchronize": (_I, [_P]),
     "aej_last_hysteresis_passes": (_I, [_P]),
+    "aej_set_profiling": (_I, [_P, _I]),
+    "aej_get_stage_ms": (_I, [_P, _P]),
+    "aej_stage_name": (ctypes.c_char_p, [_I]),
     "aej_set_settings": (_I, [_P, _I, _I, _I, _P]),
     "aej_encode_plan": (_I, [_P, _I, _I, _I, ctypes.POINTER(AejPlan)]),
     "aej_encode_batch": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _U64]),
@@ -68,6 +71,10 @@ def load_library():
                 raise AejError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+            # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  The
+            # device pointers we receive come from that runtime, so it must be the one this library binds to:
+            # import torch first, then the loader resolves our NEEDED libamdhip64.so.7 to the loaded copy.
+            import torch  # noqa: F401
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
@@ -141,6 +148,17 @@ class Context:
         q = np.ascontiguousarray(qmats, dtype=np.int32)
         self.check(self.lib.aej_set_settings(self.handle, SPACE_IDS[space], bmin, bmax, q.ctypes.data_as(ctypes.c_void_p)))
         self.settings_key = key
+
+    N_STAGES = 15
+
+    def set_profiling(self, on):
+        self.check(self.lib.aej_set_profiling(self.handle, 1 if on else 0))
+
+    def stage_ms(self):
+        """-> {stage name: milliseconds} for the last aej_encode_batch call (profiling must be on)."""
+        buf = (ctypes.c_float * self.N_STAGES)()
+        self.check(self.lib.aej_get_stage_ms(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
+        return {self.lib.aej_stage_name(i).decode(): float(buf[i]) for i in range(self.N_STAGES)}
 
     def plan(self, batch, H, W):
         p = AejPlan()

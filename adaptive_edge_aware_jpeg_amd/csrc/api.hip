@@ -27,6 +27,12 @@ struct aej_ctx {
     const float *d_space_w = nullptr, *d_color_w = nullptr;
     int *h_flag = nullptr;             // pinned host word for counter read-backs
     int last_hyst_passes = 0;
+    // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
+    bool profiling = false;
+    hipEvent_t ev[24] = {};
+    int ev_stage[24] = {};
+    int n_ev = 0;
+    float stage_ms[AEJ_N_STAGES] = {};
 };
 
 namespace aej {
@@ -45,6 +51,24 @@ int hip_fail(aej_ctx *ctx, hipError_t e, const char *expr, const char *file, int
     return fail(ctx, AEJ_ERR_HIP, "%s failed: %s (%s:%d)", expr, hipGetErrorString(e), file, line);
 }
 }  // namespace aej
+
+static void mark(aej_ctx *ctx, int stage)
+{
+    if (!ctx->profiling || ctx->n_ev >= 24) return;
+    if (!ctx->ev[ctx->n_ev] && hipEventCreate(&ctx->ev[ctx->n_ev]) != hipSuccess) return;
+    ctx->ev_stage[ctx->n_ev] = stage;   // the stage that ENDS at this event
+    (void)hipEventRecord(ctx->ev[ctx->n_ev], ctx->stream);
+    ctx->n_ev++;
+}
+
+static void collect_marks(aej_ctx *ctx)
+{
+    for (int i = 0; i < AEJ_N_STAGES; i++) ctx->stage_ms[i] = 0.f;
+    for (int i = 1; i < ctx->n_ev; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[i - 1], ctx->ev[i]) == hipSuccess && ctx->ev_stage[i] >= 0) ctx->stage_ms[ctx->ev_stage[i]] += ms;
+    }
+}
 
 // ---- constant tables ---------------------------------------------------------------------------------
 // down-sampling ratios (rh, rw) per layer: JpegCompressionSettings.COLOR_SPACE_SETTINGS, jpeg.py:62-147
@@ -123,7 +147,7 @@ static void make_plane_geom(int H, int W, Geom &g)   // one stand-alone plane as
     fill_clahe_geom(g);
 }
 
-static int make_qtgeom(aej_ctx *ctx, const Geom &g, int bmin, int bmax, QtGeom &q)
+static int make_qtgeom(aej_ctx *ctx, const Geom &g, int bmin, int bmax, QtGeom &q, bool allow_small_root = false)
 {
     memset(&q, 0, sizeof q);
     if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 1)
@@ -132,7 +156,11 @@ static int make_qtgeom(aej_ctx *ctx, const Geom &g, int bmin, int bmax, QtGeom &
     long long pyr = 0, chunks = 0, co = 0, lo = 0, so = 0;
     for (int l = 0; l < g.nl; l++) {
         int root = root_size_of(g.h[l], g.w[l]);
-        if (root < bmin) return fail(ctx, AEJ_ERR_UNSUPPORTED, "layer %d (%dx%d): root %d smaller than min block %d", l, g.h[l], g.w[l], root, bmin);
+        if (root < bmin) {
+            // the whole layer is one leaf of size `root` (quadtree.py:116-118); the codec has no tables for that size
+            if (!allow_small_root || g.nl != 1) return fail(ctx, AEJ_ERR_UNSUPPORTED, "layer %d (%dx%d): root %d smaller than min block %d", l, g.h[l], g.w[l], root, bmin);
+            q.cell = root;
+        }
         q.root[l] = root;
         q.ncell[l] = root / q.cell;
         q.ltot[l] = ilog2(q.ncell[l]);
@@ -257,6 +285,7 @@ extern "C" void aej_destroy(aej_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    for (int i = 0; i < 24; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
 }
 
@@ -386,10 +415,14 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, unsigned cha
     if (stages_scaled) AEJ_HIP_CHECK(hipMemcpyAsync(stages_scaled, w.cb.u8a, planes, hipMemcpyDeviceToDevice, st));
     launch_clahe_pad_hist(st, g, w.cb);
     launch_clahe_lut(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_CLAHE_LUT);
     launch_clahe_blur(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_CLAHE_BLUR);
     if (stages_bilateral) AEJ_HIP_CHECK(hipMemcpyAsync(stages_bilateral, w.cb.u8b, planes, hipMemcpyDeviceToDevice, st));
     launch_thresholds(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_THRESHOLDS);
     launch_sobel_nms(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_SOBEL_NMS);
     if (stages_nms) AEJ_HIP_CHECK(hipMemcpyAsync(stages_nms, w.cb.u8a, planes, hipMemcpyDeviceToDevice, st));
     // hysteresis: groups of passes, one counter read-back per group
     const int group = 4;
@@ -402,6 +435,7 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, unsigned cha
         if (pass + group > kMaxHystPasses) return fail(ctx, AEJ_ERR_STATE, "hysteresis did not converge in %d passes", pass);
     }
     ctx->last_hyst_passes = pass;
+    mark(ctx, AEJ_STAGE_HYSTERESIS);
     AEJ_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -492,18 +526,23 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
     hipStream_t st = ctx->stream;
     w.canny.cb.space_w = ctx->d_space_w;
     w.canny.cb.color_w = ctx->d_color_w;
+    ctx->n_ev = 0;
+    mark(ctx, -1);
     if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
+    mark(ctx, AEJ_STAGE_CLEAR);
 
     float mid[3], scale[3];
     for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
     if (launch_color_planes(st, ctx->space, rgb, g, mid, scale, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist))
         return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+    mark(ctx, AEJ_STAGE_COLOR_PLANES);
     if ((rc = run_canny_chain(ctx, g, w.canny, nullptr, nullptr, nullptr))) return rc;
 
     w.qt.qb.leaves = leaves;
     w.qt.qb.states = states;
     w.qt.qb.counts = reinterpret_cast<long long *>(counts);
     if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.u8a, 2))) return rc;
+    mark(ctx, AEJ_STAGE_QUADTREE);
 
     int k = 0;
     for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
@@ -513,10 +552,12 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
         a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
         for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
         launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k]);
+        mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
     }
     AEJ_HIP_CHECK(hipGetLastError());
     AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qt.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
     AEJ_HIP_CHECK(hipStreamSynchronize(st));
+    if (ctx->profiling) collect_marks(ctx);
     if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
     return 0;
 }
@@ -616,7 +657,7 @@ extern "C" int aej_quadtree_capacity(int H, int W, int min_size, int max_size, i
     Geom g;
     make_plane_geom(H, W, g);
     QtGeom q;
-    int rc = make_qtgeom(nullptr, g, min_size, max_size, q);
+    int rc = make_qtgeom(nullptr, g, min_size, max_size, q, true);
     if (rc) return rc;
     if (leaf_cap) *leaf_cap = q.leaf_cap[0];
     if (state_cap) *state_cap = q.state_cap[0];
@@ -630,7 +671,7 @@ extern "C" uint64_t aej_quadtree_workspace_bytes(int H, int W, int min_size, int
     Geom g;
     make_plane_geom(H, W, g);
     QtGeom q;
-    if (make_qtgeom(nullptr, g, min_size, max_size, q)) return 0;
+    if (make_qtgeom(nullptr, g, min_size, max_size, q, true)) return 0;
     Carver c(nullptr);
     QtWs w;
     carve_qt(c, g, q, false, w);
@@ -648,7 +689,7 @@ extern "C" int aej_quadtree(aej_ctx *ctx, const uint8_t *edge, int H, int W, int
     make_plane_geom(H, W, g);
     g.pstride = (long long)H * W;
     QtGeom q;
-    int rc = make_qtgeom(ctx, g, min_size, max_size, q);
+    int rc = make_qtgeom(ctx, g, min_size, max_size, q, true);
     if (rc) return rc;
     Carver c(workspace);
     QtWs w;
@@ -710,3 +751,24 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
 }
 
 extern "C" int aej_last_hysteresis_passes(aej_ctx *ctx) { return ctx ? ctx->last_hyst_passes : -1; }
+
+extern "C" int aej_set_profiling(aej_ctx *ctx, int enable)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    ctx->profiling = enable != 0;
+    return 0;
+}
+
+extern "C" int aej_get_stage_ms(aej_ctx *ctx, float *ms_host)
+{
+    if (!ctx || !ms_host) return AEJ_ERR_ARG;
+    for (int i = 0; i < AEJ_N_STAGES; i++) ms_host[i] = ctx->stage_ms[i];
+    return 0;
+}
+
+extern "C" const char *aej_stage_name(int i)
+{
+    static const char *names[AEJ_N_STAGES] = { "clear", "color_planes", "clahe_lut", "clahe_blur", "thresholds", "sobel_nms",
+                                               "hysteresis", "quadtree", "dct2", "dct4", "dct8", "dct16", "dct32", "dct64", "dct128" };
+    return i >= 0 && i < AEJ_N_STAGES ? names[i] : "";
+}

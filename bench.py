@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- encode-hot-path throughput on MI355X (BASELINE.json metric: megapixels/s, 4K batch).
+
+One "step" = one pass of the whole encode hot path (colour convert -> chroma down-sample -> Canny chain ->
+quadtree -> DCT -> quantise -> zigzag) over one device-resident batch of
+64 synthetic 3840x2160 float32 RGB images per GPU (BASELINE config 4: 512 4K images over 8 GPUs = 64 per GPU;
+weak scaling).  Inputs are in HBM before the timed region; outputs stay in HBM.
+
+    python bench.py                      # 1 GPU, 64 x 4K, 5 steps
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, HIP-event
+timed on the launch stream inside the library) and `cpu_baseline` (the C oracle on one host core, bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+H4K, W4K = 2160, 3840
+
+# algorithmic HBM bytes per INPUT pixel of each stage for 4:2:0-type spaces (1.5 plane-pixels per pixel); DESIGN.md
+ALGO_BYTES_PER_PX = {
+    "color_planes": 12.0 + 1.5 * 4 + 1.5 * 1,   # f32 RGB in; normalised f32 planes + u8 planes out
+    "clahe_blur": 1.5 * (1 + 1),                 # u8 in, u8 out
+    "sobel_nms": 1.5 * (1 + 1),                  # u8 in, u8 map out
+    "hysteresis": 1.5 * (1 + 1),                 # map in, map out (one sweep is the algorithmic minimum)
+    "quadtree": 1.5 * 1,                         # map in (leaf/state tables are < 0.1 B/px)
+    "dct": 1.5 * (4 + 4),                        # f32 plane in, int32 coefficients out (all block sizes together)
+}
+WHOLE_PATH_BYTES_PER_PX = 18.0                   # 12 B f32 RGB in + 4 B x 1.5 coefficients out
+
+
+def synth_batch(torch, B, H, W, seed, device):
+    """'mixed' synthetic images of SURVEY.md 8d, generated on the GPU: smooth sinusoidal background, K = ceil(N/32768)
+    opaque rectangles, N(0, 1.5^2) noise, rounded to uint8 levels, /255 -> float32 [B, H, W, 3]."""
+    out = torch.empty((B, H, W, 3), dtype=torch.float32, device=device)
+    yy = (torch.arange(H, device=device, dtype=torch.float32) / H)[:, None]
+    xx = (torch.arange(W, device=device, dtype=torch.float32) / W)[None, :]
+    K = -(-(H * W) // 32768)
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        img = out[b]
+        for c in range(3):
+            fx, fy = rng.integers(1, 4, size=2)
+            phi, psi = rng.uniform(0, 2 * np.pi, size=2)
+            img[:, :, c] = 127.5 + 80.0 * torch.sin(2 * math.pi * float(fx) * xx + float(phi)) * torch.cos(2 * math.pi * float(fy) * yy + float(psi))
+        x0 = rng.integers(0, W, size=K); y0 = rng.integers(0, H, size=K)
+        ww = rng.integers(16, 257, size=K); hh = rng.integers(16, 257, size=K)
+        col = rng.integers(0, 256, size=(K, 3)).astype(np.float32)
+        colt = torch.from_numpy(col).to(device)
+        for k in range(K):
+            img[y0[k]:y0[k] + hh[k], x0[k]:x0[k] + ww[k], :] = colt[k]
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + b)
+        img += torch.randn(img.shape, generator=g, device=device) * 1.5
+        img.round_().clamp_(0, 255)
+        img /= 255.0
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("AEJ_BENCH_BATCH", "64")), help="images per GPU")
+    ap.add_argument("--height", type=int, default=H4K)
+    ap.add_argument("--width", type=int, default=W4K)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=6, help="4K images encoded by the CPU oracle for cpu_baseline")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import adaptive_edge_aware_jpeg_amd as A
+    from adaptive_edge_aware_jpeg_amd._lib import get_context
+
+    B, H, W = args.batch, args.height, args.width
+    space, qrange, brange = "YCbCr", (40, 80), (4, 64)
+    dev = torch.device("cuda", local_rank)
+    x = synth_batch(torch, B, H, W, 20250718 + rank * B, dev)
+
+    jpeg = A.Jpeg(A.JpegCompressionSettings(space, qrange, brange), device=local_rank)
+    ctx = jpeg._bind()
+    plan = ctx.plan(B, H, W)
+    coeffs = ctx.empty((B * plan.coeff_stride,), torch.int32)
+    leaves = ctx.empty((B * plan.leaf_stride, 4), torch.int32)
+    states = ctx.empty((B * plan.state_stride,), torch.uint8)
+    counts = ctx.empty((B, 3, 4), torch.int64)
+    ctx.set_profiling(True)
+
+    def step():
+        jpeg.encode_into(ctx, x, plan, coeffs, leaves, states, counts)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    stage_acc = {}
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in ctx.stage_ms().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput
+    px_total, dt = aggregate_throughput(dist, B * H * W * args.steps, dt, dev)   # SUM of pixels, MAX of seconds
+
+    value = px_total / dt / 1e6
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- per-stage means and the roofline of the dominant kernel (this rank) ----
+    stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+    dct_ms = sum(v for k, v in stage_ms.items() if k.startswith("dct"))
+    kernels = {k: stage_ms.get(k, 0.0) for k in ("color_planes", "clahe_blur", "sobel_nms", "hysteresis", "quadtree")}
+    kernels["dct"] = dct_ms
+    dom = max(kernels, key=kernels.get)
+    local_px = B * H * W
+    achieved = ALGO_BYTES_PER_PX[dom] * local_px / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX[dom] * local_px, "avg_launch_ms": round(kernels[dom], 4)}
+    whole = WHOLE_PATH_BYTES_PER_PX * local_px / (ms_per_step * 1e-3) / 1e9
+    per_stage = {k: {"ms": round(v, 4), "GBps": round(ALGO_BYTES_PER_PX[k] * local_px / (v * 1e-3) / 1e9, 1) if v > 0 else None}
+                 for k, v in kernels.items()}
+
+    cnt = counts.cpu().numpy()
+    out = {
+        "metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch",
+        "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic ('mixed' images generated on the GPU, SURVEY.md 8d recipe)",
+        "config": {"workload": f"{B} x {W}x{H} float32 RGB per GPU, {space}, blocks {brange[0]}-{brange[1]}, quality {qrange[0]}-{qrange[1]} "
+                               f"(BASELINE config 4: 512 4K images / 8 GPUs)",
+                   "images_per_gpu": B, "height": H, "width": W, "color_space": space,
+                   "block_size_range": list(brange), "quality_range": list(qrange)},
+        "roofline": roofline,
+        "whole_path": {"bytes_per_px": WHOLE_PATH_BYTES_PER_PX, "achieved_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4)},
+        "stages": per_stage,
+        "hysteresis_passes": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle)),
+        "leaves_per_image": {"luma": int(cnt[:, 0, 1].mean()), "chroma": int(cnt[:, 1:, 1].mean())},
+    }
+
+    # ---- CPU baseline: the C oracle (a scalar port of the reference algorithm), one host core, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        O.build()
+        n_img = max(1, min(args.cpu_images, B))
+        imgs = x[:n_img].cpu().numpy()
+        t0 = time.perf_counter()
+        for i in range(n_img):
+            O.encode_image(imgs[i], space, qrange, brange)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n_img * H * W / cdt / 1e6, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+                               "sample": f"{n_img} of the {B} bench images ({W}x{H}), whole path a-1..a-15 in the C oracle, {cdt:.1f} s",
+                               "host_cpus": os.cpu_count()}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,17 @@ AEJ_API const char *aej_last_error(aej_ctx *ctx); /* host string owned by ctx (o
 AEJ_API int aej_synchronize(aej_ctx *ctx);
 AEJ_API int aej_last_hysteresis_passes(aej_ctx *ctx); /* diagnostic: passes enqueued by the last Canny run */
 
+/* Stage timing of aej_encode_batch: HIP events recorded on the context's stream around every stage of the
+ * last call (measurement only; used by bench.py for the roofline figures). */
+enum {
+    AEJ_STAGE_CLEAR = 0, AEJ_STAGE_COLOR_PLANES, AEJ_STAGE_CLAHE_LUT, AEJ_STAGE_CLAHE_BLUR, AEJ_STAGE_THRESHOLDS,
+    AEJ_STAGE_SOBEL_NMS, AEJ_STAGE_HYSTERESIS, AEJ_STAGE_QUADTREE, AEJ_STAGE_DCT_2, AEJ_STAGE_DCT_4, AEJ_STAGE_DCT_8,
+    AEJ_STAGE_DCT_16, AEJ_STAGE_DCT_32, AEJ_STAGE_DCT_64, AEJ_STAGE_DCT_128, AEJ_N_STAGES
+};
+AEJ_API int aej_set_profiling(aej_ctx *ctx, int enable);
+AEJ_API int aej_get_stage_ms(aej_ctx *ctx, float *ms_host /* [AEJ_N_STAGES] */);
+AEJ_API const char *aej_stage_name(int stage);
+
 /* ---- settings: JpegCompressionSettings + Jpeg.precompute_caches (jpeg.py:150-174, 216-238) ------
  * qmats_host: the integer quantisation matrices of Jpeg._get_quantization_matrix (jpeg.py:707-724),
  * built by the Python host, laid out [layer 0..2][size = bmin, 2*bmin, ..., bmax][size*size] int32.

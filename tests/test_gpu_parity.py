@@ -1,0 +1,302 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs --
+bit-exact for every integer / index output and for the float32 stages whose arithmetic order is defined.
+Full-size cases (1080p, 4K) are checked through size-independent properties."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import adaptive_edge_aware_jpeg_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def ctx(A):
+    from adaptive_edge_aware_jpeg_amd._lib import get_context
+    return get_context()
+
+
+def synth(oracle, H, W, seed, kind="mixed"):
+    return oracle.synth_image(H, W, seed, kind).astype(np.float32) / np.float32(255.0)
+
+
+# ------------------------------------------------------------------ a-1 colour
+@pytest.mark.parametrize("space", ["YCbCr", "YCoCg", "YCoCg-R", "OKLAB", "ICtCp", "ICaCb", "JzAzBz"])
+def test_colour_convert_bit_exact(A, oracle, space):
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, size=(50000, 3)).astype(np.float32) / np.float32(255.0)
+    x[:256] = (np.arange(256, dtype=np.float32) / np.float32(255.0))[:, None]        # greys: exact-integer luma
+    assert np.array_equal(A.convert("sRGB", space, x), oracle.color_forward(space, x))
+
+
+def test_colour_against_reference_golden(A):
+    c = np.load(os.path.join(GOLDEN, "color_forward.npz"))
+    x = c["rgb_u8"].astype(np.float32) / np.float32(255.0)
+    for sp in ("YCbCr", "YCoCg", "YCoCg-R", "ICaCb"):
+        assert np.array_equal(A.convert("sRGB", sp, x), c[sp])
+    for sp, tol in (("OKLAB", 6e-7), ("ICtCp", 1e-9), ("JzAzBz", 1e-9)):
+        assert np.abs(A.convert("sRGB", sp, x) - c[sp]).max() <= tol
+
+
+def test_colour_round_trip_closure_property(A, oracle):
+    """reference test_color_conversions.py:67-68 asserts round-trip error < 1e-4; the inverse transforms are decode
+    scope, so close the loop with float64 matrix inverses for the linear spaces."""
+    rng = np.random.default_rng(4)
+    x = rng.random((4096, 3), dtype=np.float32)
+    M = {"YCbCr": [[0.299, 0.587, 0.114], [-0.168736, -0.331264, 0.5], [0.5, -0.418688, -0.081312]],
+         "YCoCg": [[0.25, 0.5, 0.25], [0.5, 0, -0.5], [-0.25, 0.5, -0.25]]}
+    for sp, m in M.items():
+        y = A.convert("sRGB", sp, x).astype(np.float64)
+        back = y @ np.linalg.inv(np.array(m)).T
+        assert np.abs(back - x).max() < 1e-4
+
+
+# ------------------------------------------------------------------ a-2/a-3/a-11 fused plane kernel
+@pytest.mark.parametrize("space,H,W", [("YCbCr", 64, 128), ("YCoCg", 130, 260), ("ICtCp", 34, 72), ("OKLAB", 18, 36), ("JzAzBz", 16, 20)])
+def test_colour_planes_kernel(A, ctx, oracle, space, H, W):
+    import torch
+    img = synth(oracle, H, W, 5)
+    j = A.Jpeg(A.JpegCompressionSettings(space))
+    c = j._bind()
+    plan = c.plan(1, H, W)
+    n = sum(((plan.layer_h[l] * plan.layer_w[l] + 63) // 64) * 64 for l in range(3))
+    raw, nrm, u8 = c.empty((n,), torch.float32), c.empty((n,), torch.float32), c.empty((n,), torch.uint8)
+    x = c.to_device(img[None], torch.float32)
+    c.check(c.lib.aej_color_planes(c.handle, x.data_ptr(), 1, H, W, raw.data_ptr(), nrm.data_ptr(), u8.data_ptr()))
+    raw, nrm, u8 = raw.cpu().numpy(), nrm.cpu().numpy(), u8.cpu().numpy()
+    conv = oracle.color_forward(space, img.reshape(-1, 3)).reshape(H, W, 3)
+    off = 0
+    for l, (rh, rw) in enumerate(oracle.RATIOS[space]):
+        pl = oracle.downsample(conv, l, rh, rw)
+        m = pl.size
+        assert (plan.layer_h[l], plan.layer_w[l]) == pl.shape
+        assert np.array_equal(raw[off:off + m].reshape(pl.shape), pl)
+        assert np.array_equal(nrm[off:off + m].reshape(pl.shape), oracle.normalize(pl, space, l))
+        assert np.array_equal(u8[off:off + m].reshape(pl.shape), oracle.to_u8(pl))
+        off += ((m + 63) // 64) * 64
+
+
+# ------------------------------------------------------------------ a-3..a-8 Canny chain, stage by stage
+@pytest.mark.parametrize("H,W,seed,shift", [(96, 160, 1, 0.0), (67, 101, 2, -0.5), (270, 480, 3, 0.0), (33, 50, 4, 0.0),
+                                            (512, 512, 5, 0.0), (5, 7, 6, 0.0), (64, 64, 7, 0.0), (130, 70, 8, 0.3)])
+def test_canny_chain_stages(A, ctx, oracle, H, W, seed, shift):
+    img = synth(oracle, H, W, seed)
+    plane = oracle.color_forward("YCbCr", img.reshape(-1, 3)).reshape(H, W, 3)[:, :, 0].copy() + np.float32(shift)
+    e, st, thr = A.EdgeDetection.canny(plane, return_stages=True)
+    eo, so, pct = oracle.edge_pipeline(plane, return_stages=True)
+    for i, name in enumerate(("scaled", "clahe", "gauss", "bilateral")):
+        assert np.array_equal(st[i], so[i]), name
+    assert thr == oracle.canny_thresholds(*pct)
+    _, nms = oracle.canny(so[3], pct[0], pct[1], return_nms=True)
+    assert np.array_equal(st[4], nms), "nms map"
+    assert e.dtype == np.float32 and np.array_equal(e.astype(np.uint8), eo)
+
+
+def test_canny_extremes(A, oracle):
+    flat = np.full((128, 192), 0.5, np.float32)
+    assert A.EdgeDetection.canny(flat).sum() == 0
+    noise = np.random.default_rng(1).random((128, 192), dtype=np.float32)
+    assert np.array_equal(A.EdgeDetection.canny(noise).astype(np.uint8), oracle.edge_pipeline(noise))
+
+
+def test_hysteresis_long_chain(A, oracle):
+    """a weak spiral many tiles long with a single strong seed: needs many hysteresis passes."""
+    H = W = 400
+    plane = np.full((H, W), 0.30, np.float32)
+    y = x = 10
+    dx, dy, run = 1, 0, 380
+    while run > 8:                                   # rectangular spiral of a faint line
+        for _ in range(run):
+            plane[y, x] += 0.035
+            x += dx
+            y += dy
+        dx, dy = -dy, dx
+        run -= 12
+    plane[10, 10:14] = 0.9                            # the strong seed
+    got = A.EdgeDetection.canny(plane).astype(np.uint8)
+    assert np.array_equal(got, oracle.edge_pipeline(plane))
+
+
+# ------------------------------------------------------------------ a-9/a-10 quadtree
+def test_quadtree_reference_golden_cases(A):
+    g = np.load(os.path.join(GOLDEN, "quadtree_cases.npz"))
+    n, checked = int(g["n_cases"][0]), 0
+    for i in range(n):
+        edge = g[f"c{i}_edge"].astype(np.float32)
+        mn, mx, root = (int(v) for v in g[f"c{i}_params"])
+        qt = A.QuadTree(edge, max_size=mx, min_size=mn)
+        leaves, states = qt.get_leaves_and_states()
+        assert qt.root_size == root
+        assert [[l.x, l.y, l.size] for l in leaves] == g[f"c{i}_leaves"].tolist(), i
+        assert [int(s, 2) for s in states] == g[f"c{i}_states"].tolist(), i
+        checked += 1
+    assert checked == n
+
+
+def test_quadtree_tree_rebuild(A, oracle):
+    rng = np.random.default_rng(2)
+    edge = (rng.random((90, 130)) < 0.01).astype(np.float32)
+    qt = A.QuadTree(edge, 32, 4)
+    leaves, states = qt.get_leaves_and_states()
+    found = []
+    stack = [qt.root]
+    while stack:                                      # quadtree.py:149-163
+        node = stack.pop()
+        if node is None:
+            continue
+        if node.is_leaf():
+            found.append((node.x, node.y, node.size))
+        else:
+            stack.extend(reversed(node.children))
+    assert found == [(l.x, l.y, l.size) for l in leaves]
+
+
+@pytest.mark.parametrize("H,W,mn,mx", [(1080, 1920, 4, 64), (540, 960, 4, 64), (700, 1100, 8, 128), (333, 517, 2, 32)])
+def test_quadtree_large_random(A, oracle, H, W, mn, mx):
+    rng = np.random.default_rng(H)
+    edge = (rng.random((H, W)) < 0.002).astype(np.float32)
+    edge[H // 3, : W // 2] = 1.0
+    qt = A.QuadTree(edge, max_size=mx, min_size=mn)
+    lo, so, ro = oracle.quadtree(edge, mn, mx)
+    assert np.array_equal(qt._leaves[:, :3], lo) and np.array_equal(qt._states, so) and qt.root_size == ro
+
+
+# ------------------------------------------------------------------ a-11..a-15 DCT / quantise / zigzag
+@pytest.mark.parametrize("bmin,bmax,H,W", [(4, 64, 150, 210), (4, 128, 260, 300), (8, 8, 64, 64), (2, 16, 40, 56), (32, 32, 70, 100)])
+def test_dct_quant_zigzag(A, ctx, oracle, bmin, bmax, H, W):
+    import torch
+    rng = np.random.default_rng(9)
+    space, qr = "YCbCr", (40, 80)
+    j = A.Jpeg(A.JpegCompressionSettings(space, qr, (bmin, bmax)))
+    c = j._bind()
+    norm = (rng.random((H, W), dtype=np.float32) * 254 - 127).astype(np.float32)
+    edge = (rng.random((H, W)) < 0.004).astype(np.uint8)
+    leaves, _, _ = oracle.quadtree(edge, bmin, bmax)
+    _, zz, qm = oracle.tables(space, qr, (bmin, bmax))
+    offs = np.concatenate([[0], np.cumsum(leaves[:, 2].astype(np.int64) ** 2)[:-1]]).astype(np.int32)
+    lv4 = np.concatenate([leaves, offs[:, None]], 1).astype(np.int32)
+    for layer in (0, 2):
+        co, do = oracle.blocks_encode(norm, leaves, qm[layer], zz, want_dct=True)
+        d_l, d_n = c.to_device(lv4, torch.int32), c.to_device(norm, torch.float32)
+        d_c, d_d = c.empty((co.size,), torch.int32), c.empty((co.size,), torch.float32)
+        c.check(c.lib.aej_dct_quant_zigzag(c.handle, d_n.data_ptr(), H, W, layer, d_l.data_ptr(), ctypes.c_int64(len(lv4)),
+                                           d_c.data_ptr(), d_d.data_ptr()))
+        got_d, got_c = d_d.cpu().numpy(), d_c.cpu().numpy()
+        # pre-quantisation DCT: contract is bit equality with the k-ordered fma chain (MFMA f32 == fmaf chain);
+        # stated float tolerance vs the float64 DCT is 1e-6 * s * 127 (tests/test_oracle_pins.py)
+        assert np.array_equal(got_d, do), f"layer {layer}: DCT floats"
+        assert np.array_equal(got_c, co), f"layer {layer}: coefficients"
+
+
+# ------------------------------------------------------------------ whole path
+CASES = [("lena YCbCr 8-8 q50", "lena", "YCbCr", (50, 50), (8, 8)),
+         ("lena YCoCg default", "lena", "YCoCg", (40, 80), (4, 64)),
+         ("lena YCoCg-R 4-32", "lena", "YCoCg-R", (75, 75), (4, 32)),
+         ("synth 360x640 YCbCr", (360, 640, 20250718), "YCbCr", (40, 80), (4, 64)),
+         ("synth 250x332 OKLAB 4-128", (250, 332, 11), "OKLAB", (40, 80), (4, 128)),
+         ("synth 128x256 ICtCp", (128, 256, 12), "ICtCp", (20, 60), (4, 32)),
+         ("synth 96x128 ICaCb", (96, 128, 13), "ICaCb", (40, 80), (4, 16)),
+         ("synth 120x200 JzAzBz", (120, 200, 14), "JzAzBz", (40, 80), (8, 64)),
+         ("synth 1080p YCbCr", (1080, 1920, 20250718), "YCbCr", (40, 80), (4, 64))]
+
+
+@pytest.mark.parametrize("name,src,space,qr,br", CASES, ids=[c[0] for c in CASES])
+def test_encode_matches_oracle(A, oracle, lena, name, src, space, qr, br):
+    img = lena if src == "lena" else synth(oracle, *src)
+    enc = A.Jpeg(A.JpegCompressionSettings(space, qr, br)).compress_batch(img[None], want_dct=True)
+    ref = oracle.encode_image(img, space, qr, br)
+    for l in range(3):
+        got = enc.layer(0, l)
+        assert got["root_size"] == ref[l]["root_size"]
+        assert np.array_equal(got["states"], ref[l]["states"]), f"L{l} states"
+        assert np.array_equal(got["leaves"], ref[l]["leaves"]), f"L{l} leaves"
+        assert np.array_equal(got["coeffs"], ref[l]["coeffs"]), f"L{l} coeffs"
+
+
+def test_compress_bytes_match_reference_orchestrated_fixture(A, lena):
+    """Jpeg.compress(Image) -> .ajpg identical to the files the reference's own compress() wrote (with the oracle
+    as its cv2)."""
+    meta = json.load(open(os.path.join(GOLDEN, "compress_cases.json")))
+    for name, m in meta.items():
+        img = lena
+        if m["crop"]:
+            y, x, h, w = m["crop"]
+            img = np.ascontiguousarray(lena[y:y + h, x:x + w])
+        if img.shape[1] % 4 or img.shape[0] % 2:
+            continue
+        codec = A.Jpeg(A.JpegCompressionSettings(m["space"], tuple(m["quality_range"]), tuple(m["block_size_range"])))
+        data = codec.compress(A.Image(img, img.shape, ".png"))
+        assert hashlib.sha256(data).hexdigest() == m["sha256"], name
+        assert A.Jpeg._decode_leaf_sizes  # header decoder of the reference stays available
+
+
+def test_batch_equals_single_and_is_deterministic(A, oracle):
+    imgs = np.stack([synth(oracle, 256, 384, s, k) for s, k in ((1, "mixed"), (2, "noise"), (3, "flat"), (4, "mixed"))])
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    batch = codec.compress_batch(imgs)
+    again = codec.compress_batch(imgs)
+    for b in range(len(imgs)):
+        single = codec.compress_batch(imgs[b:b + 1])
+        for l in range(3):
+            x, y, z = batch.layer(b, l), single.layer(0, l), again.layer(b, l)
+            for k in ("states", "leaves", "coeffs"):
+                assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k])
+    flat, noise = batch.layer(2, 0), batch.layer(1, 0)
+    assert set(flat["leaves"][:, 2].tolist()) == {64}                 # constant image: all max-size leaves
+    assert np.count_nonzero(flat["coeffs"]) <= len(flat["leaves"])    # only DC terms survive
+    assert (noise["leaves"][:, 2] == 4).mean() > 0.5 and 64 not in set(noise["leaves"][:, 2].tolist())   # white noise: small leaves
+
+
+@pytest.mark.parametrize("H,W,B", [(1080, 1920, 2), (2160, 3840, 1)])
+def test_full_size_properties(A, oracle, H, W, B):
+    """BASELINE sizes: structural invariants instead of an oracle run per pixel (the 1080p oracle comparison is
+    in test_encode_matches_oracle)."""
+    imgs = np.stack([synth(oracle, H, W, 20250718 + i) for i in range(B)])
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    enc = codec.compress_batch(imgs)
+    for b in range(B):
+        for l in range(3):
+            L = enc.layer(b, l)
+            h, w = (H, W) if l == 0 else (H // 2, W // 2)
+            lv = L["leaves"]
+            cover = np.zeros((h + 64, w + 64), np.int16)
+            for s in np.unique(lv[:, 2]):
+                sel = lv[lv[:, 2] == s]
+                for dy in range(0, s, 4):               # paint in 4x4 cells, vectorised over leaves
+                    for dx in range(0, s, 4):
+                        np.add.at(cover, (sel[:, 1] + dy, sel[:, 0] + dx), 1)
+            assert np.all(cover[:h:4, :w:4][: (h + 3) // 4, : (w + 3) // 4] == 1), "leaves must tile the plane exactly once"
+            assert L["coeffs"].size == int((lv[:, 2].astype(np.int64) ** 2).sum())
+            assert A.Jpeg._decode_leaf_sizes(L["states"].tolist(), L["root_size"]) == lv[:, 2].tolist()
+            assert np.array_equal(L["leaf_coeff_offsets"], np.concatenate([[0], np.cumsum(lv[:, 2].astype(np.int64) ** 2)[:-1]]))
+            # Morton (x in even bits) order of the leaf origins == DFS order
+            def morton(x, y):
+                m = np.zeros_like(x, dtype=np.int64)
+                for bit in range(13):
+                    m |= ((x >> bit) & 1).astype(np.int64) << (2 * bit)
+                    m |= ((y >> bit) & 1).astype(np.int64) << (2 * bit + 1)
+                return m
+            mc = morton(lv[:, 0], lv[:, 1])
+            assert np.all(np.diff(mc) > 0)
+
+
+def test_unsupported_inputs_fail_loudly(A):
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr"))
+    with pytest.raises(NotImplementedError):
+        codec.compress_batch(np.zeros((1, 33, 35, 3), np.float32))     # odd sizes: fractional INTER_AREA not built
+    with pytest.raises(NotImplementedError):
+        A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 256))).compress_batch(np.zeros((1, 64, 64, 3), np.float32))
+    with pytest.raises(ValueError):
+        codec.compress_batch(np.zeros((64, 64, 3), np.float32))

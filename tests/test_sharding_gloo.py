@@ -1,0 +1,55 @@
+"""CPU: the multi-GPU path (independent shards + counter reduction) with world_size 2 over gloo."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput, shard_bounds
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(7, rank, world)
+    px, sec = aggregate_throughput(dist, (hi - lo) * 1000, 1.0 + rank)
+    q.put((rank, lo, hi, px, sec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_aggregation_over_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 4), (4, 7)]
+    assert all(r[3] == 7000 and r[4] == 2.0 for r in res)      # SUM of pixels, MAX of seconds on every rank
+
+
+def test_single_process_passthrough():
+    assert aggregate_throughput(None, 10, 2.5) == (10, 2.5)
