@@ -22,6 +22,10 @@ struct Geom {
     long long pstride;   // plane elements per image = sum h*w
     // CLAHE tile geometry per layer (clahe.cpp): padded size / 4
     int ctw[3], cth[3];
+    // edge bit-planes (weak / strong): one 64-bit word per 64 pixels of a row
+    int wpr[3];               // words per row = ceil(w / 64)
+    long long bpoff[3];       // word offset of layer l inside one image's bit-plane storage
+    long long bpstride;       // words per image
 };
 
 // Quadtree geometry per layer.

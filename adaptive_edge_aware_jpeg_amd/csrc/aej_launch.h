@@ -18,8 +18,11 @@ struct CannyBuffers {
     unsigned char *lut;     // [B][3][16][256]
     int *blur_hist;         // [B][3][256]
     int *thr;               // [B][3][2]
-    unsigned char *dirty;   // [2][B][hyst tiles per image]
-    int *pass_changed;      // [kMaxHystPasses]
+    unsigned long long *weak;    // [B][bpstride] NMS candidates (bit-plane)
+    unsigned long long *strong;  // [B][bpstride] strong edges, grown by the hysteresis passes -> final edge map
+    int *hflags;            // [2][B * tiles] "already queued" flags, one parity per pass
+    int *hlist;             // [2][B * tiles] work lists of dirty tiles
+    int *pass_count;        // [kMaxHystPasses + 1] tiles queued for pass p (pass 0 = every tile)
     const float *space_w;   // [13]
     const float *color_w;   // [256]
     // optional stage dumps (stand-alone entry point only)
@@ -33,7 +36,8 @@ void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass);
-void launch_edge_final(hipStream_t st, const Geom &g, const unsigned char *map, unsigned char *edge01);
+void launch_bits_to_edge(hipStream_t st, const Geom &g, const unsigned long long *strong, unsigned char *edge01);
+void launch_bits_to_map(hipStream_t st, const Geom &g, const unsigned long long *weak, const unsigned long long *strong, unsigned char *map);
 
 // quadtree.hip
 struct QtBuffers {
@@ -47,7 +51,8 @@ struct QtBuffers {
     long long work_cap[kMaxSizes];
     int *overflow;          // [1] set to 1 when a capacity would be exceeded
 };
-void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned char *map, int edge_value, const QtBuffers &qb);
+void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned long long *edge_bits, const QtBuffers &qb);
+void launch_pack_edge_bits(hipStream_t st, const Geom &g, const unsigned char *edge, unsigned long long *bits);
 void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb);
 void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb);
 void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb);

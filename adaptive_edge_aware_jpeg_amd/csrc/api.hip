@@ -109,6 +109,13 @@ static int root_size_of(int h, int w)
 
 static void fill_clahe_geom(Geom &g)
 {
+    long long bp = 0;
+    for (int l = 0; l < g.nl; l++) {
+        g.wpr[l] = (g.w[l] + 63) / 64;
+        g.bpoff[l] = bp;
+        bp += align_up((long long)g.wpr[l] * g.h[l], 32);
+    }
+    g.bpstride = bp;
     for (int l = 0; l < g.nl; l++) {
         int w = g.w[l], h = g.h[l];
         int wp = w, hp = h;
@@ -206,7 +213,6 @@ struct Carver {
 struct CannyWs {
     CannyBuffers cb;
     char *zero_begin, *zero_end;     // region cleared at the start of every call
-    unsigned char *dirty0; long long dirty_n;
 };
 
 static void carve_canny(Carver &c, const Geom &g, CannyWs &w)
@@ -216,16 +222,18 @@ static void carve_canny(Carver &c, const Geom &g, CannyWs &w)
     long long tiles = hyst_tiles_per_image(g) * g.B;
     w.cb.u8a = c.take<unsigned char>(planes);
     w.cb.u8b = c.take<unsigned char>(planes);
+    w.cb.weak = c.take<unsigned long long>((long long)g.B * g.bpstride);
+    w.cb.strong = c.take<unsigned long long>((long long)g.B * g.bpstride);
     w.cb.lut = c.take<unsigned char>((long long)g.B * 3 * 16 * 256);
     w.cb.thr = c.take<int>((long long)g.B * 3 * 2);
+    w.cb.hlist = c.take<int>(2 * tiles);
     w.zero_begin = reinterpret_cast<char *>(c.take<int>(0));
     w.cb.tile_hist = c.take<int>((long long)g.B * 3 * 16 * 256);
     w.cb.blur_hist = c.take<int>((long long)g.B * 3 * 256);
-    w.cb.pass_changed = c.take<int>(kMaxHystPasses);
+    w.cb.pass_count = c.take<int>(kMaxHystPasses + 1);
+    w.cb.hflags = c.take<int>(2 * tiles);
     c.take<int>(0);
     w.zero_end = c.base ? c.base + c.off : nullptr;
-    w.cb.dirty = c.take<unsigned char>(2 * tiles);
-    w.dirty0 = w.cb.dirty; w.dirty_n = tiles;
 }
 
 struct QtWs {
@@ -407,34 +415,37 @@ static int ensure_canny_tables(aej_ctx *ctx)
 }
 
 // ---- Canny chain on a prepared uint8 buffer (cb.u8a) ------------------------------------------------------
-static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, unsigned char *stages_scaled, unsigned char *stages_bilateral,
-                           unsigned char *stages_nms)
+static int run_hysteresis(aej_ctx *ctx, const Geom &g, CannyWs &w)
 {
     hipStream_t st = ctx->stream;
-    long long planes = (long long)g.B * g.pstride;
-    if (stages_scaled) AEJ_HIP_CHECK(hipMemcpyAsync(stages_scaled, w.cb.u8a, planes, hipMemcpyDeviceToDevice, st));
-    launch_clahe_pad_hist(st, g, w.cb);
-    launch_clahe_lut(st, g, w.cb);
-    mark(ctx, AEJ_STAGE_CLAHE_LUT);
-    launch_clahe_blur(st, g, w.cb);
-    mark(ctx, AEJ_STAGE_CLAHE_BLUR);
-    if (stages_bilateral) AEJ_HIP_CHECK(hipMemcpyAsync(stages_bilateral, w.cb.u8b, planes, hipMemcpyDeviceToDevice, st));
-    launch_thresholds(st, g, w.cb);
-    mark(ctx, AEJ_STAGE_THRESHOLDS);
-    launch_sobel_nms(st, g, w.cb);
-    mark(ctx, AEJ_STAGE_SOBEL_NMS);
-    if (stages_nms) AEJ_HIP_CHECK(hipMemcpyAsync(stages_nms, w.cb.u8a, planes, hipMemcpyDeviceToDevice, st));
-    // hysteresis: groups of passes, one counter read-back per group
-    const int group = 4;
+    // groups of passes, one counter read-back per group; a pass with an empty work list is a ~5 us no-op
+    const int group = 8;
     int pass = 0;
     for (;;) {
         for (int i = 0; i < group; i++) launch_hyst_pass(st, g, w.cb, pass++);
-        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.cb.pass_changed + (pass - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.cb.pass_count + pass, sizeof(int), hipMemcpyDeviceToHost, st));
         AEJ_HIP_CHECK(hipStreamSynchronize(st));
         if (*ctx->h_flag == 0) break;
         if (pass + group > kMaxHystPasses) return fail(ctx, AEJ_ERR_STATE, "hysteresis did not converge in %d passes", pass);
     }
     ctx->last_hyst_passes = pass;
+    return 0;
+}
+
+static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w)
+{
+    hipStream_t st = ctx->stream;
+    launch_clahe_pad_hist(st, g, w.cb);
+    launch_clahe_lut(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_CLAHE_LUT);
+    launch_clahe_blur(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_CLAHE_BLUR);
+    launch_thresholds(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_THRESHOLDS);
+    launch_sobel_nms(st, g, w.cb);
+    mark(ctx, AEJ_STAGE_SOBEL_NMS);
+    int rc = run_hysteresis(ctx, g, w);
+    if (rc) return rc;
     mark(ctx, AEJ_STAGE_HYSTERESIS);
     AEJ_HIP_CHECK(hipGetLastError());
     return 0;
@@ -443,16 +454,14 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, unsigned cha
 static int clear_canny_ws(aej_ctx *ctx, const CannyWs &w)
 {
     AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), ctx->stream));
-    AEJ_HIP_CHECK(hipMemsetAsync(w.dirty0, 1, (size_t)w.dirty_n, ctx->stream));
-    AEJ_HIP_CHECK(hipMemsetAsync(w.dirty0 + w.dirty_n, 0, (size_t)w.dirty_n, ctx->stream));
     return 0;
 }
 
-static int run_quadtree(aej_ctx *ctx, const Geom &g, const QtGeom &q, QtWs &w, const unsigned char *map, int edge_value)
+static int run_quadtree(aej_ctx *ctx, const Geom &g, const QtGeom &q, QtWs &w, const unsigned long long *edge_bits)
 {
     hipStream_t st = ctx->stream;
     AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));
-    launch_qt_cells(st, g, q, map, edge_value, w.qb);
+    launch_qt_cells(st, g, q, edge_bits, w.qb);
     launch_qt_count(st, g, q, w.qb);
     launch_qt_scan(st, g, q, w.qb);
     launch_qt_emit(st, g, q, w.qb);
@@ -536,12 +545,12 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
     if (launch_color_planes(st, ctx->space, rgb, g, mid, scale, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist))
         return fail(ctx, AEJ_ERR_ARG, "bad colour space");
     mark(ctx, AEJ_STAGE_COLOR_PLANES);
-    if ((rc = run_canny_chain(ctx, g, w.canny, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = run_canny_chain(ctx, g, w.canny))) return rc;
 
     w.qt.qb.leaves = leaves;
     w.qt.qb.states = states;
     w.qt.qb.counts = reinterpret_cast<long long *>(counts);
-    if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.u8a, 2))) return rc;
+    if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
     mark(ctx, AEJ_STAGE_QUADTREE);
 
     int k = 0;
@@ -632,20 +641,11 @@ extern "C" int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t
     launch_thresholds(st, g, w.cb);
     if (thresholds) AEJ_HIP_CHECK(hipMemcpyAsync(thresholds, w.cb.thr, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
     launch_sobel_nms(st, g, w.cb);
-    if (stages) AEJ_HIP_CHECK(hipMemcpyAsync(stages + 4 * n, w.cb.u8a, n, hipMemcpyDeviceToDevice, st));
-    const int group = 4;
-    int pass = 0;
-    for (;;) {
-        for (int i = 0; i < group; i++) launch_hyst_pass(st, g, w.cb, pass++);
-        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.cb.pass_changed + (pass - 1), sizeof(int), hipMemcpyDeviceToHost, st));
-        AEJ_HIP_CHECK(hipStreamSynchronize(st));
-        if (*ctx->h_flag == 0) break;
-        if (pass + group > kMaxHystPasses) return fail(ctx, AEJ_ERR_STATE, "hysteresis did not converge in %d passes", pass);
-    }
-    ctx->last_hyst_passes = pass;
     Geom ge = g;
-    ge.pstride = n;   // edge output is exactly H*W
-    launch_edge_final(st, ge, w.cb.u8a, edge);
+    ge.pstride = n;   // uint8 outputs are exactly H*W
+    if (stages) launch_bits_to_map(st, ge, w.cb.weak, w.cb.strong, stages + 4 * n);
+    if ((rc = run_hysteresis(ctx, g, w))) return rc;
+    launch_bits_to_edge(st, ge, w.cb.strong, edge);
     AEJ_HIP_CHECK(hipGetLastError());
     AEJ_HIP_CHECK(hipStreamSynchronize(st));
     return 0;
@@ -675,6 +675,7 @@ extern "C" uint64_t aej_quadtree_workspace_bytes(int H, int W, int min_size, int
     Carver c(nullptr);
     QtWs w;
     carve_qt(c, g, q, false, w);
+    c.take<unsigned long long>(g.bpstride);
     return (c.off + 255) & ~255ull;
 }
 
@@ -694,9 +695,11 @@ extern "C" int aej_quadtree(aej_ctx *ctx, const uint8_t *edge, int H, int W, int
     Carver c(workspace);
     QtWs w;
     carve_qt(c, g, q, false, w);
+    unsigned long long *bits = c.take<unsigned long long>(g.bpstride);
     if (((c.off + 255) & ~255ull) > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
     w.qb.leaves = leaves; w.qb.states = states; w.qb.counts = reinterpret_cast<long long *>(counts);
-    if ((rc = run_quadtree(ctx, g, q, w, edge, 1))) return rc;
+    launch_pack_edge_bits(ctx->stream, g, edge, bits);
+    if ((rc = run_quadtree(ctx, g, q, w, bits))) return rc;
     AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "leaf/state capacity exceeded");

@@ -111,66 +111,76 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 // ------------------------------------------------------------------------------------------------
 // fused CLAHE apply (a-4) + Gaussian 3x3 (a-5) + bilateral d=5 (a-6) + histogram of the result (a-7)
 // Output tile 64 x 32; LDS holds the CLAHE image with a 3-pixel halo and the Gaussian image with a
-// 2-pixel halo, indexed by image coordinate so that REFLECT_101 is a coordinate remap.
+// 2-pixel halo, indexed by image coordinate so that REFLECT_101 is a coordinate remap.  Tiles whose
+// halo lies fully inside the image (almost all of them) take the INTERIOR path: no bounds tests, no
+// reflection, dword LDS reads and 4 pixels per thread in the bilateral stage.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAW = kBlurTW + 8;   // LDS row stride (bytes)
+constexpr int kAW = kBlurTW + 8;   // LDS row stride (bytes), multiple of 4
 constexpr int kAH = kBlurTH + 6;
 constexpr int kBH = kBlurTH + 4;
+constexpr int kACols = kBlurTW + 6;
 
 __constant__ int c_bil_dy[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
 __constant__ int c_bil_dx[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
 
-__global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char sLut[16 * 256];
-    __shared__ unsigned char sA[kAH * kAW];
-    __shared__ unsigned char sB[kBH * kAW];
-    __shared__ float sCw[256];
-    __shared__ float sSw[16];
-    __shared__ int sHist[256];
+struct BlurLds {
+    unsigned char lut[16 * 256];
+    unsigned char A[kAH * kAW];
+    unsigned char Bm[kBH * kAW];
+    float cw[256];
+    float sw[16];
+    int hist[256];
+    int colOff1[kACols], colOff2[kACols];
+    float colXa[kACols], colXa1[kACols];
+    int rowOff1[kAH], rowOff2[kAH];
+    float rowYa[kAH], rowYa1[kAH];
+};
 
-    const int tid = threadIdx.x, b = blockIdx.y;
-    int l, tx, ty, ntx, nty, tbase;
-    if (!locate_tile(g, kBlurTW, kBlurTH, blockIdx.x, l, tx, ty, ntx, nty, tbase)) return;
+// histogram add with wave-level aggregation of equal values (flat regions put all 64 lanes on one bin)
+__device__ __forceinline__ void hist_add_wave(int *hist, int v, bool valid)
+{
+    unsigned long long active = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int it = 0; it < 3 && active; it++) {
+        int lead = __ffsll((long long)active) - 1;
+        int vstar = __shfl(v, lead);
+        unsigned long long m = __ballot(valid && v == vstar) & active;
+        if (lane == lead) atomicAdd(&hist[vstar], __popcll(m));
+        active &= ~m;
+    }
+    if ((active >> lane) & 1ull) atomicAdd(&hist[v], 1);
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb, BlurLds &L, int l, int b, int x0, int y0)
+{
+    const int tid = threadIdx.x;
     const int w = g.w[l], h = g.h[l];
-    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
     const long long pbase = (long long)b * g.pstride + g.poff[l];
     const unsigned char *src = cb.u8a + pbase;
 
-    reinterpret_cast<uint4 *>(sLut)[tid] = reinterpret_cast<const uint4 *>(cb.lut + ((long long)b * 3 + l) * 4096)[tid];
-    sCw[tid] = cb.color_w[tid];
-    if (tid < 13) sSw[tid] = cb.space_w[tid];
-    sHist[tid] = 0;
-    __syncthreads();
-
     // ---- stage A: CLAHE interpolation (CLAHE_Interpolation_Body) on [x0-3, x0+TW+3) x [y0-3, y0+TH+3)
-    const float inv_tw = 1.0f / (float)g.ctw[l], inv_th = 1.0f / (float)g.cth[l];
-    for (int idx = tid; idx < kAH * (kBlurTW + 6); idx += 256) {
-        int j = idx / (kBlurTW + 6), i = idx - j * (kBlurTW + 6);
+    for (int idx = tid; idx < kAH * kACols; idx += 256) {
+        int j = idx / kACols, i = idx - j * kACols;
         int gx = x0 - 3 + i, gy = y0 - 3 + j;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+        if (INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h)) {
             int v = src[(long long)gy * w + gx];
-            float tyf = (float)gy * inv_th - 0.5f;
-            int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
-            float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
-            if (ty1 < 0) ty1 = 0;
-            if (ty2 > 3) ty2 = 3;
-            float txf = (float)gx * inv_tw - 0.5f;
-            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
-            float xa = txf - (float)tx1, xa1 = 1.0f - xa;
-            if (tx1 < 0) tx1 = 0;
-            if (tx2 > 3) tx2 = 3;
-            float pa = (float)sLut[(ty1 * 4 + tx1) * 256 + v] * xa1;
-            float pb = (float)sLut[(ty1 * 4 + tx2) * 256 + v] * xa;
-            float pc = (float)sLut[(ty2 * 4 + tx1) * 256 + v] * xa1;
-            float pd = (float)sLut[(ty2 * 4 + tx2) * 256 + v] * xa;
+            int r1 = L.rowOff1[j] + v, r2 = L.rowOff2[j] + v;
+            int c1 = L.colOff1[i], c2 = L.colOff2[i];
+            float xa = L.colXa[i], xa1 = L.colXa1[i], ya = L.rowYa[j], ya1 = L.rowYa1[j];
+            float pa = (float)L.lut[r1 + c1] * xa1;
+            float pb = (float)L.lut[r1 + c2] * xa;
+            float pc = (float)L.lut[r2 + c1] * xa1;
+            float pd = (float)L.lut[r2 + c2] * xa;
             float top = pa + pb, bot = pc + pd;
             float t1 = top * ya1, t2 = bot * ya;
             float res = t1 + t2;
             int r = __float2int_rn(res);
             unsigned char o = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
-            sA[j * kAW + i] = o;
-            if (cb.dump_clahe && i >= 3 && i < kBlurTW + 3 && j >= 3 && j < kBlurTH + 3) cb.dump_clahe[pbase + (long long)gy * w + gx] = o;
+            L.A[j * kAW + i] = o;
+            if (cb.dump_clahe && i >= 3 && i < kBlurTW + 3 && j >= 3 && j < kBlurTH + 3 && gx < w && gy < h)
+                cb.dump_clahe[pbase + (long long)gy * w + gx] = o;
         }
     }
     __syncthreads();
@@ -179,13 +189,19 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
     for (int idx = tid; idx < kBH * (kBlurTW + 4); idx += 256) {
         int j = idx / (kBlurTW + 4), i = idx - j * (kBlurTW + 4);
         int gx = x0 - 2 + i, gy = y0 - 2 + j;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+        if (INTERIOR) {
+            const unsigned char *r0 = L.A + j * kAW + i, *r1 = r0 + kAW, *r2 = r1 + kAW;   // rows gy-1.., cols gx-1..
+            int s = (r0[0] + 2 * r0[1] + r0[2]) + 2 * (r1[0] + 2 * r1[1] + r1[2]) + (r2[0] + 2 * r2[1] + r2[2]);
+            unsigned char o = (unsigned char)((s + 8) >> 4);
+            L.Bm[j * kAW + i] = o;
+            if (cb.dump_gauss && i >= 2 && i < kBlurTW + 2 && j >= 2 && j < kBlurTH + 2) cb.dump_gauss[pbase + (long long)gy * w + gx] = o;
+        } else if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
             int xm = reflect101(gx - 1, w) - (x0 - 3), xc = gx - (x0 - 3), xp = reflect101(gx + 1, w) - (x0 - 3);
             int ym = reflect101(gy - 1, h) - (y0 - 3), yc = gy - (y0 - 3), yp = reflect101(gy + 1, h) - (y0 - 3);
-            const unsigned char *r0 = sA + ym * kAW, *r1 = sA + yc * kAW, *r2 = sA + yp * kAW;
+            const unsigned char *r0 = L.A + ym * kAW, *r1 = L.A + yc * kAW, *r2 = L.A + yp * kAW;
             int s = (r0[xm] + 2 * r0[xc] + r0[xp]) + 2 * (r1[xm] + 2 * r1[xc] + r1[xp]) + (r2[xm] + 2 * r2[xc] + r2[xp]);
             unsigned char o = (unsigned char)((s + 8) >> 4);
-            sB[j * kAW + i] = o;
+            L.Bm[j * kAW + i] = o;
             if (cb.dump_gauss && i >= 2 && i < kBlurTW + 2 && j >= 2 && j < kBlurTH + 2) cb.dump_gauss[pbase + (long long)gy * w + gx] = o;
         }
     }
@@ -193,31 +209,111 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
 
     // ---- stage C: bilateral, 13 taps in row-major order, w = sw*cw, wsum += w, sum = fma(v, w, sum)
     unsigned char *dst = cb.u8b + pbase;
-    for (int idx = tid; idx < kBlurTW * kBlurTH; idx += 256) {
-        int j = idx / kBlurTW, i = idx - j * kBlurTW;
-        int gx = x0 + i, gy = y0 + j;
-        if (gx < w && gy < h) {
-            int v0 = sB[(j + 2) * kAW + (i + 2)];
-            float sum = 0.f, wsum = 0.f;
+    if (INTERIOR) {
+        // 4 consecutive pixels per thread; 5 rows x 8 bytes of the Gaussian image held in 10 registers
+        const int cx = (tid & 15) * 4;
+#pragma unroll 1
+        for (int pass = 0; pass < kBlurTH / 16; pass++) {
+            const int j = (tid >> 4) + pass * 16;
+            unsigned int rw[5][2];
 #pragma unroll
-            for (int k = 0; k < 13; k++) {
-                int yy = reflect101(gy + c_bil_dy[k], h) - (y0 - 2);
-                int xx = reflect101(gx + c_bil_dx[k], w) - (x0 - 2);
-                int v = sB[yy * kAW + xx];
-                int d = v - v0;
-                d = d < 0 ? -d : d;
-                float wgt = sSw[k] * sCw[d];
-                wsum = wsum + wgt;
-                sum = __builtin_fmaf((float)v, wgt, sum);
+            for (int r = 0; r < 5; r++) {
+                const unsigned int *p = reinterpret_cast<const unsigned int *>(L.Bm + (j + r) * kAW + cx);
+                rw[r][0] = p[0]; rw[r][1] = p[1];
             }
-            int r = __float2int_rn(sum / wsum);
-            unsigned char o = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
-            dst[(long long)gy * w + gx] = o;
-            atomicAdd(&sHist[o], 1);
+            unsigned char o[4];
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                const int cc = px + 2;
+                const int v0 = (int)((rw[2][cc >> 2] >> (8 * (cc & 3))) & 0xffu);
+                float sum = 0.f, wsum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 13; k++) {
+                    constexpr int dys[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
+                    constexpr int dxs[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
+                    const int rr = 2 + dys[k], c = cc + dxs[k];
+                    const int v = (int)((rw[rr][c >> 2] >> (8 * (c & 3))) & 0xffu);
+                    int d = v - v0;
+                    d = d < 0 ? -d : d;
+                    float wgt = L.sw[k] * L.cw[d];
+                    wsum = wsum + wgt;
+                    sum = __builtin_fmaf((float)v, wgt, sum);
+                }
+                int r = __float2int_rn(sum / wsum);
+                o[px] = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+            }
+            *reinterpret_cast<uchar4 *>(dst + (long long)(y0 + j) * w + x0 + cx) = make_uchar4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for (int px = 0; px < 4; px++) hist_add_wave(L.hist, o[px], true);
+        }
+    } else {
+        for (int idx = tid; idx < kBlurTW * kBlurTH; idx += 256) {
+            int j = idx / kBlurTW, i = idx - j * kBlurTW;
+            int gx = x0 + i, gy = y0 + j;
+            if (gx < w && gy < h) {
+                int v0 = L.Bm[(j + 2) * kAW + (i + 2)];
+                float sum = 0.f, wsum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 13; k++) {
+                    int yy = reflect101(gy + c_bil_dy[k], h) - (y0 - 2);
+                    int xx = reflect101(gx + c_bil_dx[k], w) - (x0 - 2);
+                    int v = L.Bm[yy * kAW + xx];
+                    int d = v - v0;
+                    d = d < 0 ? -d : d;
+                    float wgt = L.sw[k] * L.cw[d];
+                    wsum = wsum + wgt;
+                    sum = __builtin_fmaf((float)v, wgt, sum);
+                }
+                int r = __float2int_rn(sum / wsum);
+                unsigned char o = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+                dst[(long long)gy * w + gx] = o;
+                atomicAdd(&L.hist[o], 1);
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
+{
+    __shared__ __attribute__((aligned(16))) BlurLds L;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    int l, tx, ty, ntx, nty, tbase;
+    if (!locate_tile(g, kBlurTW, kBlurTH, blockIdx.x, l, tx, ty, ntx, nty, tbase)) return;
+    const int w = g.w[l], h = g.h[l];
+    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
+
+    reinterpret_cast<uint4 *>(L.lut)[tid] = reinterpret_cast<const uint4 *>(cb.lut + ((long long)b * 3 + l) * 4096)[tid];
+    L.cw[tid] = cb.color_w[tid];
+    if (tid < 13) L.sw[tid] = cb.space_w[tid];
+    L.hist[tid] = 0;
+    // per-column / per-row interpolation parameters of CLAHE_Interpolation_Body (clahe.cpp)
+    if (tid < kACols) {
+        const float inv_tw = 1.0f / (float)g.ctw[l];
+        float txf = (float)(x0 - 3 + tid) * inv_tw - 0.5f;
+        int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+        float xa = txf - (float)tx1;
+        L.colXa[tid] = xa; L.colXa1[tid] = 1.0f - xa;
+        if (tx1 < 0) tx1 = 0;
+        if (tx2 > 3) tx2 = 3;
+        L.colOff1[tid] = tx1 * 256; L.colOff2[tid] = tx2 * 256;
+    } else if (tid >= 128 && tid < 128 + kAH) {
+        const int j = tid - 128;
+        const float inv_th = 1.0f / (float)g.cth[l];
+        float tyf = (float)(y0 - 3 + j) * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        float ya = tyf - (float)ty1;
+        L.rowYa[j] = ya; L.rowYa1[j] = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > 3) ty2 = 3;
+        L.rowOff1[j] = ty1 * 1024; L.rowOff2[j] = ty2 * 1024;
+    }
     __syncthreads();
-    int c = sHist[tid];
+
+    const bool interior = x0 >= 3 && y0 >= 3 && x0 + kBlurTW + 3 <= w && y0 + kBlurTH + 3 <= h && (w % 4) == 0;
+    if (interior) blur_tile<true>(g, cb, L, l, b, x0, y0);
+    else blur_tile<false>(g, cb, L, l, b, x0, y0);
+    __syncthreads();
+    int c = L.hist[tid];
     if (c) atomicAdd(&cb.blur_hist[((long long)b * 3 + l) * 256 + tid], c);
 }
 
@@ -276,7 +372,9 @@ __global__ __launch_bounds__(256) void k_thresholds(Geom g, const int *__restric
 
 // ------------------------------------------------------------------------------------------------
 // a-8 part 1: Sobel 3x3 (BORDER_REPLICATE), magnitude dx^2+dy^2, non-maximum suppression.
-// map: 1 = suppressed, 0 = weak candidate, 2 = strong (OpenCV's encoding).
+// Output: two bit-planes (one 64-bit word per 64 pixels of a row): `weak` = NMS survivors with
+// low < mag <= high (OpenCV map value 0), `strong` = survivors with mag > high (map value 2).
+// A wave owns one 64-pixel row segment per step, so the words are wave ballots.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSW = kBlurTW + 8;        // u8 LDS stride
 constexpr int kMW = kBlurTW + 2 + 1;    // magnitude LDS stride (ints), +1 to skew banks
@@ -315,14 +413,16 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
         sM[j * kMW + i] = m;
     }
     __syncthreads();
-    unsigned char *map = cb.u8a + pbase;
-    for (int idx = tid; idx < kBlurTW * kBlurTH; idx += 256) {
-        int j = idx / kBlurTW, i = idx - j * kBlurTW;
-        int gx = x0 + i, gy = y0 + j;
+    unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
+    unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
+    const int i = tid & 63;
+#pragma unroll 1
+    for (int j = tid >> 6; j < kBlurTH; j += 4) {
+        const int gx = x0 + i, gy = y0 + j;
+        int res = 1;
         if (gx < w && gy < h) {
             const int *ma = sM + (j + 1) * kMW + (i + 1), *mp = ma - kMW, *mn = ma + kMW;
             int m = *ma;
-            unsigned char res = 1;
             if (m > low) {
                 const unsigned char *r0 = sU + (j + 1) * kSW + (i + 1), *r1 = r0 + kSW, *r2 = r1 + kSW;
                 int xs = (r0[2] + 2 * r1[2] + r2[2]) - (r0[0] + 2 * r1[0] + r2[0]);
@@ -341,95 +441,157 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
                 }
                 if (keep) res = (m > high) ? 2 : 0;
             }
-            map[(long long)gy * w + gx] = res;
+        }
+        unsigned long long wmask = __ballot(res == 0), smask = __ballot(res == 2);
+        if (i == 0 && gy < h) {
+            wk[(long long)gy * g.wpr[l] + tx] = wmask;
+            sg[(long long)gy * g.wpr[l] + tx] = smask;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// a-8 part 2: hysteresis.  Each pass brings every dirty 64x64 tile to its local fix-point in LDS (given
-// the current 1-pixel halo) and marks the 8 neighbours dirty when its border ring changed.  The map only
-// ever moves 0 -> 2, so the global fix-point is unique and equals OpenCV's stack-based flood fill.
+// a-8 part 2: hysteresis on the bit-planes.  One WAVE owns a 64x64 tile: lane r holds row r of the
+// strong and weak planes as 64-bit words, the 8-neighbourhood dilation is shifts + two lane shuffles, and
+// horizontal runs are filled in one step with a Kogge-Stone occluded fill; the loop runs in registers until
+// the tile is at its fix-point for the current halo.  A tile whose border ring changed queues its 8
+// neighbours for the next pass (device work list, de-duplicated with per-parity flags).  Strong bits only
+// ever get set, so the global fix-point is unique = OpenCV's stack flood fill.
 // ------------------------------------------------------------------------------------------------
-constexpr int kHS = kHystTile + 2 + 2;   // LDS stride 68
-
-__global__ __launch_bounds__(256) void k_hyst_pass(Geom g, unsigned char *__restrict__ mapbuf, unsigned char *__restrict__ dirty_cur,
-                                                   unsigned char *__restrict__ dirty_nxt, int *__restrict__ pass_changed,
-                                                   long long tiles_per_img)
+__device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed, unsigned long long open)
 {
-    __shared__ unsigned char s[(kHystTile + 2) * kHS];
-    __shared__ int s_flag;
-    const int tid = threadIdx.x, b = blockIdx.y, t = blockIdx.x;
-    unsigned char *dc = dirty_cur + (long long)b * tiles_per_img + t;
-    if (*dc == 0) return;          // block-uniform
-    int l, tx, ty, ntx, nty, tbase;
-    if (!locate_tile(g, kHystTile, kHystTile, t, l, tx, ty, ntx, nty, tbase)) return;
-    const int w = g.w[l], h = g.h[l];
-    const int x0 = tx * kHystTile, y0 = ty * kHystTile;
-    unsigned char *map = mapbuf + (long long)b * g.pstride + g.poff[l];
-    if (tid == 0) { *dc = 0; s_flag = 0; }
+    unsigned long long gL = seed, pL = open, gR = seed, pR = open;
+    gL |= pL & (gL << 1);  pL &= pL << 1;   gR |= pR & (gR >> 1);  pR &= pR >> 1;
+    gL |= pL & (gL << 2);  pL &= pL << 2;   gR |= pR & (gR >> 2);  pR &= pR >> 2;
+    gL |= pL & (gL << 4);  pL &= pL << 4;   gR |= pR & (gR >> 4);  pR &= pR >> 4;
+    gL |= pL & (gL << 8);  pL &= pL << 8;   gR |= pR & (gR >> 8);  pR &= pR >> 8;
+    gL |= pL & (gL << 16); pL &= pL << 16;  gR |= pR & (gR >> 16); pR &= pR >> 16;
+    gL |= pL & (gL << 32);                  gR |= pR & (gR >> 32);
+    return gL | gR;
+}
 
-    for (int idx = tid; idx < (kHystTile + 2) * (kHystTile + 2); idx += 256) {
-        int j = idx / (kHystTile + 2), i = idx - j * (kHystTile + 2);
-        int gx = x0 - 1 + i, gy = y0 - 1 + j;
-        unsigned char v = 1;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = map[(long long)gy * w + gx];
-        s[j * kHS + i] = v;
-    }
-    __syncthreads();
-    // each thread owns a 4x4 patch of the 64x64 interior
-    const int pxo = (tid & 15) * 4 + 1, pyo = (tid >> 4) * 4 + 1;
-    bool any_change = false, border_change = false;
-    for (;;) {
-        bool changed = false;
-#pragma unroll
-        for (int dy = 0; dy < 4; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 4; dx++) {
-                unsigned char *p = s + (pyo + dy) * kHS + (pxo + dx);
-                if (*p == 0) {
-                    bool n2 = p[-kHS - 1] == 2 || p[-kHS] == 2 || p[-kHS + 1] == 2 || p[-1] == 2 || p[1] == 2 ||
-                              p[kHS - 1] == 2 || p[kHS] == 2 || p[kHS + 1] == 2;
-                    if (n2) {
-                        *p = 2;
-                        changed = true;
-                        int yy = pyo + dy, xx = pxo + dx;
-                        if (yy == 1 || yy == kHystTile || xx == 1 || xx == kHystTile) border_change = true;
-                    }
-                }
-            }
-        any_change |= changed;
-        if (!__syncthreads_or(changed ? 1 : 0)) break;
-    }
-    if (any_change) {
-#pragma unroll
-        for (int dy = 0; dy < 4; dy++) {
-            int gy = y0 + pyo - 1 + dy;
-#pragma unroll
-            for (int dx = 0; dx < 4; dx++) {
-                int gx = x0 + pxo - 1 + dx;
-                if (gx < w && gy < h) {
-                    unsigned char v = s[(pyo + dy) * kHS + (pxo + dx)];
-                    if (v == 2) map[(long long)gy * w + gx] = 2;
-                }
+__global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int pass, long long tiles_per_img, long long total_tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    const long long n = pass == 0 ? total_tiles : (long long)cb.pass_count[pass];
+    int *flags_cur = cb.hflags + (long long)(pass & 1) * total_tiles;
+    int *flags_nxt = cb.hflags + (long long)((pass + 1) & 1) * total_tiles;
+    const int *list_cur = cb.hlist + (long long)(pass & 1) * total_tiles;
+    int *list_nxt = cb.hlist + (long long)((pass + 1) & 1) * total_tiles;
+
+    for (long long item = wave; item < n; item += nwaves) {
+        const long long T = pass == 0 ? item : (long long)list_cur[item];
+        if (lane == 0) flags_cur[T] = 0;
+        const int b = (int)(T / tiles_per_img);
+        int l, tx, ty, ntx, nty, tbase;
+        if (!locate_tile(g, kHystTile, kHystTile, (int)(T - (long long)b * tiles_per_img), l, tx, ty, ntx, nty, tbase)) continue;
+        const int h = g.h[l], wpr = g.wpr[l];
+        unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
+        const unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
+        const int y = ty * 64 + lane;
+        const bool valid = y < h;
+        unsigned long long S = 0, W = 0, SL = 0, SR = 0;
+        if (valid) {
+            const long long o = (long long)y * wpr + tx;
+            S = sg[o]; W = wk[o];
+            if (tx > 0) SL = sg[o - 1] >> 63;
+            if (tx + 1 < wpr) SR = sg[o + 1] & 1ull;
+        }
+        // halo rows above / below the tile (wave-uniform addresses)
+        unsigned long long Tm = 0, Tl = 0, Tr = 0, Bm = 0, Bl = 0, Br = 0;
+        if (ty > 0) {
+            const long long o = (long long)(ty * 64 - 1) * wpr + tx;
+            Tm = sg[o];
+            if (tx > 0) Tl = sg[o - 1] >> 63;
+            if (tx + 1 < wpr) Tr = sg[o + 1] & 1ull;
+        }
+        if (ty * 64 + 64 < h) {
+            const long long o = (long long)(ty * 64 + 64) * wpr + tx;
+            Bm = sg[o];
+            if (tx > 0) Bl = sg[o - 1] >> 63;
+            if (tx + 1 < wpr) Br = sg[o + 1] & 1ull;
+        }
+        const unsigned long long S0 = S;
+        for (;;) {
+            unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
+            unsigned long long upL = __shfl_up(SL, 1), dnL = __shfl_down(SL, 1);
+            unsigned long long upR = __shfl_up(SR, 1), dnR = __shfl_down(SR, 1);
+            if (lane == 0) { up = Tm; upL = Tl; upR = Tr; }
+            if (lane == 63) { dn = Bm; dnL = Bl; dnR = Br; }
+            unsigned long long m = S | up | dn;
+            unsigned long long mm = m | (m << 1) | (m >> 1) | (SL | upL | dnL) | ((SR | upR | dnR) << 63);
+            unsigned long long seed = W & mm & ~S;
+            unsigned long long f = fill_runs(seed, W);
+            unsigned long long nS = S | f;
+            bool ch = nS != S;
+            S = nS;
+            if (!__any(ch)) break;
+        }
+        const unsigned long long diff = S ^ S0;
+        if (diff && valid) sg[(long long)y * wpr + tx] = S;
+        // border ring of the tile: first/last valid row, first/last column
+        const int last_row = min(63, h - 1 - ty * 64);
+        const bool border = diff && ((diff & 0x8000000000000001ull) || lane == 0 || lane == last_row);
+        if (__any(border) && lane < 8) {
+            const int ox[8] = { -1, 0, 1, -1, 1, -1, 0, 1 }, oy[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
+            int nx = tx + ox[lane], ny = ty + oy[lane];
+            if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty) {
+                long long nT = (long long)b * tiles_per_img + tbase + (long long)ny * ntx + nx;
+                if (atomicExch(&flags_nxt[nT], 1) == 0) list_nxt[atomicAdd(&cb.pass_count[pass + 1], 1)] = (int)nT;
             }
         }
     }
-    if (border_change) atomicOr(&s_flag, 1);
-    __syncthreads();
-    if (s_flag && tid < 8) {
-        const int ox[8] = { -1, 0, 1, -1, 1, -1, 0, 1 }, oy[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
-        int nx = tx + ox[tid], ny = ty + oy[tid];
-        if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty) dirty_nxt[(long long)b * tiles_per_img + tbase + ny * ntx + nx] = 1;
-        if (tid == 0) atomicAdd(pass_changed, 1);
+}
+
+// bit-plane -> uint8 expansions (stand-alone EdgeDetection.canny output and the stage dump for the tests)
+__global__ __launch_bounds__(256) void k_bits_to_edge(Geom g, const unsigned long long *__restrict__ strong, unsigned char *__restrict__ edge)
+{
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int w = g.w[l], h = g.h[l], wpr = g.wpr[l];
+    const unsigned long long *sg = strong + (long long)b * g.bpstride + g.bpoff[l];
+    unsigned char *out = edge + (long long)b * g.pstride + g.poff[l];
+    const long long n = (long long)w * h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        out[i] = (unsigned char)((sg[(long long)y * wpr + (x >> 6)] >> (x & 63)) & 1ull);
     }
 }
 
-__global__ __launch_bounds__(256) void k_edge_final(const unsigned char *__restrict__ map, unsigned char *__restrict__ edge, long long n)
+__global__ __launch_bounds__(256) void k_bits_to_map(Geom g, const unsigned long long *__restrict__ weak, const unsigned long long *__restrict__ strong,
+                                                     unsigned char *__restrict__ map)
 {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) edge[i] = map[i] == 2 ? 1 : 0;
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int w = g.w[l], h = g.h[l], wpr = g.wpr[l];
+    const unsigned long long *sg = strong + (long long)b * g.bpstride + g.bpoff[l];
+    const unsigned long long *wk = weak + (long long)b * g.bpstride + g.bpoff[l];
+    unsigned char *out = map + (long long)b * g.pstride + g.poff[l];
+    const long long n = (long long)w * h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        long long o = (long long)y * wpr + (x >> 6);
+        int s = (int)((sg[o] >> (x & 63)) & 1ull), k = (int)((wk[o] >> (x & 63)) & 1ull);
+        out[i] = (unsigned char)(s ? 2 : k ? 0 : 1);
+    }
+}
+
+// uint8 edge image (non-zero == edge) -> bit-plane (stand-alone QuadTree entry)
+__global__ __launch_bounds__(256) void k_pack_edge_bits(Geom g, const unsigned char *__restrict__ edge, unsigned long long *__restrict__ bits)
+{
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int w = g.w[l], h = g.h[l], wpr = g.wpr[l];
+    const unsigned char *src = edge + (long long)b * g.pstride + g.poff[l];
+    unsigned long long *out = bits + (long long)b * g.bpstride + g.bpoff[l];
+    const long long nwords = (long long)h * wpr;
+    const int lane = threadIdx.x & 63;
+    for (long long wd = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wd < nwords; wd += (long long)gridDim.x * 4) {
+        int y = (int)(wd / wpr), xw = (int)(wd - (long long)y * wpr);
+        int x = xw * 64 + lane;
+        bool e = x < w && src[(long long)y * w + x] != 0;
+        unsigned long long m = __ballot(e);
+        if (lane == 0) out[wd] = m;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -477,17 +639,34 @@ void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass)
 {
     long long t = hyst_tiles_per_image(g);
-    unsigned char *cur = cb.dirty + (long long)(pass & 1) * g.B * t;
-    unsigned char *nxt = cb.dirty + (long long)((pass + 1) & 1) * g.B * t;
-    hipLaunchKernelGGL(k_hyst_pass, dim3((unsigned)t, g.B), dim3(256), 0, st, g, cb.u8a, cur, nxt, cb.pass_changed + pass, t);
+    long long total = t * g.B;
+    long long blocks = pass == 0 ? (total + 3) / 4 : 512;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_hyst_pass, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, pass, t, total);
 }
 
-void launch_edge_final(hipStream_t st, const Geom &g, const unsigned char *map, unsigned char *edge01)
+static int expand_blocks(const Geom &g)
 {
-    long long n = (long long)g.B * g.pstride;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_edge_final, dim3(blocks), dim3(256), 0, st, map, edge01, n);
+    long long n = 0;
+    for (int l = 0; l < g.nl; l++) { long long m = (long long)g.w[l] * g.h[l]; if (m > n) n = m; }
+    long long b = (n + 255) / 256;
+    return (int)(b > 4096 ? 4096 : b < 1 ? 1 : b);
+}
+
+void launch_bits_to_edge(hipStream_t st, const Geom &g, const unsigned long long *strong, unsigned char *edge01)
+{
+    hipLaunchKernelGGL(k_bits_to_edge, dim3(expand_blocks(g), g.nl, g.B), dim3(256), 0, st, g, strong, edge01);
+}
+
+void launch_bits_to_map(hipStream_t st, const Geom &g, const unsigned long long *weak, const unsigned long long *strong, unsigned char *map)
+{
+    hipLaunchKernelGGL(k_bits_to_map, dim3(expand_blocks(g), g.nl, g.B), dim3(256), 0, st, g, weak, strong, map);
+}
+
+void launch_pack_edge_bits(hipStream_t st, const Geom &g, const unsigned char *edge, unsigned long long *bits)
+{
+    hipLaunchKernelGGL(k_pack_edge_bits, dim3(expand_blocks(g), g.nl, g.B), dim3(256), 0, st, g, edge, bits);
 }
 
 }  // namespace aej

@@ -38,7 +38,7 @@ __device__ __forceinline__ long long lvl_off(int ncell, int lv)
 // pass 1: OR-pyramid.  One block per chunk of 16x16 cells; levels 0..4 reduced in LDS, higher levels
 // (only those that can still matter, cell<<lv <= bmax) are set with idempotent stores of 1.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_qt_cells(Geom g, QtGeom q, const unsigned char *__restrict__ map, int edge_value,
+__global__ __launch_bounds__(256) void k_qt_cells(Geom g, QtGeom q, const unsigned long long *__restrict__ edge_bits,
                                                   unsigned char *__restrict__ pyr_all)
 {
     __shared__ unsigned char lv[5][256];
@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void k_qt_cells(Geom g, QtGeom q, const unsign
     int lx, ly;
     morton_decode(tid, lx, ly);
     const int cx = ccx + lx, cy = ccy + ly;
-    const unsigned char *src = map + (long long)b * g.pstride + g.poff[l];
+    const unsigned long long *src = edge_bits + (long long)b * g.bpstride + g.bpoff[l];
+    const int wpr = g.wpr[l];
     unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
     const bool valid = (long long)tid < ncell2;
     unsigned char e = 0;
@@ -62,7 +63,11 @@ __global__ __launch_bounds__(256) void k_qt_cells(Geom g, QtGeom q, const unsign
         int x0 = cx * cell, y0 = cy * cell;
         int x1 = min(x0 + cell, w), y1 = min(y0 + cell, h);
         for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) e |= (src[(long long)y * w + x] == edge_value) ? 1 : 0;
+            for (int xw = x0 >> 6; xw <= (x1 - 1) >> 6; xw++) {
+                int lo = max(x0, xw * 64) - xw * 64, hi = min(x1, xw * 64 + 64) - xw * 64;
+                unsigned long long mask = (hi - lo == 64) ? ~0ull : (((1ull << (hi - lo)) - 1ull) << lo);
+                e |= (src[(long long)y * wpr + xw] & mask) ? 1 : 0;
+            }
         pyr[(long long)cy * ncell + cx] = e;
     }
     lv[0][tid] = e;
@@ -142,21 +147,26 @@ __device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, in
     return r;
 }
 
-__device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int tid, int &total)
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
-    // 256-thread exclusive scan via LDS
-    s_tmp[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        int t = tid >= o ? s_tmp[tid - o] : 0;
-        __syncthreads();
-        s_tmp[tid] += t;
-        __syncthreads();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
     }
-    int incl = s_tmp[tid];
-    total = s_tmp[255];
+    return v;
+}
+
+// exclusive scan of three per-thread values over a 256-thread block: wave shuffles + one barrier
+__device__ __forceinline__ void block_excl_scan3(int v0, int v1, int v2, int (*s_w)[4], int tid, int &e0, int &e1, int &e2)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    int i0 = wave_incl_scan(v0, lane), i1 = wave_incl_scan(v1, lane), i2 = wave_incl_scan(v2, lane);
+    if (lane == 63) { s_w[0][wv] = i0; s_w[1][wv] = i1; s_w[2][wv] = i2; }
     __syncthreads();
-    return incl - v;
+    int p0 = 0, p1 = 0, p2 = 0;
+    for (int k = 0; k < wv; k++) { p0 += s_w[0][k]; p1 += s_w[1][k]; p2 += s_w[2][k]; }
+    e0 = p0 + i0 - v0; e1 = p1 + i1 - v1; e2 = p2 + i2 - v2;
 }
 
 // pass 2: per-chunk totals
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restr
 // pass 4: emit symbols, leaf table and the per-size DCT work lists
 __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
 {
-    __shared__ int s_tmp[256];
+    __shared__ int s_w[3][4];
     __shared__ int s_cnt[kMaxSizes], s_base[kMaxSizes];
     const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
     const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
@@ -244,10 +254,9 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
     c.nsym = 0; c.syms = 0; c.leaf_lvl = -1;
     if ((long long)gidx < ncell2) c = eval_cell(q, l, g.w[l], g.h[l], pyr, gidx);
     const int size = c.leaf_lvl >= 0 ? (q.cell << c.leaf_lvl) : 0;
-    int tot;
-    const int sym_pos = sym_base + block_excl_scan(c.nsym, s_tmp, tid, tot);
-    const int leaf_pos = leaf_base + block_excl_scan(c.leaf_lvl >= 0 ? 1 : 0, s_tmp, tid, tot);
-    const int coef_pos = coef_base + block_excl_scan(size * size, s_tmp, tid, tot);
+    int e0, e1, e2;
+    block_excl_scan3(c.nsym, c.leaf_lvl >= 0 ? 1 : 0, size * size, s_w, tid, e0, e1, e2);
+    const int sym_pos = sym_base + e0, leaf_pos = leaf_base + e1, coef_pos = coef_base + e2;
 
     unsigned char *st = qb.states + (long long)b * q.state_stride + q.state_off[l];
     for (int k = 0; k < c.nsym; k++) {
@@ -297,9 +306,9 @@ static int max_chunks(const Geom &g, const QtGeom &q)
     return m;
 }
 
-void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned char *map, int edge_value, const QtBuffers &qb)
+void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned long long *edge_bits, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_cells, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, map, edge_value, qb.pyr);
+    hipLaunchKernelGGL(k_qt_cells, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, edge_bits, qb.pyr);
 }
 void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
