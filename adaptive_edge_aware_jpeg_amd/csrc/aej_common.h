@@ -45,7 +45,13 @@ struct QtGeom {
     long long leaf_off[3], leaf_stride;
     long long state_off[3], state_stride;
     long long coeff_cap[3], leaf_cap[3], state_cap[3];
+    // per-size DCT work lists: the list of plane (b, l) for size index k starts at element
+    // b * work_stride[k] + work_off[l][k] of work[k] and holds work_count[(b*3+l)*kMaxSizes + k] leaves in Morton order
+    int nsizes;
+    long long work_off[3][kMaxSizes], work_stride[kMaxSizes];
 };
+constexpr int kChunkInts = 4 + kMaxSizes;   // per-chunk record: nsym, nleaf, ncoef, pad, leaves per size
+constexpr int kMaxPlanes = 3072;            // planes (3 x images) one DCT launch can address
 
 // One unit of DCT work (a leaf), appended by the quadtree emit kernel.
 struct LeafWork {

@@ -42,12 +42,12 @@ void launch_bits_to_map(hipStream_t st, const Geom &g, const unsigned long long 
 // quadtree.hip
 struct QtBuffers {
     unsigned char *pyr;     // [B][pyr_stride]
-    int *chunk_cnt;         // [B][chunk_stride][4]  (nsym, nleaf, ncoef, pad) then exclusive offsets after scan
+    int *chunk_cnt;         // [B][chunk_stride][kChunkInts]: counts, then exclusive offsets after the scan
     int *leaves;            // out [B][leaf_stride][4]
     unsigned char *states;  // out [B][state_stride]
     long long *counts;      // out [B][3][4]
-    LeafWork *work[kMaxSizes];   // per-size work lists (may be null when no DCT follows)
-    int *work_count;        // [kMaxSizes]
+    LeafWork *work[kMaxSizes];   // per-size work lists (null when no DCT follows)
+    int *work_count;        // [B*3][kMaxSizes] leaves per plane and size (written by the scan pass); null without DCT
     long long work_cap[kMaxSizes];
     int *overflow;          // [1] set to 1 when a capacity would be exceeded
 };
@@ -62,8 +62,10 @@ struct DctArgs {
     const float *norm;        // [B][pstride] normalised planes
     int *coeffs;              // out [B][coeff_stride]
     float *dct_f32;           // optional
-    const LeafWork *work;     // work list for this size
-    const int *work_count;    // device counter for this size
+    const LeafWork *work;     // work lists for this size (per-plane segments, see QtGeom)
+    const int *work_count;    // [nplanes][kMaxSizes]
+    int k;                    // size index
+    int nplanes;
     const float *D;           // [s][s]
     const int *zzinv;         // [s*s]
     const int *qm[3];         // [s*s] per layer

@@ -193,6 +193,22 @@ static int make_qtgeom(aej_ctx *ctx, const Geom &g, int bmin, int bmax, QtGeom &
     }
     q.pyr_stride = pyr; q.chunk_stride = chunks;
     q.coeff_stride = co; q.leaf_stride = lo; q.state_stride = so;
+    // per-size work lists: worst-case leaves of size s per layer
+    int k = 0;
+    for (int s = bmin; s <= bmax && k < kMaxSizes; s *= 2, k++) {
+        long long off = 0;
+        for (int l = 0; l < g.nl; l++) {
+            q.work_off[l][k] = off;
+            if (s > q.root[l]) continue;
+            int top = bmax < q.root[l] ? bmax : q.root[l];
+            long long wc = align_up(g.w[l], top), hc = align_up(g.h[l], top);
+            if (wc > q.root[l]) wc = q.root[l];
+            if (hc > q.root[l]) hc = q.root[l];
+            off += ((wc + s - 1) / s) * ((hc + s - 1) / s);
+        }
+        q.work_stride[k] = off;
+    }
+    q.nsizes = k;
     return 0;
 }
 
@@ -246,24 +262,14 @@ static void carve_qt(Carver &c, const Geom &g, const QtGeom &q, bool with_work, 
     memset(&w, 0, sizeof w);
     w.zero_begin = reinterpret_cast<char *>(c.take<int>(0));
     w.qb.pyr = c.take<unsigned char>((long long)g.B * q.pyr_stride);
-    w.qb.work_count = c.take<int>(kMaxSizes);
     w.qb.overflow = c.take<int>(1);
     c.take<int>(0);
     w.zero_end = c.base ? c.base + c.off : nullptr;
-    w.qb.chunk_cnt = c.take<int>((long long)g.B * q.chunk_stride * 4);
+    w.qb.chunk_cnt = c.take<int>((long long)g.B * q.chunk_stride * kChunkInts);
     if (with_work) {
-        int k = 0;
-        for (int s = q.bmin; s <= q.bmax && k < kMaxSizes; s *= 2, k++) {
-            long long cap = 0;
-            for (int l = 0; l < g.nl; l++) {
-                if (s > q.root[l]) continue;
-                int top = q.bmax < q.root[l] ? q.bmax : q.root[l];
-                long long wc = align_up(g.w[l], top), hc = align_up(g.h[l], top);
-                if (wc > q.root[l]) wc = q.root[l];
-                if (hc > q.root[l]) hc = q.root[l];
-                cap += ((wc + s - 1) / s) * ((hc + s - 1) / s);
-            }
-            cap *= g.B;
+        w.qb.work_count = c.take<int>((long long)g.B * 3 * kMaxSizes);
+        for (int k = 0; k < q.nsizes; k++) {
+            long long cap = q.work_stride[k] * g.B;
             w.qb.work_cap[k] = cap;
             w.qb.work[k] = c.take<LeafWork>(cap > 0 ? cap : 1);
         }
@@ -491,6 +497,7 @@ static int check_encode_args(aej_ctx *ctx, int batch, int H, int W)
     if (!ctx) return AEJ_ERR_ARG;
     if (!ctx->has_settings) return fail(ctx, AEJ_ERR_STATE, "aej_set_settings has not been called");
     if (batch < 1 || H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "batch, H, W must be positive");
+    if (batch * 3 > kMaxPlanes) return fail(ctx, AEJ_ERR_UNSUPPORTED, "batch %d too large for one call (max %d images)", batch, kMaxPlanes / 3);
     if ((W % 4) != 0 || (H % 2) != 0)
         return fail(ctx, AEJ_ERR_UNSUPPORTED, "image %dx%d: this build needs W %% 4 == 0 and H %% 2 == 0 (fractional INTER_AREA not built)", H, W);
     return 0;
@@ -557,7 +564,7 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
     for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
         DctArgs a;
         a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
-        a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count + k;
+        a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
         a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
         for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
         launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k]);
@@ -724,11 +731,11 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
     g.pstride = (long long)H * W;
     QtGeom q;
     memset(&q, 0, sizeof q);
-    q.bmin = ctx->bmin; q.bmax = ctx->bmax; q.cell = ctx->bmin;
+    q.bmin = ctx->bmin; q.bmax = ctx->bmax; q.cell = ctx->bmin; q.nsizes = ctx->nsizes;   // work_off / work_stride stay 0
     // stage-only scratch (not on the hot path): per-size work lists
     char *scratch = nullptr;
     size_t list_bytes = (size_t)n_leaves * sizeof(LeafWork);
-    size_t total = 256 + (size_t)ctx->nsizes * ((list_bytes + 255) & ~(size_t)255);
+    size_t total = 256 + (size_t)ctx->nsizes * ((list_bytes + 255) & ~(size_t)255);   // 256 B = [3 planes][kMaxSizes] counters
     AEJ_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&scratch), total));
     int *work_count = reinterpret_cast<int *>(scratch);
     LeafWork *work[kMaxSizes] = {};
@@ -740,7 +747,7 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
         for (int s = ctx->bmin; s <= ctx->bmax; s *= 2, k++) {
             DctArgs a;
             a.norm = norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
-            a.work = work[k]; a.work_count = work_count + k;
+            a.work = work[k]; a.work_count = work_count; a.k = k; a.nplanes = 3;
             a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
             for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
             launch_dct(st, s, g, q, a, n_leaves);

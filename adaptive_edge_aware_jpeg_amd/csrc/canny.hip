@@ -115,206 +115,285 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 // halo lies fully inside the image (almost all of them) take the INTERIOR path: no bounds tests, no
 // reflection, dword LDS reads and 4 pixels per thread in the bilateral stage.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAW = kBlurTW + 8;   // LDS row stride (bytes), multiple of 4
-constexpr int kAH = kBlurTH + 6;
-constexpr int kBH = kBlurTH + 4;
-constexpr int kACols = kBlurTW + 6;
+constexpr int kAW = kBlurTW + 8;   // LDS row stride in bytes (72 = 18 dwords); column c <-> gx = x0 - 4 + c
+constexpr int kAW4 = kAW / 4;
+constexpr int kAH = kBlurTH + 6;   // CLAHE rows  [y0-3, y0+TH+3)
+constexpr int kBH = kBlurTH + 4;   // Gauss rows  [y0-2, y0+TH+2)
 
 __constant__ int c_bil_dy[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
 __constant__ int c_bil_dx[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
 
-struct BlurLds {
+struct __attribute__((aligned(16))) BlurLds {
     unsigned char lut[16 * 256];
-    unsigned char A[kAH * kAW];
-    unsigned char Bm[kBH * kAW];
+    unsigned int R[kAH * kAW4];      // raw uint8 source
+    unsigned int A[kAH * kAW4];      // CLAHE image
+    unsigned int Bm[kBH * kAW4];     // Gaussian image
     float cw[256];
     float sw[16];
-    int hist[256];
-    int colOff1[kACols], colOff2[kACols];
-    float colXa[kACols], colXa1[kACols];
+    unsigned int hist16[16 * 128];   // 16 lane-striped copies of 256 packed 16-bit counters
+    int colOff1[kAW], colOff2[kAW];
+    float colXa[kAW], colXa1[kAW];
     int rowOff1[kAH], rowOff2[kAH];
     float rowYa[kAH], rowYa1[kAH];
+    int colSrc[kAW], rowSrc[kAH];    // REFLECT_101-mapped source column / row of every staged column / row
 };
 
-// histogram add with wave-level aggregation of equal values (flat regions put all 64 lanes on one bin)
-__device__ __forceinline__ void hist_add_wave(int *hist, int v, bool valid)
+// Per-tile histogram: lane-striped copies keep same-value lanes of a wave off the same LDS word (flat image
+// regions would otherwise serialise 64-way); two 16-bit counters per word (a tile has 2048 pixels).
+__device__ __forceinline__ void hist_add(BlurLds &L, int v)
 {
-    unsigned long long active = __ballot(valid);
-    const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int it = 0; it < 3 && active; it++) {
-        int lead = __ffsll((long long)active) - 1;
-        int vstar = __shfl(v, lead);
-        unsigned long long m = __ballot(valid && v == vstar) & active;
-        if (lane == lead) atomicAdd(&hist[vstar], __popcll(m));
-        active &= ~m;
-    }
-    if ((active >> lane) & 1ull) atomicAdd(&hist[v], 1);
+    atomicAdd(&L.hist16[(threadIdx.x & 15) * 128 + (v >> 1)], 1u << (16 * (v & 1)));
 }
 
-template <bool INTERIOR>
-__device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb, BlurLds &L, int l, int b, int x0, int y0)
+__device__ __forceinline__ unsigned char clahe_px(const BlurLds &L, int v, int r1, int r2, int c1, int c2, float xa, float xa1, float ya, float ya1)
+{
+    float pa = (float)L.lut[r1 + c1 + v] * xa1;
+    float pb = (float)L.lut[r1 + c2 + v] * xa;
+    float pc = (float)L.lut[r2 + c1 + v] * xa1;
+    float pd = (float)L.lut[r2 + c2 + v] * xa;
+    float top = pa + pb, bot = pc + pd;
+    float t1 = top * ya1, t2 = bot * ya;
+    float res = t1 + t2;
+    int r = __float2int_rn(res);
+    return (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+
+// 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2).  The space weight of
+// tap k is one of 4 values by its radius; the centre tap has |delta| = 0 and cw[0] = sw[6] = 1, so its weight is 1.
+__device__ __forceinline__ unsigned char bilateral_px(const BlurLds &L, const int (&v)[13])
+{
+    const int v0 = v[6];
+    const float s1 = L.sw[5], s2 = L.sw[1], s4 = L.sw[0];     // radius 1, sqrt(2), 2
+    float sum = 0.f, wsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        float wgt;
+        if (k == 6) {
+            wgt = 1.0f;                                         // sw[6] * cw[0] == 1.0f * 1.0f
+        } else {
+            const float sk = (k == 0 || k == 4 || k == 8 || k == 12) ? s4 : (k == 1 || k == 3 || k == 9 || k == 11) ? s2 : s1;
+            int d = (int)__sad(v[k], v0, 0u);
+            wgt = sk * L.cw[d];
+        }
+        wsum = wsum + wgt;
+        sum = __builtin_fmaf((float)v[k], wgt, sum);
+    }
+    int r = __float2int_rn(sum / wsum);
+    return (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+
+// INTERIOR tiles: the whole halo is inside the image -> dword LDS traffic, 4 pixels per thread everywhere.
+// The raw bytes of a tile (38 rows x 18 aligned dwords = 684 dwords, <= 3 per thread) are prefetched into
+// registers one tile ahead by the strip loop, so their HBM latency hides under the previous tile's compute.
+constexpr int kRawPerThread = (kAH * kAW4 + 255) / 256;
+
+__device__ __forceinline__ void blur_prefetch(const unsigned char *src, int w, int x0, int y0, unsigned int (&raw)[kRawPerThread])
+{
+#pragma unroll
+    for (int k = 0; k < kRawPerThread; k++) {
+        int idx = threadIdx.x + k * 256;
+        if (idx < kAH * kAW4) {
+            int j = idx / kAW4, i4 = idx - j * kAW4;
+            raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 3 + j) * w + (x0 - 4) + 4 * i4);
+        }
+    }
+}
+
+// One 64x32 tile from the staged raw bytes in L.R.  For tiles that touch the image border the staging (and the
+// CLAHE parameter arrays) already hold REFLECT_101-mapped data, i.e. the padded CLAHE image; because the Gaussian
+// kernel is symmetric, Gaussian(pad(A)) at a mirrored position equals the mirrored Gaussian, so the padded Gaussian
+// image the bilateral filter needs comes out of the same code.  `full` = the 64x32 outputs all lie inside the image.
+__device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb, BlurLds &L, int l, int b, int x0, int y0, bool full)
 {
     const int tid = threadIdx.x;
     const int w = g.w[l], h = g.h[l];
     const long long pbase = (long long)b * g.pstride + g.poff[l];
-    const unsigned char *src = cb.u8a + pbase;
-
-    // ---- stage A: CLAHE interpolation (CLAHE_Interpolation_Body) on [x0-3, x0+TW+3) x [y0-3, y0+TH+3)
-    for (int idx = tid; idx < kAH * kACols; idx += 256) {
-        int j = idx / kACols, i = idx - j * kACols;
-        int gx = x0 - 3 + i, gy = y0 - 3 + j;
-        if (INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h)) {
-            int v = src[(long long)gy * w + gx];
-            int r1 = L.rowOff1[j] + v, r2 = L.rowOff2[j] + v;
-            int c1 = L.colOff1[i], c2 = L.colOff2[i];
-            float xa = L.colXa[i], xa1 = L.colXa1[i], ya = L.rowYa[j], ya1 = L.rowYa1[j];
-            float pa = (float)L.lut[r1 + c1] * xa1;
-            float pb = (float)L.lut[r1 + c2] * xa;
-            float pc = (float)L.lut[r2 + c1] * xa1;
-            float pd = (float)L.lut[r2 + c2] * xa;
-            float top = pa + pb, bot = pc + pd;
-            float t1 = top * ya1, t2 = bot * ya;
-            float res = t1 + t2;
-            int r = __float2int_rn(res);
-            unsigned char o = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
-            L.A[j * kAW + i] = o;
-            if (cb.dump_clahe && i >= 3 && i < kBlurTW + 3 && j >= 3 && j < kBlurTH + 3 && gx < w && gy < h)
-                cb.dump_clahe[pbase + (long long)gy * w + gx] = o;
-        }
+    // ---- stage A: CLAHE interpolation, 4 pixels (one dword) per item
+    for (int idx = tid; idx < kAH * kAW4; idx += 256) {
+        int j = idx / kAW4, i4 = idx - j * kAW4;
+        unsigned int rv = L.R[idx];
+#if defined(AEJ_ABLATE) && (AEJ_ABLATE == 3 || AEJ_ABLATE == 5)
+        L.A[idx] = rv; continue;
+#endif
+        const int4 c1 = reinterpret_cast<const int4 *>(L.colOff1)[i4], c2 = reinterpret_cast<const int4 *>(L.colOff2)[i4];
+        const float4 xa = reinterpret_cast<const float4 *>(L.colXa)[i4], xa1 = reinterpret_cast<const float4 *>(L.colXa1)[i4];
+        const int r1 = L.rowOff1[j], r2 = L.rowOff2[j];
+        const float ya = L.rowYa[j], ya1 = L.rowYa1[j];
+        unsigned int o0 = clahe_px(L, rv & 0xff, r1, r2, c1.x, c2.x, xa.x, xa1.x, ya, ya1);
+        unsigned int o1 = clahe_px(L, (rv >> 8) & 0xff, r1, r2, c1.y, c2.y, xa.y, xa1.y, ya, ya1);
+        unsigned int o2 = clahe_px(L, (rv >> 16) & 0xff, r1, r2, c1.z, c2.z, xa.z, xa1.z, ya, ya1);
+        unsigned int o3 = clahe_px(L, rv >> 24, r1, r2, c1.w, c2.w, xa.w, xa1.w, ya, ya1);
+        L.A[idx] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
     }
     __syncthreads();
-
-    // ---- stage B: Gaussian [1 2 1]^2, (sum + 8) >> 4, REFLECT_101, on [x0-2, x0+TW+2) x [y0-2, y0+TH+2)
-    for (int idx = tid; idx < kBH * (kBlurTW + 4); idx += 256) {
-        int j = idx / (kBlurTW + 4), i = idx - j * (kBlurTW + 4);
-        int gx = x0 - 2 + i, gy = y0 - 2 + j;
-        if (INTERIOR) {
-            const unsigned char *r0 = L.A + j * kAW + i, *r1 = r0 + kAW, *r2 = r1 + kAW;   // rows gy-1.., cols gx-1..
-            int s = (r0[0] + 2 * r0[1] + r0[2]) + 2 * (r1[0] + 2 * r1[1] + r1[2]) + (r2[0] + 2 * r2[1] + r2[2]);
-            unsigned char o = (unsigned char)((s + 8) >> 4);
-            L.Bm[j * kAW + i] = o;
-            if (cb.dump_gauss && i >= 2 && i < kBlurTW + 2 && j >= 2 && j < kBlurTH + 2) cb.dump_gauss[pbase + (long long)gy * w + gx] = o;
-        } else if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-            int xm = reflect101(gx - 1, w) - (x0 - 3), xc = gx - (x0 - 3), xp = reflect101(gx + 1, w) - (x0 - 3);
-            int ym = reflect101(gy - 1, h) - (y0 - 3), yc = gy - (y0 - 3), yp = reflect101(gy + 1, h) - (y0 - 3);
-            const unsigned char *r0 = L.A + ym * kAW, *r1 = L.A + yc * kAW, *r2 = L.A + yp * kAW;
-            int s = (r0[xm] + 2 * r0[xc] + r0[xp]) + 2 * (r1[xm] + 2 * r1[xc] + r1[xp]) + (r2[xm] + 2 * r2[xc] + r2[xp]);
-            unsigned char o = (unsigned char)((s + 8) >> 4);
-            L.Bm[j * kAW + i] = o;
-            if (cb.dump_gauss && i >= 2 && i < kBlurTW + 2 && j >= 2 && j < kBlurTH + 2) cb.dump_gauss[pbase + (long long)gy * w + gx] = o;
-        }
-    }
-    __syncthreads();
-
-    // ---- stage C: bilateral, 13 taps in row-major order, w = sw*cw, wsum += w, sum = fma(v, w, sum)
-    unsigned char *dst = cb.u8b + pbase;
-    if (INTERIOR) {
-        // 4 consecutive pixels per thread; 5 rows x 8 bytes of the Gaussian image held in 10 registers
-        const int cx = (tid & 15) * 4;
-#pragma unroll 1
-        for (int pass = 0; pass < kBlurTH / 16; pass++) {
-            const int j = (tid >> 4) + pass * 16;
-            unsigned int rw[5][2];
-#pragma unroll
-            for (int r = 0; r < 5; r++) {
-                const unsigned int *p = reinterpret_cast<const unsigned int *>(L.Bm + (j + r) * kAW + cx);
-                rw[r][0] = p[0]; rw[r][1] = p[1];
-            }
-            unsigned char o[4];
-#pragma unroll
-            for (int px = 0; px < 4; px++) {
-                const int cc = px + 2;
-                const int v0 = (int)((rw[2][cc >> 2] >> (8 * (cc & 3))) & 0xffu);
-                float sum = 0.f, wsum = 0.f;
-#pragma unroll
-                for (int k = 0; k < 13; k++) {
-                    constexpr int dys[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
-                    constexpr int dxs[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
-                    const int rr = 2 + dys[k], c = cc + dxs[k];
-                    const int v = (int)((rw[rr][c >> 2] >> (8 * (c & 3))) & 0xffu);
-                    int d = v - v0;
-                    d = d < 0 ? -d : d;
-                    float wgt = L.sw[k] * L.cw[d];
-                    wsum = wsum + wgt;
-                    sum = __builtin_fmaf((float)v, wgt, sum);
-                }
-                int r = __float2int_rn(sum / wsum);
-                o[px] = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
-            }
-            *reinterpret_cast<uchar4 *>(dst + (long long)(y0 + j) * w + x0 + cx) = make_uchar4(o[0], o[1], o[2], o[3]);
-#pragma unroll
-            for (int px = 0; px < 4; px++) hist_add_wave(L.hist, o[px], true);
-        }
-    } else {
-        for (int idx = tid; idx < kBlurTW * kBlurTH; idx += 256) {
+    if (cb.dump_clahe)
+        for (int idx = tid; idx < kBlurTH * kBlurTW; idx += 256) {
             int j = idx / kBlurTW, i = idx - j * kBlurTW;
-            int gx = x0 + i, gy = y0 + j;
-            if (gx < w && gy < h) {
-                int v0 = L.Bm[(j + 2) * kAW + (i + 2)];
-                float sum = 0.f, wsum = 0.f;
+            if (x0 + i < w && y0 + j < h)
+                cb.dump_clahe[pbase + (long long)(y0 + j) * w + x0 + i] = reinterpret_cast<const unsigned char *>(L.A)[(j + 3) * kAW + i + 4];
+        }
+    // ---- stage B: Gaussian [1 2 1]^2, (sum + 8) >> 4, SWAR on even/odd bytes (16-bit fields hold <= 4088)
+    for (int idx = tid; idx < kBH * kAW4; idx += 256) {
+        int j = idx / kAW4, i4 = idx - j * kAW4;
+        const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kAW4 - 1 ? i4 + 1 : kAW4 - 1;   // edge dwords feed unused columns only
+#if defined(AEJ_ABLATE) && (AEJ_ABLATE == 4 || AEJ_ABLATE == 5)
+        L.Bm[idx] = L.A[(j + 1) * kAW4 + i4]; continue;
+#endif
+        unsigned int he[3], ho[3];
 #pragma unroll
-                for (int k = 0; k < 13; k++) {
-                    int yy = reflect101(gy + c_bil_dy[k], h) - (y0 - 2);
-                    int xx = reflect101(gx + c_bil_dx[k], w) - (x0 - 2);
-                    int v = L.Bm[yy * kAW + xx];
-                    int d = v - v0;
-                    d = d < 0 ? -d : d;
-                    float wgt = L.sw[k] * L.cw[d];
-                    wsum = wsum + wgt;
-                    sum = __builtin_fmaf((float)v, wgt, sum);
-                }
-                int r = __float2int_rn(sum / wsum);
-                unsigned char o = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
-                dst[(long long)gy * w + gx] = o;
-                atomicAdd(&L.hist[o], 1);
+        for (int r = 0; r < 3; r++) {
+            const unsigned int *row = L.A + (j + r) * kAW4;
+            unsigned int m = row[i4], lf = row[il], rt = row[ir];
+            unsigned int sl = __builtin_amdgcn_alignbyte(m, lf, 3);    // bytes b[-1], b0, b1, b2
+            unsigned int sr = __builtin_amdgcn_alignbyte(rt, m, 1);    // bytes b1, b2, b3, b4
+            const unsigned int M = 0x00FF00FFu;
+            he[r] = (sl & M) + 2u * (m & M) + (sr & M);
+            ho[r] = ((sl >> 8) & M) + 2u * ((m >> 8) & M) + ((sr >> 8) & M);
+        }
+        unsigned int ve = he[0] + 2u * he[1] + he[2] + 0x00080008u;
+        unsigned int vo = ho[0] + 2u * ho[1] + ho[2] + 0x00080008u;
+        L.Bm[idx] = ((ve >> 4) & 0x00FF00FFu) | (((vo >> 4) & 0x00FF00FFu) << 8);
+    }
+    __syncthreads();
+    if (cb.dump_gauss)
+        for (int idx = tid; idx < kBlurTH * kBlurTW; idx += 256) {
+            int j = idx / kBlurTW, i = idx - j * kBlurTW;
+            if (x0 + i < w && y0 + j < h)
+                cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] = reinterpret_cast<const unsigned char *>(L.Bm)[(j + 2) * kAW + i + 4];
+        }
+    // ---- stage C: bilateral, 4 consecutive pixels per thread; 5 rows x 12 bytes of the Gaussian image in registers
+    unsigned char *dst = cb.u8b + pbase;
+    const int c4 = tid & 15;           // output pixels x0 + 4*c4 .. +3  <->  window bytes 2..9 of dwords c4 .. c4+2
+#pragma unroll 1
+    for (int pass = 0; pass < kBlurTH / 16; pass++) {
+        const int j = (tid >> 4) + pass * 16;
+        unsigned int rw[5][3];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const unsigned int *p = L.Bm + (j + r) * kAW4 + c4;
+            rw[r][0] = p[0]; rw[r][1] = p[1]; rw[r][2] = p[2];
+        }
+        unsigned int o[4];
+#pragma unroll
+        for (int px = 0; px < 4; px++) {
+#if defined(AEJ_ABLATE) && (AEJ_ABLATE == 2 || AEJ_ABLATE == 5)
+            o[px] = (rw[2][(px + 4) >> 2] >> (8 * ((px + 4) & 3))) & 0xffu; continue;
+#endif
+            constexpr int dys[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
+            constexpr int dxs[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
+            int v[13];
+#pragma unroll
+            for (int k = 0; k < 13; k++) {
+                const int rr = 2 + dys[k], c = px + 4 + dxs[k];
+                v[k] = (int)((rw[rr][c >> 2] >> (8 * (c & 3))) & 0xffu);
             }
+            o[px] = bilateral_px(L, v);
+        }
+        if (full) {
+            *reinterpret_cast<unsigned int *>(dst + (long long)(y0 + j) * w + x0 + 4 * c4) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+#if !defined(AEJ_ABLATE) || (AEJ_ABLATE != 1 && AEJ_ABLATE != 5)
+#pragma unroll
+            for (int px = 0; px < 4; px++) hist_add(L, (int)o[px]);
+#endif
+        } else if (y0 + j < h) {
+#pragma unroll
+            for (int px = 0; px < 4; px++)
+                if (x0 + 4 * c4 + px < w) {
+                    dst[(long long)(y0 + j) * w + x0 + 4 * c4 + px] = (unsigned char)o[px];
+                    hist_add(L, (int)o[px]);
+                }
         }
     }
 }
 
+constexpr int kStrip = 8;    // tiles of one tile-row handled by one workgroup (LUT / tables / histogram stay in LDS)
+
+__device__ __forceinline__ bool locate_strip(const Geom &g, int t, int &layer, int &sx, int &ty)
+{
+    for (int l = 0; l < g.nl; l++) {
+        int ntx = cdiv(g.w[l], kBlurTW), nty = cdiv(g.h[l], kBlurTH), nsx = cdiv(ntx, kStrip);
+        int n = nsx * nty;
+        if (t < n) { layer = l; ty = t / nsx; sx = t - ty * nsx; return true; }
+        t -= n;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
 {
-    __shared__ __attribute__((aligned(16))) BlurLds L;
+    __shared__ BlurLds L;
     const int tid = threadIdx.x, b = blockIdx.y;
-    int l, tx, ty, ntx, nty, tbase;
-    if (!locate_tile(g, kBlurTW, kBlurTH, blockIdx.x, l, tx, ty, ntx, nty, tbase)) return;
+    int l, sx, ty;
+    if (!locate_strip(g, blockIdx.x, l, sx, ty)) return;
     const int w = g.w[l], h = g.h[l];
-    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
+    const int ntx = cdiv(w, kBlurTW);
+    const int y0 = ty * kBlurTH;
+    const int tx_begin = sx * kStrip, tx_end = min(ntx, tx_begin + kStrip);
+    const unsigned char *src = cb.u8a + (long long)b * g.pstride + g.poff[l];
 
     reinterpret_cast<uint4 *>(L.lut)[tid] = reinterpret_cast<const uint4 *>(cb.lut + ((long long)b * 3 + l) * 4096)[tid];
     L.cw[tid] = cb.color_w[tid];
     if (tid < 13) L.sw[tid] = cb.space_w[tid];
-    L.hist[tid] = 0;
-    // per-column / per-row interpolation parameters of CLAHE_Interpolation_Body (clahe.cpp)
-    if (tid < kACols) {
-        const float inv_tw = 1.0f / (float)g.ctw[l];
-        float txf = (float)(x0 - 3 + tid) * inv_tw - 0.5f;
-        int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
-        float xa = txf - (float)tx1;
-        L.colXa[tid] = xa; L.colXa1[tid] = 1.0f - xa;
-        if (tx1 < 0) tx1 = 0;
-        if (tx2 > 3) tx2 = 3;
-        L.colOff1[tid] = tx1 * 256; L.colOff2[tid] = tx2 * 256;
-    } else if (tid >= 128 && tid < 128 + kAH) {
+    for (int i = tid; i < 16 * 128; i += 256) L.hist16[i] = 0;
+    if (tid >= 128 && tid < 128 + kAH) {      // row parameters of CLAHE_Interpolation_Body: fixed for the strip
         const int j = tid - 128;
+        const int gy = reflect101(y0 - 3 + j, h);
         const float inv_th = 1.0f / (float)g.cth[l];
-        float tyf = (float)(y0 - 3 + j) * inv_th - 0.5f;
+        float tyf = (float)gy * inv_th - 0.5f;
         int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
         float ya = tyf - (float)ty1;
         L.rowYa[j] = ya; L.rowYa1[j] = 1.0f - ya;
         if (ty1 < 0) ty1 = 0;
         if (ty2 > 3) ty2 = 3;
         L.rowOff1[j] = ty1 * 1024; L.rowOff2[j] = ty2 * 1024;
+        L.rowSrc[j] = gy;
+    }
+    // a tile is "aligned" when its staged window [x0-4, x0+68) x [y0-3, y0+35) lies inside the image: dword prefetch
+    auto is_aligned = [&](int tx) {
+        int x0 = tx * kBlurTW;
+        return x0 >= 4 && y0 >= 3 && x0 + kBlurTW + 4 <= w && y0 + kBlurTH + 3 <= h && (w % 4) == 0;
+    };
+    unsigned int raw[kRawPerThread];
+    if (is_aligned(tx_begin)) blur_prefetch(src, w, tx_begin * kBlurTW, y0, raw);
+
+    for (int tx = tx_begin; tx < tx_end; tx++) {
+        const int x0 = tx * kBlurTW;
+        const bool aligned = is_aligned(tx);
+        if (tid < kAW) {                       // column parameters for this tile (reflected at the image border)
+            const int gx = reflect101(x0 - 4 + tid, w);
+            const float inv_tw = 1.0f / (float)g.ctw[l];
+            float txf = (float)gx * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            float xa = txf - (float)tx1;
+            L.colXa[tid] = xa; L.colXa1[tid] = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > 3) tx2 = 3;
+            L.colOff1[tid] = tx1 * 256; L.colOff2[tid] = tx2 * 256;
+            L.colSrc[tid] = gx;
+        }
+        if (aligned) {
+#pragma unroll
+            for (int k = 0; k < kRawPerThread; k++) {
+                int idx = tid + k * 256;
+                if (idx < kAH * kAW4) L.R[idx] = raw[k];
+            }
+        } else {
+            __syncthreads();                   // colSrc / rowSrc visible
+            unsigned char *R8 = reinterpret_cast<unsigned char *>(L.R);
+            for (int idx = tid; idx < kAH * kAW; idx += 256) {
+                int j = idx / kAW, c = idx - j * kAW;
+                R8[idx] = src[(long long)L.rowSrc[j] * w + L.colSrc[c]];
+            }
+        }
+        __syncthreads();
+        if (tx + 1 < tx_end && is_aligned(tx + 1)) blur_prefetch(src, w, (tx + 1) * kBlurTW, y0, raw);
+        blur_tile(g, cb, L, l, b, x0, y0, x0 + kBlurTW <= w && y0 + kBlurTH <= h && (w % 4) == 0);
     }
     __syncthreads();
-
-    const bool interior = x0 >= 3 && y0 >= 3 && x0 + kBlurTW + 3 <= w && y0 + kBlurTH + 3 <= h && (w % 4) == 0;
-    if (interior) blur_tile<true>(g, cb, L, l, b, x0, y0);
-    else blur_tile<false>(g, cb, L, l, b, x0, y0);
-    __syncthreads();
-    int c = L.hist[tid];
-    if (c) atomicAdd(&cb.blur_hist[((long long)b * 3 + l) * 256 + tid], c);
+    unsigned int c = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) c += (L.hist16[k * 128 + (tid >> 1)] >> (16 * (tid & 1))) & 0xffffu;
+    if (c) atomicAdd(&cb.blur_hist[((long long)b * 3 + l) * 256 + tid], (int)c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -621,7 +700,11 @@ void launch_clahe_lut(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 
 void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
-    long long t = tiles_per_image(g, kBlurTW, kBlurTH);
+    long long t = 0;
+    for (int l = 0; l < g.nl; l++) {
+        int ntx = (g.w[l] + kBlurTW - 1) / kBlurTW, nty = (g.h[l] + kBlurTH - 1) / kBlurTH;
+        t += (long long)((ntx + kStrip - 1) / kStrip) * nty;
+    }
     hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)t, g.B), dim3(256), 0, st, g, cb);
 }
 

@@ -31,6 +31,48 @@ __device__ __forceinline__ int quantise(float y, int q)
     return (int)rint(v);
 }
 
+// Work items of one block size are the concatenation, over planes (b, l), of that plane's Morton-ordered leaf list.
+// s_pref[p] = number of items in planes < p (built once per workgroup by wave 0); an item index is mapped back to
+// (plane, index in plane) with a binary search.
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void build_plane_prefix(const DctArgs &a, int *s_pref)
+{
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int carry = 0;
+        if (lane == 0) s_pref[0] = 0;
+        for (int base = 0; base < a.nplanes; base += 64) {
+            int p = base + lane;
+            int v = p < a.nplanes ? a.work_count[(long long)p * kMaxSizes + a.k] : 0;
+            int inc = wave_incl_scan_i(v, lane);
+            if (p < a.nplanes) s_pref[p + 1] = carry + inc;
+            carry += __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int4 fetch_item(const DctArgs &a, const QtGeom &q, const int *s_pref, long long item)
+{
+    int lo = 0, hi = a.nplanes;          // largest p with s_pref[p] <= item
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if ((long long)s_pref[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int b = lo / 3, l = lo - 3 * b;
+    const long long idx = (long long)b * q.work_stride[a.k] + q.work_off[l][a.k] + (item - s_pref[lo]);
+    return reinterpret_cast<const int4 *>(a.work)[idx];
+}
+
 // ------------------------------------------------------------------------------------------------
 // small blocks: S in {2, 4, 8, 16}; 256 threads = 256/S leaves, S threads per leaf
 // ------------------------------------------------------------------------------------------------
@@ -44,19 +86,21 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
     __shared__ float sD[SS];
     __shared__ int sZ[SS];
     __shared__ int sQm[3 * SS];
+    extern __shared__ int s_pref[];
     const int tid = threadIdx.x;
     for (int i = tid; i < SS; i += 256) { sD[i] = a.D[i]; sZ[i] = a.zzinv[i]; }
     for (int i = tid; i < 3 * SS; i += 256) sQm[i] = a.qm[i / SS] ? a.qm[i / SS][i % SS] : 1;
-    __syncthreads();
-    long long count = *a.work_count;
+    build_plane_prefix(a, s_pref);
+    long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
     const int slot = tid / S, j = tid % S;
     for (long long base = (long long)blockIdx.x * LPB; base < count; base += (long long)gridDim.x * LPB) {
         const long long item = base + slot;
         const bool active = item < count;
         int layer = 0;
+        int4 wk = make_int4(0, 0, 0, 0);
         if (active) {
-            int4 wk = reinterpret_cast<const int4 *>(a.work)[item];
+            wk = fetch_item(a, q, s_pref, item);
             const int b = wk.x / 3;
             layer = wk.x - b * 3;
             const int w = g.w[layer], h = g.h[layer];
@@ -78,7 +122,6 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
         __syncthreads();
         long long out_base = 0;
         if (active) {
-            int4 wk = reinterpret_cast<const int4 *>(a.work)[item];
             const int b = wk.x / 3;
             out_base = (long long)b * q.coeff_stride + q.coeff_off[layer] + wk.w;
             // Y[i][jj] = sum_k T[i][k] D[jj][k], this thread owns row i = j
@@ -121,6 +164,7 @@ __global__ __launch_bounds__((S / 32) * (S / 32) * 64) void k_dct_mfma(Geom g, Q
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sX = smem;            // [S][S]  X, later reused as int staging for the zigzag scatter
     float *sP = smem + SS;       // [S][S]  P = T^T
+    int *s_pref = reinterpret_cast<int *>(smem + 2 * SS);   // [nplanes + 1]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wi = wave / NT, wj = wave % NT;
@@ -132,10 +176,11 @@ __global__ __launch_bounds__((S / 32) * (S / 32) * 64) void k_dct_mfma(Geom g, Q
 #pragma unroll
     for (int s = 0; s < S / 2; s++) dreg[s] = a.D[(J0 + li) * S + 2 * s + lh];
 
-    long long count = *a.work_count;
+    build_plane_prefix(a, s_pref);
+    long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
     for (long long item = blockIdx.x; item < count; item += gridDim.x) {
-        const int4 wk = reinterpret_cast<const int4 *>(a.work)[item];
+        const int4 wk = fetch_item(a, q, s_pref, item);
         const int b = wk.x / 3, layer = wk.x - b * 3;
         const int w = g.w[layer], h = g.h[layer];
         const float *src = a.norm + (long long)b * g.pstride + g.poff[layer];
@@ -200,7 +245,7 @@ __global__ __launch_bounds__(256) void k_work_from_leaves(const int *__restrict_
     int4 lf = reinterpret_cast<const int4 *>(leaves)[i];
     int k = (31 - __clz(lf.z)) - bmin_log2;
     if (k < 0 || k >= kMaxSizes || !wp.w[k]) return;
-    int pos = atomicAdd(&work_count[k], 1);
+    int pos = atomicAdd(&work_count[plane * kMaxSizes + k], 1);
     reinterpret_cast<int4 *>(wp.w[k])[pos] = make_int4(plane, lf.x, lf.y, lf.w);
 }
 
@@ -216,27 +261,28 @@ template <int S>
 static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, int blocks)
 {
     constexpr int NT = S / 32;
-    size_t lds = (size_t)2 * S * S * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    size_t lds = (size_t)2 * S * S * sizeof(float) + (size_t)(a.nplanes + 1) * sizeof(int);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dct_mfma<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_lds = lds;
     }
     hipLaunchKernelGGL(k_dct_mfma<S>, dim3(blocks), dim3(NT * NT * 64), lds, st, g, q, a, max_items);
 }
 
 void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
 {
-    if (max_items <= 0) return;
+    if (max_items <= 0 || a.nplanes > kMaxPlanes) return;
+    const size_t pref = (size_t)(a.nplanes + 1) * sizeof(int);
     auto cap = [&](long long per_block, int hi) {
         long long b = (max_items + per_block - 1) / per_block;
         return (int)(b < 1 ? 1 : b > hi ? hi : b);
     };
     switch (size) {
-    case 2: hipLaunchKernelGGL(k_dct_small<2>, dim3(cap(128, 2048)), dim3(256), 0, st, g, q, a, max_items); break;
-    case 4: hipLaunchKernelGGL(k_dct_small<4>, dim3(cap(64, 4096)), dim3(256), 0, st, g, q, a, max_items); break;
-    case 8: hipLaunchKernelGGL(k_dct_small<8>, dim3(cap(32, 4096)), dim3(256), 0, st, g, q, a, max_items); break;
-    case 16: hipLaunchKernelGGL(k_dct_small<16>, dim3(cap(16, 4096)), dim3(256), 0, st, g, q, a, max_items); break;
+    case 2: hipLaunchKernelGGL(k_dct_small<2>, dim3(cap(128, 2048)), dim3(256), pref, st, g, q, a, max_items); break;
+    case 4: hipLaunchKernelGGL(k_dct_small<4>, dim3(cap(64, 4096)), dim3(256), pref, st, g, q, a, max_items); break;
+    case 8: hipLaunchKernelGGL(k_dct_small<8>, dim3(cap(32, 4096)), dim3(256), pref, st, g, q, a, max_items); break;
+    case 16: hipLaunchKernelGGL(k_dct_small<16>, dim3(cap(16, 4096)), dim3(256), pref, st, g, q, a, max_items); break;
     case 32: launch_mfma_t<32>(st, g, q, a, max_items, cap(1, 4096)); break;
     case 64: launch_mfma_t<64>(st, g, q, a, max_items, cap(1, 1024)); break;
     case 128: launch_mfma_t<128>(st, g, q, a, max_items, cap(1, 256)); break;

@@ -169,62 +169,77 @@ __device__ __forceinline__ void block_excl_scan3(int v0, int v1, int v2, int (*s
     e0 = p0 + i0 - v0; e1 = p1 + i1 - v1; e2 = p2 + i2 - v2;
 }
 
-// pass 2: per-chunk totals
+// pass 2: per-chunk totals (symbols, leaves, coefficients, leaves per block size)
 __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsigned char *__restrict__ pyr_all, int *__restrict__ chunk_cnt)
 {
-    __shared__ int s_red[3][4];
+    __shared__ int s_red[3 + kMaxSizes][4];
     const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
     const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
     if ((long long)blockIdx.x >= q.nchunk[l]) return;
     const unsigned gidx = blockIdx.x * 256u + tid;
     const unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
-    int nsym = 0, nleaf = 0, ncoef = 0;
+    int nsym = 0, nleaf = 0, ncoef = 0, lvl = -1;
     if ((long long)gidx < ncell2) {
         CellNodes c = eval_cell(q, l, g.w[l], g.h[l], pyr, gidx);
         nsym = c.nsym;
-        if (c.leaf_lvl >= 0) { nleaf = 1; int s = q.cell << c.leaf_lvl; ncoef = s * s; }
+        lvl = c.leaf_lvl;
+        if (lvl >= 0) { nleaf = 1; int s = q.cell << lvl; ncoef = s * s; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         nsym += __shfl_down(nsym, o);
         nleaf += __shfl_down(nleaf, o);
         ncoef += __shfl_down(ncoef, o);
     }
-    if ((tid & 63) == 0) { s_red[0][tid >> 6] = nsym; s_red[1][tid >> 6] = nleaf; s_red[2][tid >> 6] = ncoef; }
+    const int wv = tid >> 6;
+    if ((tid & 63) == 0) { s_red[0][wv] = nsym; s_red[1][wv] = nleaf; s_red[2][wv] = ncoef; }
+    for (int k = 0; k < q.nsizes; k++) {
+        unsigned long long m = __ballot(lvl == k);
+        if ((tid & 63) == 0) s_red[3 + k][wv] = __popcll(m);
+    }
     __syncthreads();
-    if (tid < 3) {
-        int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * 4;
-        o[tid] = s_red[tid][0] + s_red[tid][1] + s_red[tid][2] + s_red[tid][3];
+    if (tid < 3 + kMaxSizes) {
+        int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * kChunkInts;
+        int v = (tid < 3 || tid - 3 < q.nsizes) ? s_red[tid][0] + s_red[tid][1] + s_red[tid][2] + s_red[tid][3] : 0;
+        o[tid < 3 ? tid : tid + 1] = v;
     }
 }
 
-// pass 3: exclusive scan of the chunk totals per (image, layer); totals -> counts
-__global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restrict__ chunk_cnt, long long *__restrict__ counts)
+// pass 3: exclusive scan of the chunk records per (image, layer); totals -> counts and per-plane work counts
+__global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restrict__ chunk_cnt, long long *__restrict__ counts,
+                                                  int *__restrict__ work_count)
 {
-    __shared__ int s[3][1024];
-    __shared__ int carry[3];
+    constexpr int NQ = 3 + kMaxSizes;
+    __shared__ int s_w[NQ][16];
+    __shared__ int carry[NQ];
     const int tid = threadIdx.x, l = blockIdx.x, b = blockIdx.y;
-    int *base = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l]) * 4;
+    const int lane = tid & 63, wv = tid >> 6;
+    int *base = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l]) * kChunkInts;
     const int n = q.nchunk[l];
-    if (tid < 3) carry[tid] = 0;
+    const int nq = 3 + q.nsizes;
+    if (tid < NQ) carry[tid] = 0;
     __syncthreads();
     for (int start = 0; start < n; start += 1024) {
-        int i = start + tid;
-        int v[3] = { 0, 0, 0 };
-        if (i < n) { v[0] = base[i * 4 + 0]; v[1] = base[i * 4 + 1]; v[2] = base[i * 4 + 2]; }
-        for (int c = 0; c < 3; c++) s[c][tid] = v[c];
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int t[3];
-            for (int c = 0; c < 3; c++) t[c] = tid >= o ? s[c][tid - o] : 0;
-            __syncthreads();
-            for (int c = 0; c < 3; c++) s[c][tid] += t[c];
-            __syncthreads();
+        const int i = start + tid;
+        int v[NQ], inc[NQ];
+#pragma unroll
+        for (int c = 0; c < NQ; c++) {
+            v[c] = (i < n && c < nq) ? base[i * kChunkInts + (c < 3 ? c : c + 1)] : 0;
+            inc[c] = wave_incl_scan(v[c], lane);
+            if (lane == 63) s_w[c][wv] = inc[c];
         }
-        if (i < n)
-            for (int c = 0; c < 3; c++) base[i * 4 + c] = carry[c] + s[c][tid] - v[c];
         __syncthreads();
-        if (tid == 1023)
-            for (int c = 0; c < 3; c++) carry[c] += s[c][1023];
+#pragma unroll
+        for (int c = 0; c < NQ; c++) {
+            int p = carry[c];
+            for (int k = 0; k < wv; k++) p += s_w[c][k];
+            if (i < n && c < nq) base[i * kChunkInts + (c < 3 ? c : c + 1)] = p + inc[c] - v[c];
+        }
+        __syncthreads();
+        if (tid < NQ) {
+            int t = 0;
+            for (int k = 0; k < 16; k++) t += s_w[tid][k];
+            carry[tid] += t;
+        }
         __syncthreads();
     }
     if (tid == 0) {
@@ -234,21 +249,23 @@ __global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restr
         o[2] = carry[0];      // n_states
         o[3] = q.root[l];
     }
+    if (work_count && tid < kMaxSizes) work_count[((long long)b * 3 + l) * kMaxSizes + tid] = tid < q.nsizes ? carry[3 + tid] : 0;
 }
 
-// pass 4: emit symbols, leaf table and the per-size DCT work lists
+// pass 4: emit symbols, leaf table and the per-size DCT work lists (positions come from the scans: deterministic,
+// Morton-ordered lists, no global atomics)
 __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
 {
     __shared__ int s_w[3][4];
-    __shared__ int s_cnt[kMaxSizes], s_base[kMaxSizes];
+    __shared__ int s_wc[4][kMaxSizes];
     const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
+    const int lane = tid & 63, wv = tid >> 6;
     const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
     if ((long long)blockIdx.x >= q.nchunk[l]) return;
     const unsigned gidx = blockIdx.x * 256u + tid;
     const unsigned char *pyr = qb.pyr + (long long)b * q.pyr_stride + q.pyr_off[l];
-    const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * 4;
+    const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * kChunkInts;
     const int sym_base = coff[0], leaf_base = coff[1], coef_base = coff[2];
-    if (tid < kMaxSizes) s_cnt[tid] = 0;
 
     CellNodes c;
     c.nsym = 0; c.syms = 0; c.leaf_lvl = -1;
@@ -263,36 +280,36 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
         if (sym_pos + k < q.state_cap[l]) st[sym_pos + k] = (unsigned char)((c.syms >> (2 * k)) & 3u);
         else *qb.overflow = 1;
     }
-    int widx = -1, kidx = 0;
+    int cx = 0, cy = 0;
+    bool leaf_ok = false;
     if (c.leaf_lvl >= 0) {
-        int cx, cy;
         morton_decode(gidx, cx, cy);
         if (leaf_pos < q.leaf_cap[l] && (long long)coef_pos + (long long)size * size <= q.coeff_cap[l]) {
             int *lf = qb.leaves + ((long long)b * q.leaf_stride + q.leaf_off[l] + leaf_pos) * 4;
             reinterpret_cast<int4 *>(lf)[0] = make_int4(cx * q.cell, cy * q.cell, size, coef_pos);
-            if (qb.work_count) {
-                kidx = c.leaf_lvl;     // size == bmin << kidx (host guarantees cell == bmin here)
-                widx = atomicAdd(&s_cnt[kidx], 1);
-            }
+            leaf_ok = true;
         } else {
             *qb.overflow = 1;
         }
     }
     if (!qb.work_count) return;
+    // rank of this leaf among the leaves of its size inside the chunk
+    int rank = 0;
+    for (int k = 0; k < q.nsizes; k++) {
+        unsigned long long m = __ballot(c.leaf_lvl == k);
+        if (c.leaf_lvl == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wc[wv][k] = __popcll(m);
+    }
     __syncthreads();
-    if (tid < kMaxSizes && s_cnt[tid] > 0) s_base[tid] = atomicAdd(&qb.work_count[tid], s_cnt[tid]);
-    __syncthreads();
-    if (widx >= 0) {
-        long long pos = (long long)s_base[kidx] + widx;
-        if (pos < qb.work_cap[kidx]) {
-            int cx, cy;
-            morton_decode(gidx, cx, cy);
-            LeafWork wk;
-            wk.plane = b * 3 + l; wk.x = cx * q.cell; wk.y = cy * q.cell; wk.coef = coef_pos;
-            reinterpret_cast<int4 *>(qb.work[kidx])[pos] = make_int4(wk.plane, wk.x, wk.y, wk.coef);
-        } else {
+    if (leaf_ok) {
+        const int k = c.leaf_lvl;      // size == bmin << k (the codec path always has cell == bmin)
+        for (int w2 = 0; w2 < wv; w2++) rank += s_wc[w2][k];
+        long long pos = (long long)coff[4 + k] + rank;
+        long long seg = (long long)b * q.work_stride[k] + q.work_off[l][k];
+        if (seg + pos < qb.work_cap[k])
+            reinterpret_cast<int4 *>(qb.work[k])[seg + pos] = make_int4(b * 3 + l, cx * q.cell, cy * q.cell, coef_pos);
+        else
             *qb.overflow = 1;
-        }
     }
 }
 
@@ -316,7 +333,7 @@ void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuf
 }
 void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_scan, dim3(g.nl, g.B), dim3(1024), 0, st, g, q, qb.chunk_cnt, qb.counts);
+    hipLaunchKernelGGL(k_qt_scan, dim3(g.nl, g.B), dim3(1024), 0, st, g, q, qb.chunk_cnt, qb.counts, qb.work_count);
 }
 void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
