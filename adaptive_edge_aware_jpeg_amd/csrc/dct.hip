@@ -25,6 +25,21 @@ __device__ __forceinline__ int reflect_pad_idx(int i, int n)
     return j >= n ? p - j : j;
 }
 
+// position of raster element (r, c) in the zigzag sequence of an S x S block (jpeg.py:726-766): anti-diagonal d = r + c,
+// odd diagonals run top -> bottom, even ones bottom -> top
+template <int S>
+__device__ __forceinline__ int zigzag_pos(int r, int c)
+{
+    const int d = r + c;
+    if (d < S) {
+        const int before = d * (d + 1) / 2;
+        return before + ((d & 1) ? r : c);
+    }
+    const int dd = 2 * (S - 1) - d;
+    const int before = S * S - (dd + 1) * (dd + 2) / 2;
+    return before + ((d & 1) ? (S - 1 - c) : (S - 1 - r));
+}
+
 __device__ __forceinline__ int quantise(float y, int q)
 {
     double v = (double)y / (double)q;
@@ -33,7 +48,13 @@ __device__ __forceinline__ int quantise(float y, int q)
 
 // Work items of one block size are the concatenation, over planes (b, l), of that plane's Morton-ordered leaf list.
 // s_pref[p] = number of items in planes < p (built once per workgroup by wave 0); an item index is mapped back to
-// (plane, index in plane) with a binary search.
+// (plane, index in plane) with a binary search.  Per-layer geometry is copied to LDS once so that the per-leaf code
+// never indexes kernel arguments dynamically (that would be a dependent kernarg load per leaf).
+struct LayerTab {
+    int w[3], h[3];
+    long long poff[3], coff[3], woff[3];
+};
+
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
 {
 #pragma unroll
@@ -44,8 +65,13 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
     return v;
 }
 
-__device__ __forceinline__ void build_plane_prefix(const DctArgs &a, int *s_pref)
+__device__ __forceinline__ void dct_prologue(const Geom &g, const QtGeom &q, const DctArgs &a, int *s_pref, LayerTab &lt)
 {
+    if (threadIdx.x < 3) {
+        const int l = threadIdx.x;
+        lt.w[l] = g.w[l]; lt.h[l] = g.h[l];
+        lt.poff[l] = g.poff[l]; lt.coff[l] = q.coeff_off[l]; lt.woff[l] = q.work_off[l][a.k];
+    }
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         int carry = 0;
@@ -61,7 +87,7 @@ __device__ __forceinline__ void build_plane_prefix(const DctArgs &a, int *s_pref
     __syncthreads();
 }
 
-__device__ __forceinline__ int4 fetch_item(const DctArgs &a, const QtGeom &q, const int *s_pref, long long item)
+__device__ __forceinline__ int4 fetch_item(const DctArgs &a, long long work_stride, const LayerTab &lt, const int *s_pref, long long item)
 {
     int lo = 0, hi = a.nplanes;          // largest p with s_pref[p] <= item
     while (hi - lo > 1) {
@@ -69,14 +95,15 @@ __device__ __forceinline__ int4 fetch_item(const DctArgs &a, const QtGeom &q, co
         if ((long long)s_pref[mid] <= item) lo = mid; else hi = mid;
     }
     const int b = lo / 3, l = lo - 3 * b;
-    const long long idx = (long long)b * q.work_stride[a.k] + q.work_off[l][a.k] + (item - s_pref[lo]);
+    const long long idx = (long long)b * work_stride + lt.woff[l] + (item - s_pref[lo]);
     return reinterpret_cast<const int4 *>(a.work)[idx];
 }
 
 // ------------------------------------------------------------------------------------------------
-// small blocks: S in {2, 4, 8, 16}; 256 threads = 256/S leaves, S threads per leaf
+// small blocks: S in {2, 4, 8, 16}; 256 threads = 256/S leaves, S threads per leaf.
+// The descriptor of the next leaf is fetched while the current one is transformed.
 // ------------------------------------------------------------------------------------------------
-template <int S>
+template <int S, bool WANT_DCT>
 __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, long long max_items)
 {
     constexpr int LPB = 256 / S;
@@ -86,30 +113,35 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
     __shared__ float sD[SS];
     __shared__ int sZ[SS];
     __shared__ int sQm[3 * SS];
+    __shared__ LayerTab lt;
     extern __shared__ int s_pref[];
     const int tid = threadIdx.x;
     for (int i = tid; i < SS; i += 256) { sD[i] = a.D[i]; sZ[i] = a.zzinv[i]; }
     for (int i = tid; i < 3 * SS; i += 256) sQm[i] = a.qm[i / SS] ? a.qm[i / SS][i % SS] : 1;
-    build_plane_prefix(a, s_pref);
+    dct_prologue(g, q, a, s_pref, lt);
     long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
+    const long long wstride = q.work_stride[a.k];
     const int slot = tid / S, j = tid % S;
-    for (long long base = (long long)blockIdx.x * LPB; base < count; base += (long long)gridDim.x * LPB) {
-        const long long item = base + slot;
-        const bool active = item < count;
-        int layer = 0;
-        int4 wk = make_int4(0, 0, 0, 0);
+    const long long step = (long long)gridDim.x * LPB;
+    long long base = (long long)blockIdx.x * LPB;
+    int4 wk = make_int4(0, 0, 0, 0);
+    if (base + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + slot);
+    for (; base < count; base += step) {
+        const bool active = base + slot < count;
+        const int4 cur = wk;
+        int layer = 0, b = 0;
         if (active) {
-            wk = fetch_item(a, q, s_pref, item);
-            const int b = wk.x / 3;
-            layer = wk.x - b * 3;
-            const int w = g.w[layer], h = g.h[layer];
-            const float *src = a.norm + (long long)b * g.pstride + g.poff[layer];
-            const int hc = min(S, h - wk.z), wc = min(S, w - wk.y);
-            const int col = wk.y + reflect_pad_idx(j, wc);
+            b = cur.x / 3;
+            layer = cur.x - b * 3;
+            const int w = lt.w[layer], h = lt.h[layer];
+            const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+            const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
+            const int col = cur.y + reflect_pad_idx(j, wc);
             float x[S];
 #pragma unroll
-            for (int k = 0; k < S; k++) x[k] = src[(long long)(wk.z + reflect_pad_idx(k, hc)) * w + col];
+            for (int k = 0; k < S; k++) x[k] = src[(long long)(cur.z + reflect_pad_idx(k, hc)) * w + col];
+            if (base + step + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + step + slot);
             // T[i][j] = sum_k D[i][k] X[k][j]
 #pragma unroll
             for (int i = 0; i < S; i++) {
@@ -122,8 +154,7 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
         __syncthreads();
         long long out_base = 0;
         if (active) {
-            const int b = wk.x / 3;
-            out_base = (long long)b * q.coeff_stride + q.coeff_off[layer] + wk.w;
+            out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
             // Y[i][jj] = sum_k T[i][k] D[jj][k], this thread owns row i = j
             float t[S];
 #pragma unroll
@@ -134,7 +165,7 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
 #pragma unroll
                 for (int k = 0; k < S; k++) acc = __builtin_fmaf(t[k], sD[jj * S + k], acc);
                 const int ridx = j * S + jj;
-                if (a.dct_f32) a.dct_f32[out_base + ridx] = acc;
+                if (WANT_DCT) a.dct_f32[out_base + ridx] = acc;
                 sQ[slot * SS + sZ[ridx]] = quantise(acc, sQm[layer * SS + ridx]);
             }
         }
@@ -148,15 +179,28 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
     }
 }
 
+// LDS-DMA (global_load_lds): per-lane global source, LDS destination = wave-uniform base + lane * size.
+__device__ __forceinline__ void glds16(const float *g, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float *g, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // large blocks: S in {32, 64, 128}; one workgroup of (S/32)^2 waves per leaf, one 32x32 output tile per wave.
 // P = X^T.D^T  (P[r][c] = T[c][r]) with A[i][k] = X[k][I0+i] read from LDS rows, B[k][j] = D[J0+j][k] held
 // in S/2 registers for the whole kernel; P goes to LDS as stored, and Y = T.D^T reads A[i][k] = P[k][I0+i]
 // with the same row pattern and the same B registers.  Both LDS read patterns are 32 consecutive floats per
-// half-wave: conflict-free.
+// half-wave: conflict-free.  The quantisers of the lane's 16 outputs and the next leaf's descriptor are
+// loaded before the MFMA chains so that their latency hides under them.
 // ------------------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__((S / 32) * (S / 32) * 64) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
+template <int S, bool WANT_DCT>
+__global__ __launch_bounds__((S / 32) * (S / 32) * 64, S == 32 ? 4 : S == 64 ? 3 : 1) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
 {
     constexpr int NT = S / 32;
     constexpr int NTHREADS = NT * NT * 64;
@@ -164,7 +208,8 @@ __global__ __launch_bounds__((S / 32) * (S / 32) * 64) void k_dct_mfma(Geom g, Q
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sX = smem;            // [S][S]  X, later reused as int staging for the zigzag scatter
     float *sP = smem + SS;       // [S][S]  P = T^T
-    int *s_pref = reinterpret_cast<int *>(smem + 2 * SS);   // [nplanes + 1]
+    LayerTab &lt = *reinterpret_cast<LayerTab *>(smem + 2 * SS);
+    int *s_pref = reinterpret_cast<int *>(smem + 2 * SS) + (sizeof(LayerTab) + 3) / 4;   // [nplanes + 1]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wi = wave / NT, wj = wave % NT;
@@ -176,22 +221,45 @@ __global__ __launch_bounds__((S / 32) * (S / 32) * 64) void k_dct_mfma(Geom g, Q
 #pragma unroll
     for (int s = 0; s < S / 2; s++) dreg[s] = a.D[(J0 + li) * S + 2 * s + lh];
 
-    build_plane_prefix(a, s_pref);
+    dct_prologue(g, q, a, s_pref, lt);
     long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
-    for (long long item = blockIdx.x; item < count; item += gridDim.x) {
-        const int4 wk = fetch_item(a, q, s_pref, item);
-        const int b = wk.x / 3, layer = wk.x - b * 3;
-        const int w = g.w[layer], h = g.h[layer];
-        const float *src = a.norm + (long long)b * g.pstride + g.poff[layer];
-        const int hc = min(S, h - wk.z), wc = min(S, w - wk.y);
-        const long long out_base = (long long)b * q.coeff_stride + q.coeff_off[layer] + wk.w;
+    const long long wstride = q.work_stride[a.k];
+    long long item = blockIdx.x;
+    int4 wk = make_int4(0, 0, 0, 0);
+    if (item < count) wk = fetch_item(a, wstride, lt, s_pref, item);
+    for (; item < count; item += gridDim.x) {
+        const int4 cur = wk;
+        const int b = cur.x / 3, layer = cur.x - b * 3;
+        const int w = lt.w[layer], h = lt.h[layer];
+        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+        const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
+        const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
         const int *qm = a.qm[layer];
 
-        for (int idx = tid; idx < SS; idx += NTHREADS) {
-            int r = idx / S, c = idx - r * S;
-            sX[idx] = src[(long long)(wk.z + reflect_pad_idx(r, hc)) * w + wk.y + reflect_pad_idx(c, wc)];
+        // X -> LDS by LDS-DMA (no VGPR staging): full leaves 1 KiB (256 floats) per wave instruction, clipped or
+        // unaligned ones one dword per lane with the np.pad(reflect) index map applied to the source address
+        if (hc == S && wc == S && (w & 3) == 0) {
+            constexpr int ROWS = 256 / S;                 // rows per wave instruction
+#pragma unroll
+            for (int t = 0; t < SS / 256 / (NT * NT); t++) {
+                const int chunk = t * NT * NT + wave;
+                const int r = chunk * ROWS + lane / (S / 4), c = (lane % (S / 4)) * 4;
+                glds16(src + (long long)(cur.z + r) * w + cur.y + c, sX + chunk * 256);
+            }
+        } else {
+#pragma unroll 4
+            for (int t = 0; t < SS / 64 / (NT * NT); t++) {
+                const int chunk = t * NT * NT + wave;
+                const int idx = chunk * 64 + lane;
+                const int r = idx / S, c = idx - r * S;
+                glds4(src + (long long)(cur.z + reflect_pad_idx(r, hc)) * w + cur.y + reflect_pad_idx(c, wc), sX + chunk * 64);
+            }
         }
+        int qv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) qv[r] = qm[(I0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * S + J0 + li];
+        if (item + gridDim.x < count) wk = fetch_item(a, wstride, lt, s_pref, item + gridDim.x);
         __syncthreads();
 
         floatx16 acc;
@@ -221,9 +289,8 @@ __global__ __launch_bounds__((S / 32) * (S / 32) * 64) void k_dct_mfma(Geom g, Q
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            int ridx = (I0 + row) * S + J0 + li;
-            if (a.dct_f32) a.dct_f32[out_base + ridx] = acc[r];
-            sQ[a.zzinv[ridx]] = quantise(acc[r], qm[ridx]);
+            if (WANT_DCT) a.dct_f32[out_base + (I0 + row) * S + J0 + li] = acc[r];
+            sQ[zigzag_pos<S>(I0 + row, J0 + li)] = quantise(acc[r], qv[r]);
         }
         __syncthreads();
         for (int idx = tid * 4; idx < SS; idx += NTHREADS * 4)
@@ -257,17 +324,17 @@ void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int
     hipLaunchKernelGGL(k_work_from_leaves, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, leaves, n, ilog2(bmin), plane, wp, work_count);
 }
 
-template <int S>
+template <int S, bool WANT_DCT>
 static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, int blocks)
 {
     constexpr int NT = S / 32;
-    size_t lds = (size_t)2 * S * S * sizeof(float) + (size_t)(a.nplanes + 1) * sizeof(int);
+    size_t lds = (size_t)2 * S * S * sizeof(float) + sizeof(LayerTab) + 8 + (size_t)(a.nplanes + 1) * sizeof(int);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dct_mfma<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dct_mfma<S, WANT_DCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(k_dct_mfma<S>, dim3(blocks), dim3(NT * NT * 64), lds, st, g, q, a, max_items);
+    hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(NT * NT * 64), lds, st, g, q, a, max_items);
 }
 
 void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
@@ -278,16 +345,25 @@ void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const 
         long long b = (max_items + per_block - 1) / per_block;
         return (int)(b < 1 ? 1 : b > hi ? hi : b);
     };
+    const bool wd = a.dct_f32 != nullptr;
+#define AEJ_SMALL(S, PER, HI)                                                                                              \
+    if (wd) hipLaunchKernelGGL((k_dct_small<S, true>), dim3(cap(PER, HI)), dim3(256), pref, st, g, q, a, max_items);       \
+    else hipLaunchKernelGGL((k_dct_small<S, false>), dim3(cap(PER, HI)), dim3(256), pref, st, g, q, a, max_items)
+#define AEJ_MFMA(S, HI)                                                                 \
+    if (wd) launch_mfma_t<S, true>(st, g, q, a, max_items, cap(1, HI));                  \
+    else launch_mfma_t<S, false>(st, g, q, a, max_items, cap(1, HI))
     switch (size) {
-    case 2: hipLaunchKernelGGL(k_dct_small<2>, dim3(cap(128, 2048)), dim3(256), pref, st, g, q, a, max_items); break;
-    case 4: hipLaunchKernelGGL(k_dct_small<4>, dim3(cap(64, 4096)), dim3(256), pref, st, g, q, a, max_items); break;
-    case 8: hipLaunchKernelGGL(k_dct_small<8>, dim3(cap(32, 4096)), dim3(256), pref, st, g, q, a, max_items); break;
-    case 16: hipLaunchKernelGGL(k_dct_small<16>, dim3(cap(16, 4096)), dim3(256), pref, st, g, q, a, max_items); break;
-    case 32: launch_mfma_t<32>(st, g, q, a, max_items, cap(1, 4096)); break;
-    case 64: launch_mfma_t<64>(st, g, q, a, max_items, cap(1, 1024)); break;
-    case 128: launch_mfma_t<128>(st, g, q, a, max_items, cap(1, 256)); break;
+    case 2: AEJ_SMALL(2, 128, 2048); break;
+    case 4: AEJ_SMALL(4, 64, 4096); break;
+    case 8: AEJ_SMALL(8, 32, 4096); break;
+    case 16: AEJ_SMALL(16, 16, 4096); break;
+    case 32: AEJ_MFMA(32, 4096); break;
+    case 64: AEJ_MFMA(64, 768); break;
+    case 128: AEJ_MFMA(128, 256); break;
     default: break;
     }
+#undef AEJ_SMALL
+#undef AEJ_MFMA
 }
 
 }  // namespace aej
