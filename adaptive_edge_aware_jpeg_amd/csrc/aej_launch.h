@@ -41,7 +41,8 @@ void launch_bits_to_map(hipStream_t st, const Geom &g, const unsigned long long 
 
 // quadtree.hip
 struct QtBuffers {
-    unsigned char *pyr;     // [B][pyr_stride]
+    unsigned char *pyr;     // [B][pyr_stride] (only levels >= 5 are used)
+    const unsigned long long *edge_bits;   // [B][bpstride] final edge bit-plane
     int *chunk_cnt;         // [B][chunk_stride][kChunkInts]: counts, then exclusive offsets after the scan
     int *leaves;            // out [B][leaf_stride][4]
     unsigned char *states;  // out [B][state_stride]

@@ -467,6 +467,7 @@ static int run_quadtree(aej_ctx *ctx, const Geom &g, const QtGeom &q, QtWs &w, c
 {
     hipStream_t st = ctx->stream;
     AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));
+    w.qb.edge_bits = edge_bits;
     launch_qt_cells(st, g, q, edge_bits, w.qb);
     launch_qt_count(st, g, q, w.qb);
     launch_qt_scan(st, g, q, w.qb);

@@ -209,7 +209,10 @@ __device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb,
     const int w = g.w[l], h = g.h[l];
     const long long pbase = (long long)b * g.pstride + g.poff[l];
     // ---- stage A: CLAHE interpolation, 4 pixels (one dword) per item
-    for (int idx = tid; idx < kAH * kAW4; idx += 256) {
+#pragma unroll
+    for (int kk = 0; kk < (kAH * kAW4 + 255) / 256; kk++) {
+        const int idx = tid + kk * 256;
+        if (idx >= kAH * kAW4) break;
         int j = idx / kAW4, i4 = idx - j * kAW4;
         unsigned int rv = L.R[idx];
 #if defined(AEJ_ABLATE) && (AEJ_ABLATE == 3 || AEJ_ABLATE == 5)
@@ -233,7 +236,10 @@ __device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb,
                 cb.dump_clahe[pbase + (long long)(y0 + j) * w + x0 + i] = reinterpret_cast<const unsigned char *>(L.A)[(j + 3) * kAW + i + 4];
         }
     // ---- stage B: Gaussian [1 2 1]^2, (sum + 8) >> 4, SWAR on even/odd bytes (16-bit fields hold <= 4088)
-    for (int idx = tid; idx < kBH * kAW4; idx += 256) {
+#pragma unroll
+    for (int kk = 0; kk < (kBH * kAW4 + 255) / 256; kk++) {
+        const int idx = tid + kk * 256;
+        if (idx >= kBH * kAW4) break;
         int j = idx / kAW4, i4 = idx - j * kAW4;
         const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kAW4 - 1 ? i4 + 1 : kAW4 - 1;   // edge dwords feed unused columns only
 #if defined(AEJ_ABLATE) && (AEJ_ABLATE == 4 || AEJ_ABLATE == 5)
@@ -453,15 +459,25 @@ __global__ __launch_bounds__(256) void k_thresholds(Geom g, const int *__restric
 // a-8 part 1: Sobel 3x3 (BORDER_REPLICATE), magnitude dx^2+dy^2, non-maximum suppression.
 // Output: two bit-planes (one 64-bit word per 64 pixels of a row): `weak` = NMS survivors with
 // low < mag <= high (OpenCV map value 0), `strong` = survivors with mag > high (map value 2).
-// A wave owns one 64-pixel row segment per step, so the words are wave ballots.
+// Stage 0 stages the blurred bytes (replicate padding = clamped source coordinates) through registers with all
+// loads in flight; stage 1 computes gradient + magnitude for 4 pixels per item with SWAR [1 2 1] sums;
+// stage 2 does the NMS test with one wave per 64-pixel row segment so that the output words are wave ballots.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSW = kBlurTW + 8;        // u8 LDS stride
-constexpr int kMW = kBlurTW + 2 + 1;    // magnitude LDS stride (ints), +1 to skew banks
+constexpr int kNW4 = (kBlurTW + 8) / 4;      // 18 dwords per staged row: columns c <-> gx = x0 - 4 + c
+constexpr int kNUH = kBlurTH + 4;            // u8 rows  [y0-2, y0+TH+2)
+constexpr int kNMH = kBlurTH + 2;            // mag rows [y0-1, y0+TH+1)
+constexpr int kNMW = kBlurTW + 8 + 1;        // mag row stride (ints), odd to skew banks
+constexpr int kNRaw = (kNUH * kNW4 + 255) / 256;
+
+struct NmsLds {
+    unsigned int U[kNUH * kNW4];
+    int M[kNMH * kNMW];
+    int G[kNMH * kNMW];        // dx (low 16 bits) | dy << 16
+};
 
 __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
 {
-    __shared__ unsigned char sU[(kBlurTH + 4) * kSW];
-    __shared__ int sM[(kBlurTH + 2) * kMW];
+    __shared__ NmsLds L;
     const int tid = threadIdx.x, b = blockIdx.y;
     int l, tx, ty, ntx, nty, tbase;
     if (!locate_tile(g, kBlurTW, kBlurTH, blockIdx.x, l, tx, ty, ntx, nty, tbase)) return;
@@ -470,42 +486,93 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
     const long long pbase = (long long)b * g.pstride + g.poff[l];
     const unsigned char *src = cb.u8b + pbase;
     const int low = cb.thr[((long long)b * 3 + l) * 2], high = cb.thr[((long long)b * 3 + l) * 2 + 1];
+    const bool aligned = x0 >= 4 && y0 >= 2 && x0 + kBlurTW + 4 <= w && y0 + kBlurTH + 2 <= h && (w % 4) == 0;
 
-    for (int idx = tid; idx < (kBlurTH + 4) * (kBlurTW + 4); idx += 256) {
-        int j = idx / (kBlurTW + 4), i = idx - j * (kBlurTW + 4);
-        int gx = x0 - 2 + i, gy = y0 - 2 + j;
-        gx = gx < 0 ? 0 : gx >= w ? w - 1 : gx;
-        gy = gy < 0 ? 0 : gy >= h ? h - 1 : gy;
-        sU[j * kSW + i] = src[(long long)gy * w + gx];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < (kBlurTH + 2) * (kBlurTW + 2); idx += 256) {
-        int j = idx / (kBlurTW + 2), i = idx - j * (kBlurTW + 2);
-        int gx = x0 - 1 + i, gy = y0 - 1 + j;
-        int m = 0;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-            const unsigned char *r0 = sU + j * kSW + i, *r1 = r0 + kSW, *r2 = r1 + kSW;   // centre at (j+1, i+1)
-            int dx = (r0[2] + 2 * r1[2] + r2[2]) - (r0[0] + 2 * r1[0] + r2[0]);
-            int dy = (r2[0] + 2 * r2[1] + r2[2]) - (r0[0] + 2 * r0[1] + r0[2]);
-            m = dx * dx + dy * dy;
+    // ---- stage 0
+    if (aligned) {
+        unsigned int raw[kNRaw];
+#pragma unroll
+        for (int k = 0; k < kNRaw; k++) {
+            int idx = tid + k * 256;
+            if (idx < kNUH * kNW4) {
+                int j = idx / kNW4, i4 = idx - j * kNW4;
+                raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 2 + j) * w + (x0 - 4) + 4 * i4);
+            }
         }
-        sM[j * kMW + i] = m;
+#pragma unroll
+        for (int k = 0; k < kNRaw; k++) {
+            int idx = tid + k * 256;
+            if (idx < kNUH * kNW4) L.U[idx] = raw[k];
+        }
+    } else {
+        unsigned char *U8 = reinterpret_cast<unsigned char *>(L.U);
+        for (int idx = tid; idx < kNUH * kNW4 * 4; idx += 256) {
+            int j = idx / (kNW4 * 4), c = idx - j * (kNW4 * 4);
+            int gx = x0 - 4 + c, gy = y0 - 2 + j;
+            gx = gx < 0 ? 0 : gx >= w ? w - 1 : gx;
+            gy = gy < 0 ? 0 : gy >= h ? h - 1 : gy;
+            U8[idx] = src[(long long)gy * w + gx];
+        }
     }
     __syncthreads();
+
+    // ---- stage 1: 4 pixels per item; rows gy = y0-1+jm, columns gx = x0-4+4*i4 .. +3
+#pragma unroll
+    for (int k = 0; k < (kNMH * kNW4 + 255) / 256; k++) {
+        const int idx = tid + k * 256;
+        if (idx < kNMH * kNW4) {
+            const int jm = idx / kNW4, i4 = idx - jm * kNW4;
+            const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kNW4 - 1 ? i4 + 1 : kNW4 - 1;   // edge dwords feed unused columns only
+            const unsigned int M8 = 0x00FF00FFu;
+            unsigned int he[3], ho[3], vle = 0, vlo = 0, vre = 0, vro = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const unsigned int *row = L.U + (jm + r) * kNW4;
+                unsigned int m = row[i4], lf = row[il], rt = row[ir];
+                unsigned int sl = __builtin_amdgcn_alignbyte(m, lf, 3);    // columns -1, 0, 1, 2
+                unsigned int sr = __builtin_amdgcn_alignbyte(rt, m, 1);    // columns  1, 2, 3, 4
+                he[r] = (sl & M8) + 2u * (m & M8) + (sr & M8);             // horizontal [1 2 1] at columns 0, 2
+                ho[r] = ((sl >> 8) & M8) + 2u * ((m >> 8) & M8) + ((sr >> 8) & M8);   // columns 1, 3
+                const unsigned int wgt = r == 1 ? 2u : 1u;                 // vertical [1 2 1]
+                vle += wgt * (sl & M8);  vlo += wgt * ((sl >> 8) & M8);    // columns (-1, 1), (0, 2)
+                vre += wgt * (sr & M8);  vro += wgt * ((sr >> 8) & M8);    // columns ( 1, 3), (2, 4)
+            }
+            int dx[4], dy[4];
+            dx[0] = (int)(vre & 0xffffu) - (int)(vle & 0xffffu);
+            dx[1] = (int)(vro & 0xffffu) - (int)(vlo & 0xffffu);
+            dx[2] = (int)(vre >> 16) - (int)(vle >> 16);
+            dx[3] = (int)(vro >> 16) - (int)(vlo >> 16);
+            dy[0] = (int)(he[2] & 0xffffu) - (int)(he[0] & 0xffffu);
+            dy[1] = (int)(ho[2] & 0xffffu) - (int)(ho[0] & 0xffffu);
+            dy[2] = (int)(he[2] >> 16) - (int)(he[0] >> 16);
+            dy[3] = (int)(ho[2] >> 16) - (int)(ho[0] >> 16);
+            const int gy = y0 - 1 + jm;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int gx = x0 - 4 + 4 * i4 + p;
+                int m = dx[p] * dx[p] + dy[p] * dy[p];
+                if (!aligned && (gx < 0 || gx >= w || gy < 0 || gy >= h)) m = 0;      // magnitude outside the image is 0
+                L.M[jm * kNMW + 4 * i4 + p] = m;
+                L.G[jm * kNMW + 4 * i4 + p] = (dx[p] & 0xffff) | (dy[p] << 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: NMS, one wave per 64-pixel row segment
     unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
     unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
     const int i = tid & 63;
-#pragma unroll 1
+#pragma unroll 2
     for (int j = tid >> 6; j < kBlurTH; j += 4) {
         const int gx = x0 + i, gy = y0 + j;
         int res = 1;
         if (gx < w && gy < h) {
-            const int *ma = sM + (j + 1) * kMW + (i + 1), *mp = ma - kMW, *mn = ma + kMW;
+            const int *ma = L.M + (j + 1) * kNMW + (i + 4), *mp = ma - kNMW, *mn = ma + kNMW;
             int m = *ma;
             if (m > low) {
-                const unsigned char *r0 = sU + (j + 1) * kSW + (i + 1), *r1 = r0 + kSW, *r2 = r1 + kSW;
-                int xs = (r0[2] + 2 * r1[2] + r2[2]) - (r0[0] + 2 * r1[0] + r2[0]);
-                int ys = (r2[0] + 2 * r2[1] + r2[2]) - (r0[0] + 2 * r0[1] + r0[2]);
+                const int gd = L.G[(j + 1) * kNMW + (i + 4)];
+                int xs = (int)(short)(gd & 0xffff), ys = gd >> 16;
                 int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << 15;
                 int tg22x = ax * 13573;
                 bool keep;

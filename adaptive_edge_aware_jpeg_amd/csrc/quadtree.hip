@@ -35,61 +35,68 @@ __device__ __forceinline__ long long lvl_off(int ncell, int lv)
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1: OR-pyramid.  One block per chunk of 16x16 cells; levels 0..4 reduced in LDS, higher levels
-// (only those that can still matter, cell<<lv <= bmax) are set with idempotent stores of 1.
+// OR-pyramid and node evaluation, one WAVE per chunk.
+// A chunk is a Morton-aligned square of 16x16 min-size cells (256 cells); lane t owns the four sibling cells
+// 4t..4t+3 (= one level-1 node), so levels 0..1 of the pyramid are lane-local and levels 2..4 are nibble / 16-bit /
+// whole-word tests on one wave ballot.  Levels >= 5 (only needed when bmax/bmin >= 32) are a tiny global array
+// filled by k_qt_upper with idempotent stores of 1.  No LDS, no workgroup barriers.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_qt_cells(Geom g, QtGeom q, const unsigned long long *__restrict__ edge_bits,
-                                                  unsigned char *__restrict__ pyr_all)
+struct ChunkEdges {
+    unsigned e0;             // bit i = OR over cell 4*lane + i
+    bool e1, e2, e3, e4;     // OR over the lane's level-1 / 2 / 3 / 4 ancestors
+};
+
+__device__ __forceinline__ ChunkEdges chunk_edges(const Geom &g, const QtGeom &q, int l, int b, const unsigned long long *__restrict__ edge_bits,
+                                                  unsigned chunk, int lane)
 {
-    __shared__ unsigned char lv[5][256];
-    const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
-    const int ncell = q.ncell[l], ltot = q.ltot[l], cell = q.cell;
-    const long long ncell2 = (long long)ncell * ncell;
-    if ((long long)blockIdx.x * 256 >= ncell2) return;
-    const int w = g.w[l], h = g.h[l];
-    int ccx, ccy;
-    morton_decode(blockIdx.x, ccx, ccy);
-    ccx *= 16; ccy *= 16;
-    if (ccx * cell >= w || ccy * cell >= h) return;   // chunk origin out of bounds => whole chunk is
-    int lx, ly;
-    morton_decode(tid, lx, ly);
-    const int cx = ccx + lx, cy = ccy + ly;
+    const int ncell = q.ncell[l], cell = q.cell;
+    const int w = g.w[l], h = g.h[l], wpr = g.wpr[l];
+    int ccx, ccy, lx, ly;
+    morton_decode(chunk, ccx, ccy);
+    morton_decode((unsigned)lane, lx, ly);
     const unsigned long long *src = edge_bits + (long long)b * g.bpstride + g.bpoff[l];
-    const int wpr = g.wpr[l];
-    unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
-    const bool valid = (long long)tid < ncell2;
-    unsigned char e = 0;
-    if (valid) {
-        int x0 = cx * cell, y0 = cy * cell;
-        int x1 = min(x0 + cell, w), y1 = min(y0 + cell, h);
-        for (int y = y0; y < y1; y++)
-            for (int xw = x0 >> 6; xw <= (x1 - 1) >> 6; xw++) {
-                int lo = max(x0, xw * 64) - xw * 64, hi = min(x1, xw * 64 + 64) - xw * 64;
-                unsigned long long mask = (hi - lo == 64) ? ~0ull : (((1ull << (hi - lo)) - 1ull) << lo);
-                e |= (src[(long long)y * wpr + xw] & mask) ? 1 : 0;
-            }
-        pyr[(long long)cy * ncell + cx] = e;
-    }
-    lv[0][tid] = e;
-    __syncthreads();
-    const int lmax_in = ltot < 4 ? ltot : 4;
-    for (int k = 1; k <= lmax_in; k++) {
-        int n = 256 >> (2 * k);
-        if (tid < n) {
-            unsigned char v = lv[k - 1][4 * tid] | lv[k - 1][4 * tid + 1] | lv[k - 1][4 * tid + 2] | lv[k - 1][4 * tid + 3];
-            lv[k][tid] = v;
-            int mx, my;
-            morton_decode(tid, mx, my);
-            int side = ncell >> k;
-            int px = (ccx >> k) + mx, py = (ccy >> k) + my;
-            if (px < side && py < side) pyr[lvl_off(ncell, k) + (long long)py * side + px] = v;
+    ChunkEdges E;
+    E.e0 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int cx = ccx * 16 + lx * 2 + (i & 1), cy = ccy * 16 + ly * 2 + (i >> 1);
+        if (cx < ncell && cy < ncell && cx * cell < w && cy * cell < h) {
+            int x0 = cx * cell, y0 = cy * cell;
+            int x1 = min(x0 + cell, w), y1 = min(y0 + cell, h);
+            bool e = false;
+            for (int y = y0; y < y1; y++)
+                for (int xw = x0 >> 6; xw <= (x1 - 1) >> 6; xw++) {
+                    int lo = max(x0, xw * 64) - xw * 64, hi = min(x1, xw * 64 + 64) - xw * 64;
+                    unsigned long long mask = (hi - lo == 64) ? ~0ull : (((1ull << (hi - lo)) - 1ull) << lo);
+                    e |= (src[(long long)y * wpr + xw] & mask) != 0;
+                }
+            E.e0 |= (e ? 1u : 0u) << i;
         }
-        __syncthreads();
     }
-    if (tid == 0 && ltot > 4 && lv[4][0]) {
+    E.e1 = E.e0 != 0;
+    const unsigned long long m = __ballot(E.e1);
+    E.e2 = ((m >> (lane & ~3)) & 0xFull) != 0;
+    E.e3 = ((m >> (lane & ~15)) & 0xFFFFull) != 0;
+    E.e4 = m != 0;
+    return E;
+}
+
+__global__ __launch_bounds__(256) void k_qt_upper(Geom g, QtGeom q, const unsigned long long *__restrict__ edge_bits, unsigned char *__restrict__ pyr_all)
+{
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const unsigned chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ncell = q.ncell[l], ltot = q.ltot[l], cell = q.cell;
+    if ((long long)chunk >= q.nchunk[l] || ltot <= 4) return;
+    int ccx, ccy;
+    morton_decode(chunk, ccx, ccy);
+    if (ccx * 16 * cell >= g.w[l] || ccy * 16 * cell >= g.h[l]) return;
+    ChunkEdges E = chunk_edges(g, q, l, b, edge_bits, chunk, lane);
+    if (lane == 0 && E.e4) {
+        unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
         for (int k = 5; k <= ltot && (cell << k) <= q.bmax; k++) {
             int side = ncell >> k;
-            pyr[lvl_off(ncell, k) + (long long)(ccy >> k) * side + (ccx >> k)] = 1;
+            pyr[lvl_off(ncell, k) + (long long)((ccy * 16) >> k) * side + ((ccx * 16) >> k)] = 1;
         }
     }
 }
@@ -103,14 +110,30 @@ struct CellNodes {
     int leaf_lvl;    // level of the leaf originating here, or -1
 };
 
-__device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, int h, const unsigned char *__restrict__ pyr, unsigned gidx)
+// edge(level lvn ancestor of cell gidx = 256*chunk + 4*lane + i)
+__device__ __forceinline__ bool node_edge(const QtGeom &q, int l, const ChunkEdges &E, const unsigned char *__restrict__ pyr, int i, int cx, int cy, int lvn)
+{
+    switch (lvn) {
+    case 0: return (E.e0 >> i) & 1u;
+    case 1: return E.e1;
+    case 2: return E.e2;
+    case 3: return E.e3;
+    case 4: return E.e4;
+    default: {
+        const int ncell = q.ncell[l], side = ncell >> lvn;
+        return pyr[lvl_off(ncell, lvn) + (long long)(cy >> lvn) * side + (cx >> lvn)] != 0;
+    }
+    }
+}
+
+__device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, int h, const ChunkEdges &E, const unsigned char *__restrict__ pyr, unsigned gidx)
 {
     CellNodes r;
     r.nsym = 0; r.syms = 0; r.leaf_lvl = -1;
-    const int ncell = q.ncell[l], ltot = q.ltot[l], cell = q.cell;
+    const int ltot = q.ltot[l], cell = q.cell, i = (int)(gidx & 3u);
     int cx, cy;
     morton_decode(gidx, cx, cy);
-    int a = gidx == 0 ? ltot : min((int)(__ffs(gidx) - 1) >> 1, ltot);
+    int a = gidx == 0 ? ltot : min((int)(__ffs((int)gidx) - 1) >> 1, ltot);
     if (a < ltot) {
         // the level-a node exists only if its parent is in bounds and splits
         int mask = ~((2 << a) - 1);
@@ -118,10 +141,7 @@ __device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, in
         if (pcx * cell >= w || pcy * cell >= h) return r;
         int psize = cell << (a + 1);
         bool psplit = psize > q.bmax;
-        if (!psplit && psize > q.bmin) {
-            int side = ncell >> (a + 1);
-            psplit = pyr[lvl_off(ncell, a + 1) + (long long)(cy >> (a + 1)) * side + (cx >> (a + 1))] != 0;
-        }
+        if (!psplit && psize > q.bmin) psplit = node_edge(q, l, E, pyr, i, cx, cy, a + 1);
         if (!psplit) return r;
     }
     if (cx * cell >= w || cy * cell >= h) {   // quadtree.py:109-110, 153-155: absent child
@@ -131,10 +151,7 @@ __device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, in
     for (int lvn = a; lvn >= 0; lvn--) {
         int size = cell << lvn;
         bool split = size > q.bmax;
-        if (!split && size > q.bmin) {
-            int side = ncell >> lvn;
-            split = pyr[lvl_off(ncell, lvn) + (long long)(cy >> lvn) * side + (cx >> lvn)] != 0;
-        }
+        if (!split && size > q.bmin) split = node_edge(q, l, E, pyr, i, cx, cy, lvn);
         if (split) {
             r.syms |= 1u << (2 * r.nsym);
             r.nsym++;
@@ -157,50 +174,51 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
-// exclusive scan of three per-thread values over a 256-thread block: wave shuffles + one barrier
-__device__ __forceinline__ void block_excl_scan3(int v0, int v1, int v2, int (*s_w)[4], int tid, int &e0, int &e1, int &e2)
+__device__ __forceinline__ int wave_sum(int v)
 {
-    const int lane = tid & 63, wv = tid >> 6;
-    int i0 = wave_incl_scan(v0, lane), i1 = wave_incl_scan(v1, lane), i2 = wave_incl_scan(v2, lane);
-    if (lane == 63) { s_w[0][wv] = i0; s_w[1][wv] = i1; s_w[2][wv] = i2; }
-    __syncthreads();
-    int p0 = 0, p1 = 0, p2 = 0;
-    for (int k = 0; k < wv; k++) { p0 += s_w[0][k]; p1 += s_w[1][k]; p2 += s_w[2][k]; }
-    e0 = p0 + i0 - v0; e1 = p1 + i1 - v1; e2 = p2 + i2 - v2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
-// pass 2: per-chunk totals (symbols, leaves, coefficients, leaves per block size)
-__global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsigned char *__restrict__ pyr_all, int *__restrict__ chunk_cnt)
+// pass 2: per-chunk totals (symbols, leaves, coefficients, leaves per block size); one wave per chunk
+__global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsigned long long *__restrict__ edge_bits,
+                                                  const unsigned char *__restrict__ pyr_all, int *__restrict__ chunk_cnt)
 {
-    __shared__ int s_red[3 + kMaxSizes][4];
-    const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const unsigned chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((long long)chunk >= q.nchunk[l]) return;
     const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
-    if ((long long)blockIdx.x >= q.nchunk[l]) return;
-    const unsigned gidx = blockIdx.x * 256u + tid;
     const unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
-    int nsym = 0, nleaf = 0, ncoef = 0, lvl = -1;
-    if ((long long)gidx < ncell2) {
-        CellNodes c = eval_cell(q, l, g.w[l], g.h[l], pyr, gidx);
-        nsym = c.nsym;
-        lvl = c.leaf_lvl;
-        if (lvl >= 0) { nleaf = 1; int s = q.cell << lvl; ncoef = s * s; }
+    const ChunkEdges E = chunk_edges(g, q, l, b, edge_bits, chunk, lane);
+    int nsym = 0, nleaf = 0, ncoef = 0;
+    int nsz[kMaxSizes];
+#pragma unroll
+    for (int k = 0; k < kMaxSizes; k++) nsz[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned gidx = chunk * 256u + lane * 4u + i;
+        if ((long long)gidx < ncell2) {
+            CellNodes c = eval_cell(q, l, g.w[l], g.h[l], E, pyr, gidx);
+            nsym += c.nsym;
+            if (c.leaf_lvl >= 0) {
+                nleaf++;
+                int s = q.cell << c.leaf_lvl;
+                ncoef += s * s;
+#pragma unroll
+                for (int k = 0; k < kMaxSizes; k++) nsz[k] += (c.leaf_lvl == k) ? 1 : 0;
+            }
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        nsym += __shfl_down(nsym, o);
-        nleaf += __shfl_down(nleaf, o);
-        ncoef += __shfl_down(ncoef, o);
-    }
-    const int wv = tid >> 6;
-    if ((tid & 63) == 0) { s_red[0][wv] = nsym; s_red[1][wv] = nleaf; s_red[2][wv] = ncoef; }
-    for (int k = 0; k < q.nsizes; k++) {
-        unsigned long long m = __ballot(lvl == k);
-        if ((tid & 63) == 0) s_red[3 + k][wv] = __popcll(m);
-    }
-    __syncthreads();
-    if (tid < 3 + kMaxSizes) {
-        int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * kChunkInts;
-        int v = (tid < 3 || tid - 3 < q.nsizes) ? s_red[tid][0] + s_red[tid][1] + s_red[tid][2] + s_red[tid][3] : 0;
-        o[tid < 3 ? tid : tid + 1] = v;
+    nsym = wave_sum(nsym); nleaf = wave_sum(nleaf); ncoef = wave_sum(ncoef);
+#pragma unroll
+    for (int k = 0; k < kMaxSizes; k++) nsz[k] = k < q.nsizes ? wave_sum(nsz[k]) : 0;
+    if (lane == 0) {
+        int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
+        o[0] = nsym; o[1] = nleaf; o[2] = ncoef; o[3] = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxSizes; k++) o[4 + k] = nsz[k];
     }
 }
 
@@ -252,64 +270,73 @@ __global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restr
     if (work_count && tid < kMaxSizes) work_count[((long long)b * 3 + l) * kMaxSizes + tid] = tid < q.nsizes ? carry[3 + tid] : 0;
 }
 
-// pass 4: emit symbols, leaf table and the per-size DCT work lists (positions come from the scans: deterministic,
-// Morton-ordered lists, no global atomics)
+// pass 4: emit symbols, leaf table and the per-size DCT work lists; one wave per chunk.  Positions come from the
+// scans (deterministic, Morton-ordered lists, no global atomics).
 __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
 {
-    __shared__ int s_w[3][4];
-    __shared__ int s_wc[4][kMaxSizes];
-    const int tid = threadIdx.x, l = blockIdx.y, b = blockIdx.z;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const unsigned chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((long long)chunk >= q.nchunk[l]) return;
     const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
-    if ((long long)blockIdx.x >= q.nchunk[l]) return;
-    const unsigned gidx = blockIdx.x * 256u + tid;
     const unsigned char *pyr = qb.pyr + (long long)b * q.pyr_stride + q.pyr_off[l];
-    const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + blockIdx.x) * kChunkInts;
-    const int sym_base = coff[0], leaf_base = coff[1], coef_base = coff[2];
+    const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
+    const ChunkEdges E = chunk_edges(g, q, l, b, qb.edge_bits, chunk, lane);
 
-    CellNodes c;
-    c.nsym = 0; c.syms = 0; c.leaf_lvl = -1;
-    if ((long long)gidx < ncell2) c = eval_cell(q, l, g.w[l], g.h[l], pyr, gidx);
-    const int size = c.leaf_lvl >= 0 ? (q.cell << c.leaf_lvl) : 0;
-    int e0, e1, e2;
-    block_excl_scan3(c.nsym, c.leaf_lvl >= 0 ? 1 : 0, size * size, s_w, tid, e0, e1, e2);
-    const int sym_pos = sym_base + e0, leaf_pos = leaf_base + e1, coef_pos = coef_base + e2;
+    CellNodes c[4];
+    int nsym = 0, nleaf = 0, ncoef = 0, n0 = 0;   // n0: level-0 leaves of this lane (a lane has at most one larger leaf, at cell 0)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned gidx = chunk * 256u + lane * 4u + i;
+        c[i].nsym = 0; c[i].syms = 0; c[i].leaf_lvl = -1;
+        if ((long long)gidx < ncell2) c[i] = eval_cell(q, l, g.w[l], g.h[l], E, pyr, gidx);
+        nsym += c[i].nsym;
+        if (c[i].leaf_lvl >= 0) { nleaf++; int s = q.cell << c[i].leaf_lvl; ncoef += s * s; }
+        if (c[i].leaf_lvl == 0) n0++;
+    }
+    int sym_pos = coff[0] + wave_incl_scan(nsym, lane) - nsym;
+    int leaf_pos = coff[1] + wave_incl_scan(nleaf, lane) - nleaf;
+    int coef_pos = coff[2] + wave_incl_scan(ncoef, lane) - ncoef;
+    int rank0 = wave_incl_scan(n0, lane) - n0;
+    const int big = c[0].leaf_lvl;                     // > 0 when this lane holds a leaf larger than a cell
+    int rank_big = 0;
+    for (int k = 1; k < q.nsizes; k++) {
+        unsigned long long m = __ballot(big == k);
+        if (big == k) rank_big = __popcll(m & ((1ull << lane) - 1ull));
+    }
 
     unsigned char *st = qb.states + (long long)b * q.state_stride + q.state_off[l];
-    for (int k = 0; k < c.nsym; k++) {
-        if (sym_pos + k < q.state_cap[l]) st[sym_pos + k] = (unsigned char)((c.syms >> (2 * k)) & 3u);
-        else *qb.overflow = 1;
-    }
-    int cx = 0, cy = 0;
-    bool leaf_ok = false;
-    if (c.leaf_lvl >= 0) {
-        morton_decode(gidx, cx, cy);
-        if (leaf_pos < q.leaf_cap[l] && (long long)coef_pos + (long long)size * size <= q.coeff_cap[l]) {
-            int *lf = qb.leaves + ((long long)b * q.leaf_stride + q.leaf_off[l] + leaf_pos) * 4;
-            reinterpret_cast<int4 *>(lf)[0] = make_int4(cx * q.cell, cy * q.cell, size, coef_pos);
-            leaf_ok = true;
-        } else {
-            *qb.overflow = 1;
+    int *leaves = qb.leaves + ((long long)b * q.leaf_stride + q.leaf_off[l]) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        for (int k = 0; k < c[i].nsym; k++) {
+            if (sym_pos + k < q.state_cap[l]) st[sym_pos + k] = (unsigned char)((c[i].syms >> (2 * k)) & 3u);
+            else *qb.overflow = 1;
         }
-    }
-    if (!qb.work_count) return;
-    // rank of this leaf among the leaves of its size inside the chunk
-    int rank = 0;
-    for (int k = 0; k < q.nsizes; k++) {
-        unsigned long long m = __ballot(c.leaf_lvl == k);
-        if (c.leaf_lvl == k) rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wc[wv][k] = __popcll(m);
-    }
-    __syncthreads();
-    if (leaf_ok) {
-        const int k = c.leaf_lvl;      // size == bmin << k (the codec path always has cell == bmin)
-        for (int w2 = 0; w2 < wv; w2++) rank += s_wc[w2][k];
-        long long pos = (long long)coff[4 + k] + rank;
-        long long seg = (long long)b * q.work_stride[k] + q.work_off[l][k];
-        if (seg + pos < qb.work_cap[k])
-            reinterpret_cast<int4 *>(qb.work[k])[seg + pos] = make_int4(b * 3 + l, cx * q.cell, cy * q.cell, coef_pos);
-        else
-            *qb.overflow = 1;
+        sym_pos += c[i].nsym;
+        if (c[i].leaf_lvl >= 0) {
+            const unsigned gidx = chunk * 256u + lane * 4u + i;
+            int cx, cy;
+            morton_decode(gidx, cx, cy);
+            const int size = q.cell << c[i].leaf_lvl;
+            if (leaf_pos < q.leaf_cap[l] && (long long)coef_pos + (long long)size * size <= q.coeff_cap[l]) {
+                reinterpret_cast<int4 *>(leaves)[leaf_pos] = make_int4(cx * q.cell, cy * q.cell, size, coef_pos);
+                if (qb.work_count) {
+                    const int k = c[i].leaf_lvl;       // size == bmin << k (the codec path always has cell == bmin)
+                    long long pos = (long long)coff[4 + k] + (k == 0 ? rank0 : rank_big);
+                    long long seg = (long long)b * q.work_stride[k] + q.work_off[l][k];
+                    if (seg + pos < qb.work_cap[k])
+                        reinterpret_cast<int4 *>(qb.work[k])[seg + pos] = make_int4(b * 3 + l, cx * q.cell, cy * q.cell, coef_pos);
+                    else
+                        *qb.overflow = 1;
+                    if (k == 0) rank0++;
+                }
+            } else {
+                *qb.overflow = 1;
+            }
+            leaf_pos++;
+            coef_pos += size * size;
+        }
     }
 }
 
@@ -325,11 +352,14 @@ static int max_chunks(const Geom &g, const QtGeom &q)
 
 void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned long long *edge_bits, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_cells, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, edge_bits, qb.pyr);
+    // only the levels above a chunk (>= 5) live in global memory, and only when a node of that size can still be a leaf
+    bool need = false;
+    for (int l = 0; l < g.nl; l++) if (q.ltot[l] > 4 && (q.cell << 5) <= q.bmax) need = true;
+    if (need) hipLaunchKernelGGL(k_qt_upper, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, edge_bits, qb.pyr);
 }
 void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_count, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, qb.pyr, qb.chunk_cnt);
+    hipLaunchKernelGGL(k_qt_count, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, qb.edge_bits, qb.pyr, qb.chunk_cnt);
 }
 void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
@@ -337,7 +367,7 @@ void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuff
 }
 void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_emit, dim3(max_chunks(g, q), g.nl, g.B), dim3(256), 0, st, g, q, qb);
+    hipLaunchKernelGGL(k_qt_emit, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, qb);
 }
 
 }  // namespace aej
