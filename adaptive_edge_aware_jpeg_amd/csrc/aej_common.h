@@ -22,7 +22,8 @@ struct Geom {
     long long pstride;   // plane elements per image = sum h*w
     // CLAHE tile geometry per layer (clahe.cpp): padded size / 4
     int ctw[3], cth[3];
-    // edge bit-planes (weak / strong): one 64-bit word per 64 pixels of a row
+    // edge bit-planes (weak / strong): one 64-bit word per 64 pixels of a row, stored TILE-MAJOR: the 64 row-words of a
+    // 64x64-pixel tile are contiguous (512 B), see bp_index(); rows are padded to a multiple of 64
     int wpr[3];               // words per row = ceil(w / 64)
     long long bpoff[3];       // word offset of layer l inside one image's bit-plane storage
     long long bpstride;       // words per image
@@ -66,6 +67,9 @@ struct DctTables {
     const int *zzinv[kMaxSizes];      // [s*s] zigzag position of raster index
     const int *qm[3][kMaxSizes];      // [s*s] quantisation matrix per layer
 };
+
+__host__ __device__ inline long long bp_index(int y, int xw, int wpr) { return ((long long)(y >> 6) * wpr + xw) * 64 + (y & 63); }
+__host__ __device__ inline long long bp_words(int h, int wpr) { return (long long)((h + 63) / 64) * wpr * 64; }
 
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 

@@ -113,7 +113,7 @@ static void fill_clahe_geom(Geom &g)
     for (int l = 0; l < g.nl; l++) {
         g.wpr[l] = (g.w[l] + 63) / 64;
         g.bpoff[l] = bp;
-        bp += align_up((long long)g.wpr[l] * g.h[l], 32);
+        bp += bp_words(g.h[l], g.wpr[l]);
     }
     g.bpstride = bp;
     for (int l = 0; l < g.nl; l++) {

@@ -21,6 +21,14 @@ __device__ __forceinline__ int reflect101(int i, int n)
 
 __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an L2).  Stencil tiles re-read their neighbours'
+// halo lines, so give each XCD a contiguous range of tiles: bijective remap of a 1-D grid of n workgroups (speed only).
+__device__ __forceinline__ long long xcd_remap(long long id, long long n)
+{
+    const long long q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // tile index t (over all layers of one image) -> layer, tile coordinates
 __device__ __forceinline__ bool locate_tile(const Geom &g, int TW, int TH, int t, int &layer, int &tx, int &ty, int &ntx, int &nty, int &tbase)
 {
@@ -128,8 +136,7 @@ struct __attribute__((aligned(16))) BlurLds {
     unsigned int R[kAH * kAW4];      // raw uint8 source
     unsigned int A[kAH * kAW4];      // CLAHE image
     unsigned int Bm[kBH * kAW4];     // Gaussian image
-    float cw[256];
-    float sw[16];
+    float cw[3][256];                // space weight (radius 1, sqrt 2, 2) x colour weight: the product OpenCV forms per tap
     unsigned int hist16[16 * 128];   // 16 lane-striped copies of 256 packed 16-bit counters
     int colOff1[kAW], colOff2[kAW];
     float colXa[kAW], colXa1[kAW];
@@ -158,22 +165,23 @@ __device__ __forceinline__ unsigned char clahe_px(const BlurLds &L, int v, int r
     return (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
 }
 
-// 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2).  The space weight of
-// tap k is one of 4 values by its radius; the centre tap has |delta| = 0 and cw[0] = sw[6] = 1, so its weight is 1.
+// 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2).  The weight of tap k is
+// space_w[k] * color_w[|delta|]; space_w takes 3 values (radius 1, sqrt 2, 2), so the float32 products are tabulated once
+// per workgroup (same multiplication, same rounding).  The centre tap has |delta| = 0 and both factors 1.
 __device__ __forceinline__ unsigned char bilateral_px(const BlurLds &L, const int (&v)[13])
 {
     const int v0 = v[6];
-    const float s1 = L.sw[5], s2 = L.sw[1], s4 = L.sw[0];     // radius 1, sqrt(2), 2
     float sum = 0.f, wsum = 0.f;
 #pragma unroll
     for (int k = 0; k < 13; k++) {
         float wgt;
         if (k == 6) {
-            wgt = 1.0f;                                         // sw[6] * cw[0] == 1.0f * 1.0f
+            wgt = 1.0f;
         } else {
-            const float sk = (k == 0 || k == 4 || k == 8 || k == 12) ? s4 : (k == 1 || k == 3 || k == 9 || k == 11) ? s2 : s1;
-            int d = (int)__sad(v[k], v0, 0u);
-            wgt = sk * L.cw[d];
+            const int t = (k == 0 || k == 4 || k == 8 || k == 12) ? 2 : (k == 1 || k == 3 || k == 9 || k == 11) ? 1 : 0;
+            int d = v[k] - v0;
+            d = d < 0 ? -d : d;
+            wgt = L.cw[t][d];
         }
         wsum = wsum + wgt;
         sum = __builtin_fmaf((float)v[k], wgt, sum);
@@ -328,9 +336,12 @@ __device__ __forceinline__ bool locate_strip(const Geom &g, int t, int &layer, i
 __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
 {
     __shared__ BlurLds L;
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const long long wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int strips = gridDim.x / g.B;
+    const int b = (int)(wg / strips);
     int l, sx, ty;
-    if (!locate_strip(g, blockIdx.x, l, sx, ty)) return;
+    if (!locate_strip(g, (int)(wg - (long long)b * strips), l, sx, ty)) return;
     const int w = g.w[l], h = g.h[l];
     const int ntx = cdiv(w, kBlurTW);
     const int y0 = ty * kBlurTH;
@@ -338,8 +349,12 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
     const unsigned char *src = cb.u8a + (long long)b * g.pstride + g.poff[l];
 
     reinterpret_cast<uint4 *>(L.lut)[tid] = reinterpret_cast<const uint4 *>(cb.lut + ((long long)b * 3 + l) * 4096)[tid];
-    L.cw[tid] = cb.color_w[tid];
-    if (tid < 13) L.sw[tid] = cb.space_w[tid];
+    {
+        const float cwv = cb.color_w[tid];
+        L.cw[0][tid] = cb.space_w[5] * cwv;     // radius 1
+        L.cw[1][tid] = cb.space_w[1] * cwv;     // radius sqrt(2)
+        L.cw[2][tid] = cb.space_w[0] * cwv;     // radius 2
+    }
     for (int i = tid; i < 16 * 128; i += 256) L.hist16[i] = 0;
     if (tid >= 128 && tid < 128 + kAH) {      // row parameters of CLAHE_Interpolation_Body: fixed for the strip
         const int j = tid - 128;
@@ -478,9 +493,12 @@ struct NmsLds {
 __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
 {
     __shared__ NmsLds L;
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const long long wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = gridDim.x / g.B;
+    const int b = (int)(wg / tiles);
     int l, tx, ty, ntx, nty, tbase;
-    if (!locate_tile(g, kBlurTW, kBlurTH, blockIdx.x, l, tx, ty, ntx, nty, tbase)) return;
+    if (!locate_tile(g, kBlurTW, kBlurTH, (int)(wg - (long long)b * tiles), l, tx, ty, ntx, nty, tbase)) return;
     const int w = g.w[l], h = g.h[l];
     const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
     const long long pbase = (long long)b * g.pstride + g.poff[l];
@@ -590,8 +608,8 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
         }
         unsigned long long wmask = __ballot(res == 0), smask = __ballot(res == 2);
         if (i == 0 && gy < h) {
-            wk[(long long)gy * g.wpr[l] + tx] = wmask;
-            sg[(long long)gy * g.wpr[l] + tx] = smask;
+            wk[bp_index(gy, tx, g.wpr[l])] = wmask;
+            sg[bp_index(gy, tx, g.wpr[l])] = smask;
         }
     }
 }
@@ -638,26 +656,27 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
         const unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
         const int y = ty * 64 + lane;
         const bool valid = y < h;
+        // tile-major layout: this tile's 64 row-words are contiguous; the left / right tiles are +-64 words away
+        const long long o = bp_index(ty * 64, tx, wpr) + lane;
         unsigned long long S = 0, W = 0, SL = 0, SR = 0;
         if (valid) {
-            const long long o = (long long)y * wpr + tx;
             S = sg[o]; W = wk[o];
-            if (tx > 0) SL = sg[o - 1] >> 63;
-            if (tx + 1 < wpr) SR = sg[o + 1] & 1ull;
+            if (tx > 0) SL = sg[o - 64] >> 63;
+            if (tx + 1 < wpr) SR = sg[o + 64] & 1ull;
         }
         // halo rows above / below the tile (wave-uniform addresses)
         unsigned long long Tm = 0, Tl = 0, Tr = 0, Bm = 0, Bl = 0, Br = 0;
         if (ty > 0) {
-            const long long o = (long long)(ty * 64 - 1) * wpr + tx;
-            Tm = sg[o];
-            if (tx > 0) Tl = sg[o - 1] >> 63;
-            if (tx + 1 < wpr) Tr = sg[o + 1] & 1ull;
+            const long long ot = bp_index(ty * 64 - 1, tx, wpr);
+            Tm = sg[ot];
+            if (tx > 0) Tl = sg[ot - 64] >> 63;
+            if (tx + 1 < wpr) Tr = sg[ot + 64] & 1ull;
         }
         if (ty * 64 + 64 < h) {
-            const long long o = (long long)(ty * 64 + 64) * wpr + tx;
-            Bm = sg[o];
-            if (tx > 0) Bl = sg[o - 1] >> 63;
-            if (tx + 1 < wpr) Br = sg[o + 1] & 1ull;
+            const long long ob = bp_index(ty * 64 + 64, tx, wpr);
+            Bm = sg[ob];
+            if (tx > 0) Bl = sg[ob - 64] >> 63;
+            if (tx + 1 < wpr) Br = sg[ob + 64] & 1ull;
         }
         const unsigned long long S0 = S;
         for (;;) {
@@ -676,7 +695,7 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
             if (!__any(ch)) break;
         }
         const unsigned long long diff = S ^ S0;
-        if (diff && valid) sg[(long long)y * wpr + tx] = S;
+        if (diff && valid) sg[o] = S;
         // border ring of the tile: first/last valid row, first/last column
         const int last_row = min(63, h - 1 - ty * 64);
         const bool border = diff && ((diff & 0x8000000000000001ull) || lane == 0 || lane == last_row);
@@ -701,7 +720,7 @@ __global__ __launch_bounds__(256) void k_bits_to_edge(Geom g, const unsigned lon
     const long long n = (long long)w * h;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         int y = (int)(i / w), x = (int)(i - (long long)y * w);
-        out[i] = (unsigned char)((sg[(long long)y * wpr + (x >> 6)] >> (x & 63)) & 1ull);
+        out[i] = (unsigned char)((sg[bp_index(y, x >> 6, wpr)] >> (x & 63)) & 1ull);
     }
 }
 
@@ -716,7 +735,7 @@ __global__ __launch_bounds__(256) void k_bits_to_map(Geom g, const unsigned long
     const long long n = (long long)w * h;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         int y = (int)(i / w), x = (int)(i - (long long)y * w);
-        long long o = (long long)y * wpr + (x >> 6);
+        long long o = bp_index(y, x >> 6, wpr);
         int s = (int)((sg[o] >> (x & 63)) & 1ull), k = (int)((wk[o] >> (x & 63)) & 1ull);
         out[i] = (unsigned char)(s ? 2 : k ? 0 : 1);
     }
@@ -736,7 +755,7 @@ __global__ __launch_bounds__(256) void k_pack_edge_bits(Geom g, const unsigned c
         int x = xw * 64 + lane;
         bool e = x < w && src[(long long)y * w + x] != 0;
         unsigned long long m = __ballot(e);
-        if (lane == 0) out[wd] = m;
+        if (lane == 0) out[bp_index(y, xw, wpr)] = m;
     }
 }
 
@@ -772,7 +791,7 @@ void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
         int ntx = (g.w[l] + kBlurTW - 1) / kBlurTW, nty = (g.h[l] + kBlurTH - 1) / kBlurTH;
         t += (long long)((ntx + kStrip - 1) / kStrip) * nty;
     }
-    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)t, g.B), dim3(256), 0, st, g, cb);
+    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(t * g.B)), dim3(256), 0, st, g, cb);
 }
 
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
@@ -783,7 +802,7 @@ void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
     long long t = tiles_per_image(g, kBlurTW, kBlurTH);
-    hipLaunchKernelGGL(k_sobel_nms, dim3((unsigned)t, g.B), dim3(256), 0, st, g, cb);
+    hipLaunchKernelGGL(k_sobel_nms, dim3((unsigned)(t * g.B)), dim3(256), 0, st, g, cb);
 }
 
 void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass)

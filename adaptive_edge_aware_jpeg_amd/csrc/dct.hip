@@ -199,11 +199,20 @@ __device__ __forceinline__ void glds4(const float *g, float *lds_wave_base)
 // half-wave: conflict-free.  The quantisers of the lane's 16 outputs and the next leaf's descriptor are
 // loaded before the MFMA chains so that their latency hides under them.
 // ------------------------------------------------------------------------------------------------
+template <int S>
+struct MfmaCfg {
+    static constexpr int NT = S / 32;                       // 32x32 output tiles per side
+    static constexpr int TPW = S == 128 ? 2 : 1;            // tiles per wave (same tile column, so D registers are shared)
+    static constexpr int NWAVES = NT * NT / TPW;
+    static constexpr int NTHREADS = NWAVES * 64;
+    static constexpr int MINW = S == 32 ? 4 : S == 64 ? 3 : 2;   // waves per SIMD the register budget is sized for
+};
+
 template <int S, bool WANT_DCT>
-__global__ __launch_bounds__((S / 32) * (S / 32) * 64, S == 32 ? 4 : S == 64 ? 3 : 1) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
+__global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
 {
-    constexpr int NT = S / 32;
-    constexpr int NTHREADS = NT * NT * 64;
+    using C = MfmaCfg<S>;
+    constexpr int NT = C::NT, TPW = C::TPW, NWAVES = C::NWAVES, NTHREADS = C::NTHREADS;
     constexpr int SS = S * S;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sX = smem;            // [S][S]  X, later reused as int staging for the zigzag scatter
@@ -212,8 +221,8 @@ __global__ __launch_bounds__((S / 32) * (S / 32) * 64, S == 32 ? 4 : S == 64 ? 3
     int *s_pref = reinterpret_cast<int *>(smem + 2 * SS) + (sizeof(LayerTab) + 3) / 4;   // [nplanes + 1]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int wi = wave / NT, wj = wave % NT;
-    const int I0 = wi * 32, J0 = wj * 32;
+    const int wj = wave % NT, wi0 = wave / NT;       // tile column; first tile row (the others are wi0 + t * NT / TPW)
+    const int J0 = wj * 32;
     const int li = lane & 31, lh = lane >> 5;
 
     // B operand registers: D[J0 + li][2*s + lh]
@@ -242,56 +251,75 @@ __global__ __launch_bounds__((S / 32) * (S / 32) * 64, S == 32 ? 4 : S == 64 ? 3
         if (hc == S && wc == S && (w & 3) == 0) {
             constexpr int ROWS = 256 / S;                 // rows per wave instruction
 #pragma unroll
-            for (int t = 0; t < SS / 256 / (NT * NT); t++) {
-                const int chunk = t * NT * NT + wave;
+            for (int t = 0; t < SS / 256 / NWAVES; t++) {
+                const int chunk = t * NWAVES + wave;
                 const int r = chunk * ROWS + lane / (S / 4), c = (lane % (S / 4)) * 4;
                 glds16(src + (long long)(cur.z + r) * w + cur.y + c, sX + chunk * 256);
             }
         } else {
 #pragma unroll 4
-            for (int t = 0; t < SS / 64 / (NT * NT); t++) {
-                const int chunk = t * NT * NT + wave;
+            for (int t = 0; t < SS / 64 / NWAVES; t++) {
+                const int chunk = t * NWAVES + wave;
                 const int idx = chunk * 64 + lane;
                 const int r = idx / S, c = idx - r * S;
                 glds4(src + (long long)(cur.z + reflect_pad_idx(r, hc)) * w + cur.y + reflect_pad_idx(c, wc), sX + chunk * 64);
             }
         }
-        int qv[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) qv[r] = qm[(I0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * S + J0 + li];
         if (item + gridDim.x < count) wk = fetch_item(a, wstride, lt, s_pref, item + gridDim.x);
         __syncthreads();
 
-        floatx16 acc;
+        floatx16 acc[TPW];
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < S / 2; s++) {
-            float av = sX[(2 * s + lh) * S + I0 + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dreg[s], acc, 0, 0, 0);
+            if (S >= 64 && (s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all A loads
+#pragma unroll
+            for (int t = 0; t < TPW; t++) {
+                float av = sX[(2 * s + lh) * S + (wi0 + t * (NT / TPW)) * 32 + li];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dreg[s], acc[t], 0, 0, 0);
+            }
         }
         // accumulator layout: row = (r & 3) + 8 * (r >> 2) + 4 * lh, col = li
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sP[(I0 + row) * S + J0 + li] = acc[r];
-        }
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                sP[((wi0 + t * (NT / TPW)) * 32 + row) * S + J0 + li] = acc[t][r];
+            }
         __syncthreads();
 
+        // quantisers of this lane's outputs: loaded here so that their latency hides under the second MFMA chain
+        int qv[TPW][16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) qv[t][r] = qm[((wi0 + t * (NT / TPW)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * S + J0 + li];
+#pragma unroll
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < S / 2; s++) {
-            float av = sP[(2 * s + lh) * S + I0 + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dreg[s], acc, 0, 0, 0);
+            if (S >= 64 && (s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TPW; t++) {
+                float av = sP[(2 * s + lh) * S + (wi0 + t * (NT / TPW)) * 32 + li];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dreg[s], acc[t], 0, 0, 0);
+            }
         }
         int *sQ = reinterpret_cast<int *>(sX);   // every wave finished reading sX before the barrier above
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (WANT_DCT) a.dct_f32[out_base + (I0 + row) * S + J0 + li] = acc[r];
-            sQ[zigzag_pos<S>(I0 + row, J0 + li)] = quantise(acc[r], qv[r]);
-        }
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int row = (wi0 + t * (NT / TPW)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (WANT_DCT) a.dct_f32[out_base + row * S + J0 + li] = acc[t][r];
+                sQ[zigzag_pos<S>(row, J0 + li)] = quantise(acc[t][r], qv[t][r]);
+            }
         __syncthreads();
         for (int idx = tid * 4; idx < SS; idx += NTHREADS * 4)
             *reinterpret_cast<int4 *>(a.coeffs + out_base + idx) = *reinterpret_cast<const int4 *>(sQ + idx);
@@ -327,14 +355,13 @@ void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int
 template <int S, bool WANT_DCT>
 static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, int blocks)
 {
-    constexpr int NT = S / 32;
     size_t lds = (size_t)2 * S * S * sizeof(float) + sizeof(LayerTab) + 8 + (size_t)(a.nplanes + 1) * sizeof(int);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dct_mfma<S, WANT_DCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(NT * NT * 64), lds, st, g, q, a, max_items);
+    hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(MfmaCfg<S>::NTHREADS), lds, st, g, q, a, max_items);
 }
 
 void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)

@@ -68,7 +68,7 @@ __device__ __forceinline__ ChunkEdges chunk_edges(const Geom &g, const QtGeom &q
                 for (int xw = x0 >> 6; xw <= (x1 - 1) >> 6; xw++) {
                     int lo = max(x0, xw * 64) - xw * 64, hi = min(x1, xw * 64 + 64) - xw * 64;
                     unsigned long long mask = (hi - lo == 64) ? ~0ull : (((1ull << (hi - lo)) - 1ull) << lo);
-                    e |= (src[(long long)y * wpr + xw] & mask) != 0;
+                    e |= (src[bp_index(y, xw, wpr)] & mask) != 0;
                 }
             E.e0 |= (e ? 1u : 0u) << i;
         }

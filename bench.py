@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("AEJ_BENCH_BATCH", "64")), help="images per GPU")
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--width", type=int, default=W4K)
+    ap.add_argument("--space", default="YCbCr")
+    ap.add_argument("--blocks", type=int, nargs=2, default=[4, 64])
+    ap.add_argument("--quality", type=int, nargs=2, default=[40, 80])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6, help="4K images encoded by the CPU oracle for cpu_baseline")
     args = ap.parse_args()
@@ -97,7 +100,7 @@ def main():
     from adaptive_edge_aware_jpeg_amd._lib import get_context
 
     B, H, W = args.batch, args.height, args.width
-    space, qrange, brange = "YCbCr", (40, 80), (4, 64)
+    space, qrange, brange = args.space, tuple(args.quality), tuple(args.blocks)
     dev = torch.device("cuda", local_rank)
     x = synth_batch(torch, B, H, W, 20250718 + rank * B, dev)
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+# BASELINE.json configs 2..5 on one GPU (per-GPU share of the multi-GPU ones); prints value / ms / stages per config
+run() { python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import json,sys;d=json.load(sys.stdin);print('$*', '->', d['value'],'MP/s', d['ms_per_step'],'ms', {k:v['ms'] for k,v in d['stages'].items()}, 'passes', d['hysteresis_passes'], d['leaves_per_image'])"; }
+run --batch 1 --height 1080 --width 1920
+run --batch 64 --height 1080 --width 1920
+run --batch 64
+run --batch 8 --height 4320 --width 7680 --space OKLAB --blocks 4 128
+run --batch 16 --space ICtCp
+run --batch 16 --space YCoCg

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 tag=$1; ctr=$2
 R=$PWD
-rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16 > gpurun_out/pmc_$tag.json 2> gpurun_out/pmc_$tag.err
+rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch ${AEJ_PMC_BATCH:-16} > gpurun_out/pmc_$tag.json 2> gpurun_out/pmc_$tag.err
 f=$(ls gpurun_out/pmc_$tag/*/*counter_collection.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
@@ -15,3 +15,5 @@ for r in csv.DictReader(open(sys.argv[1])):
 for k, d in acc.items():
     print(k, {c: f"{v:.3g}" for c, v in d.items()})
 PY
+
+rm -rf gpurun_out/pmc_$tag
