@@ -476,9 +476,83 @@ static int run_quadtree(aej_ctx *ctx, const Geom &g, const QtGeom &q, QtWs &w, c
     return 0;
 }
 
+// ---- colour planes: fast 4x2-patch kernel when the shape allows it, generic kernel otherwise ---------------------------
+// OpenCV resize.cpp computeResizeAreaTab: taps of destination index d are entries off[d]..off[d+1]
+static void area_tab(int ssize, int dsize, double scale, std::vector<int> &off, std::vector<int> &si, std::vector<float> &alpha)
+{
+    off.assign((size_t)dsize + 1, 0); si.clear(); alpha.clear();
+    for (int dx = 0; dx < dsize; dx++) {
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        off[dx] = (int)si.size();
+        if (sx1 - fsx1 > 1e-3) { si.push_back(sx1 - 1); alpha.push_back((float)((sx1 - fsx1) / cell)); }
+        for (int sx = sx1; sx < sx2; sx++) { si.push_back(sx); alpha.push_back((float)(1.0 / cell)); }
+        if (fsx2 - sx2 > 1e-3) {
+            double a = fsx2 - sx2;
+            if (a > 1.) a = 1.;
+            if (a > cell) a = cell;
+            si.push_back(sx2); alpha.push_back((float)(a / cell));
+        }
+    }
+    off[dsize] = (int)si.size();
+}
+
+static long long area_tab_ints(const Geom &g)      // workspace ints reserved for the tables (upper bound)
+{
+    return 2LL * (g.w[1] + 1 + g.h[1] + 1) + 2LL * (g.W + 2 * g.w[1] + 2) + 2LL * (g.H + 2 * g.h[1] + 2) + 64;
+}
+
+static bool planes_fast_ok(const Geom &g)
+{
+    bool ok = (g.W % 4) == 0 && (g.H % 2) == 0;
+    for (int l = 1; l < 3; l++) ok = ok && g.h[l] * g.rh[l] == g.H && g.w[l] * g.rw[l] == g.W;
+    return ok;
+}
+
+static int run_color_planes(aej_ctx *ctx, const float *rgb, const Geom &g, float *raw, float *norm, unsigned char *u8, int *hist, int *tab_ws)
+{
+    float mid[3], scale[3];
+    for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
+    if (planes_fast_ok(g)) {
+        if (launch_color_planes(ctx->stream, ctx->space, rgb, g, mid, scale, raw, norm, u8, hist)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+        return 0;
+    }
+    AreaTabs t;
+    memset(&t, 0, sizeof t);
+    // resize(): scale = 1 / (dsize / ssize) in double; the fast integer paths need BOTH scales integral
+    double sx = 1.0 / ((double)g.w[1] / (double)g.W), sy = 1.0 / ((double)g.h[1] / (double)g.H);
+    int isx = (int)lrint(sx), isy = (int)lrint(sy);
+    bool fast = fabs(sx - isx) < 2.220446049250313e-16 && fabs(sy - isy) < 2.220446049250313e-16;
+    t.isx = isx; t.isy = isy;
+    if (fast) t.mode = (isx == 2 && isy == 2) ? 0 : 1;
+    else {
+        t.mode = 2;
+        if (!tab_ws) return fail(ctx, AEJ_ERR_STATE, "no workspace for the INTER_AREA tables");
+        std::vector<int> xoff, xsi, yoff, ysi;
+        std::vector<float> xal, yal;
+        area_tab(g.W, g.w[1], sx, xoff, xsi, xal);
+        area_tab(g.H, g.h[1], sy, yoff, ysi, yal);
+        std::vector<int> blob;
+        auto put_i = [&](const std::vector<int> &v) { size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
+        auto put_f = [&](const std::vector<float> &v) { size_t o = blob.size(); blob.resize(o + v.size()); memcpy(blob.data() + o, v.data(), v.size() * 4); return o; };
+        size_t o1 = put_i(xoff), o2 = put_i(xsi), o3 = put_f(xal), o4 = put_i(yoff), o5 = put_i(ysi), o6 = put_f(yal);
+        if ((long long)blob.size() > area_tab_ints(g)) return fail(ctx, AEJ_ERR_CAPACITY, "INTER_AREA tables larger than reserved");
+        AEJ_HIP_CHECK(hipMemcpyAsync(tab_ws, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // blob is a host temporary
+        t.xoff = tab_ws + o1; t.xsi = tab_ws + o2; t.xal = reinterpret_cast<const float *>(tab_ws + o3);
+        t.yoff = tab_ws + o4; t.ysi = tab_ws + o5; t.yal = reinterpret_cast<const float *>(tab_ws + o6);
+    }
+    if (launch_color_planes_generic(ctx->stream, ctx->space, rgb, g, mid, scale, t, raw, norm, u8, hist)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+    return 0;
+}
+
 // ---- whole path ---------------------------------------------------------------------------------------------
 struct EncodeWs {
     float *norm;
+    int *area_tabs;
     CannyWs canny;
     QtWs qt;
     unsigned long long bytes;
@@ -488,6 +562,7 @@ static void carve_encode(void *base, const Geom &g, const QtGeom &q, EncodeWs &w
 {
     Carver c(base);
     w.norm = c.take<float>((long long)g.B * g.pstride);
+    w.area_tabs = c.take<int>(area_tab_ints(g));
     carve_canny(c, g, w.canny);
     carve_qt(c, g, q, true, w.qt);
     w.bytes = (c.off + 255) & ~255ull;
@@ -499,8 +574,6 @@ static int check_encode_args(aej_ctx *ctx, int batch, int H, int W)
     if (!ctx->has_settings) return fail(ctx, AEJ_ERR_STATE, "aej_set_settings has not been called");
     if (batch < 1 || H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "batch, H, W must be positive");
     if (batch * 3 > kMaxPlanes) return fail(ctx, AEJ_ERR_UNSUPPORTED, "batch %d too large for one call (max %d images)", batch, kMaxPlanes / 3);
-    if ((W % 4) != 0 || (H % 2) != 0)
-        return fail(ctx, AEJ_ERR_UNSUPPORTED, "image %dx%d: this build needs W %% 4 == 0 and H %% 2 == 0 (fractional INTER_AREA not built)", H, W);
     return 0;
 }
 
@@ -548,10 +621,7 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
     if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
     mark(ctx, AEJ_STAGE_CLEAR);
 
-    float mid[3], scale[3];
-    for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
-    if (launch_color_planes(st, ctx->space, rgb, g, mid, scale, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist))
-        return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+    if ((rc = run_color_planes(ctx, rgb, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs))) return rc;
     mark(ctx, AEJ_STAGE_COLOR_PLANES);
     if ((rc = run_canny_chain(ctx, g, w.canny))) return rc;
 
@@ -599,10 +669,11 @@ extern "C" int aej_color_planes(aej_ctx *ctx, const float *rgb, int batch, int H
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
     Geom g;
     if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
-    float mid[3], scale[3];
-    for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
-    if (launch_color_planes(ctx->stream, ctx->space, rgb, g, mid, scale, planes_raw, planes_norm, planes_u8, nullptr))
-        return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+    int *tabs = nullptr;
+    if (!planes_fast_ok(g)) AEJ_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&tabs), (size_t)area_tab_ints(g) * 4));   // stage entry only
+    rc = run_color_planes(ctx, rgb, g, planes_raw, planes_norm, planes_u8, nullptr, tabs);
+    if (tabs) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tabs); }
+    if (rc) return rc;
     AEJ_HIP_CHECK(hipGetLastError());
     return 0;
 }

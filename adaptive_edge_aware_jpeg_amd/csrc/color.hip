@@ -323,6 +323,59 @@ __global__ __launch_bounds__(256) void k_color_planes(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// generic (slow-path) version of the fused plane kernel for shapes the 4x2-patch kernel cannot take: widths that are
+// not a multiple of 4, odd heights, and sizes that do not divide by the down-sampling ratios, where cv.resize(INTER_AREA)
+// is the general area-weighted resize (OpenCV resize.cpp computeResizeAreaTab + ResizeArea_Invoker):
+//   per destination pixel: sum = 0; for each vertical tap: buf = 0; for each horizontal tap: buf += S * alpha; sum += beta * buf
+// One thread per destination pixel of a layer; source pixels are colour-converted on the fly.
+// ------------------------------------------------------------------------------------------------
+template <int SPACE>
+__global__ __launch_bounds__(256) void k_color_planes_generic(const float *__restrict__ rgb, Geom g, NormConst nc, AreaTabs tabs,
+                                                              float *__restrict__ planes_raw, float *__restrict__ planes_norm,
+                                                              unsigned char *__restrict__ planes_u8, int *__restrict__ tile_hist)
+{
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int w = g.w[l], h = g.h[l];
+    const long long n = (long long)w * h;
+    const float *img = rgb + (long long)b * g.H * g.W * 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        float v;
+        auto chan = [&](int sy, int sx) {
+            const float *p = img + ((long long)sy * g.W + sx) * 3;
+            float o0, o1, o2;
+            color_px<SPACE>(p[0], p[1], p[2], o0, o1, o2);
+            return l == 0 ? o0 : l == 1 ? o1 : o2;
+        };
+        if (h == g.H && w == g.W) {
+            v = chan(y, x);                                              // dsize == ssize: copy
+        } else if (tabs.mode == 0) {                                     // exact 2x2: ((r0e + r0o) + (r1e + r1o)) * 0.25f
+            v = ((chan(2 * y, 2 * x) + chan(2 * y, 2 * x + 1)) + (chan(2 * y + 1, 2 * x) + chan(2 * y + 1, 2 * x + 1))) * 0.25f;
+        } else if (tabs.mode == 1) {                                     // other integer areas: sequential sum * (1 / area)
+            float sum = 0.f;
+            for (int dy = 0; dy < tabs.isy; dy++)
+                for (int dx = 0; dx < tabs.isx; dx++) sum += chan(y * tabs.isy + dy, x * tabs.isx + dx);
+            v = sum * (1.f / (float)(tabs.isx * tabs.isy));
+        } else {                                                         // general area tables
+            float sum = 0.f;
+            for (int j = tabs.yoff[y]; j < tabs.yoff[y + 1]; j++) {
+                float buf = 0.f;
+                for (int k = tabs.xoff[x]; k < tabs.xoff[x + 1]; k++) { float t = chan(tabs.ysi[j], tabs.xsi[k]) * tabs.xal[k]; buf = buf + t; }
+                float t = tabs.yal[j] * buf;
+                sum = sum + t;
+            }
+            v = sum;
+        }
+        const long long o = (long long)b * g.pstride + g.poff[l] + i;
+        if (planes_raw) planes_raw[o] = v;
+        if (planes_norm) planes_norm[o] = (v - nc.mid[l]) * nc.scale[l];
+        const unsigned char u = scale_u8(v);
+        if (planes_u8) planes_u8[o] = u;
+        if (tile_hist) atomicAdd(&tile_hist[(((long long)b * 3 + l) * 16 + (y / g.cth[l]) * 4 + (x / g.ctw[l])) * 256 + u], 1);
+    }
+}
+
 // stand-alone a-3 for one float32 plane (EdgeDetection.canny entry): uint8 + CLAHE tile histograms
 __global__ __launch_bounds__(256) void k_plane_u8(const float *__restrict__ plane, Geom g, unsigned char *__restrict__ u8,
                                                   int *__restrict__ tile_hist)
@@ -386,6 +439,34 @@ int launch_color_planes(hipStream_t st, int space, const float *rgb, const Geom 
     case 4: launch_planes_t<4, 1, 4>(st, rgb, g, nc, raw, norm, u8, hist); break;
     case 5: launch_planes_t<5, 1, 4>(st, rgb, g, nc, raw, norm, u8, hist); break;
     case 6: launch_planes_t<6, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+template <int SPACE>
+static void launch_generic_t(hipStream_t st, const float *rgb, const Geom &g, const NormConst &nc, const AreaTabs &tabs, float *raw,
+                             float *norm, unsigned char *u8, int *hist)
+{
+    long long n = (long long)g.W * g.H;
+    int bx = (int)((n + 255) / 256);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_color_planes_generic<SPACE>, dim3(bx, 3, g.B), dim3(256), 0, st, rgb, g, nc, tabs, raw, norm, u8, hist);
+}
+
+int launch_color_planes_generic(hipStream_t st, int space, const float *rgb, const Geom &g, const float *mid, const float *scale,
+                                const AreaTabs &tabs, float *raw, float *norm, unsigned char *u8, int *hist)
+{
+    NormConst nc;
+    for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
+    switch (space) {
+    case 0: launch_generic_t<0>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
+    case 1: launch_generic_t<1>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
+    case 2: launch_generic_t<2>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
+    case 3: launch_generic_t<3>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
+    case 4: launch_generic_t<4>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
+    case 5: launch_generic_t<5>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
+    case 6: launch_generic_t<6>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
     default: return -1;
     }
     return 0;

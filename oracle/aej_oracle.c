@@ -233,28 +233,79 @@ ORC_API void orc_color_forward(int space, const float *rgb, float *out, int64_t 
  *      other integer areas -> sequential sum over (row-major) taps, times 1.f/area (ResizeAreaFast_Invoker).
  *      conv is the (H,W,3) interleaved colour-converted image, ch selects the layer (jpeg.py:263-264 transposes).
  * ---------------------------------------------------------------------------------------- */
+/* general INTER_AREA (non-integer scale): OpenCV 4.x resize.cpp computeResizeAreaTab + ResizeArea_Invoker.
+ * tab entries for destination index d are contiguous; off[d]..off[d+1]. */
+static int area_tab(int ssize, int dsize, double scale, int *off, int *si, float *alpha)
+{
+    int k = 0;
+    for (int dx = 0; dx < dsize; dx++) {
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        off[dx] = k;
+        if (sx1 - fsx1 > 1e-3) { si[k] = sx1 - 1; alpha[k++] = (float)((sx1 - fsx1) / cellWidth); }
+        for (int sx = sx1; sx < sx2; sx++) { si[k] = sx; alpha[k++] = (float)(1.0 / cellWidth); }
+        if (fsx2 - sx2 > 1e-3) {
+            double a = fsx2 - sx2; if (a > 1.) a = 1.; if (a > cellWidth) a = cellWidth;
+            si[k] = sx2; alpha[k++] = (float)(a / cellWidth);
+        }
+    }
+    off[dsize] = k;
+    return k;
+}
+
 ORC_API int orc_downsample(const float *conv, int H, int W, int ch, int rh, int rw, float *out)
 {
-    if (rh < 1 || rw < 1 || H % rh || W % rw) return -1; /* fractional INTER_AREA: not restated */
+    if (rh < 1 || rw < 1) return -1;
     int Ho = H / rh, Wo = W / rw;
+    if (Ho < 1 || Wo < 1) return -1;
+    if (Ho == H && Wo == W) {                         /* dsize == ssize: copy */
+        for (int64_t i = 0; i < (int64_t)H * W; i++) out[i] = conv[i * 3 + ch];
+        return 0;
+    }
+    /* resize(): scale = 1 / (dsize / ssize) in double; "area fast" iff both scales are integers */
+    double scale_x = 1.0 / ((double)Wo / (double)W), scale_y = 1.0 / ((double)Ho / (double)H);
+    int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
+    int fast = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
+    if (fast) {
+        for (int y = 0; y < Ho; y++)
+            for (int x = 0; x < Wo; x++) {
+                float v;
+                if (isy == 2 && isx == 2) {
+                    const float *r0 = conv + ((int64_t)(2 * y) * W + 2 * x) * 3 + ch;
+                    const float *r1 = r0 + (int64_t)W * 3;
+                    v = ((r0[0] + r0[3]) + (r1[0] + r1[3])) * 0.25f;
+                } else {
+                    float sum = 0.f;
+                    for (int dy = 0; dy < isy; dy++)
+                        for (int dx = 0; dx < isx; dx++)
+                            sum += conv[((int64_t)(y * isy + dy) * W + (x * isx + dx)) * 3 + ch];
+                    v = sum * (1.f / (float)(isx * isy));
+                }
+                out[(int64_t)y * Wo + x] = v;
+            }
+        return 0;
+    }
+    int *xoff = (int *)malloc(sizeof(int) * (size_t)(Wo + 1)), *yoff = (int *)malloc(sizeof(int) * (size_t)(Ho + 1));
+    int *xsi = (int *)malloc(sizeof(int) * (size_t)(W + 2 * Wo + 2)), *ysi = (int *)malloc(sizeof(int) * (size_t)(H + 2 * Ho + 2));
+    float *xal = (float *)malloc(sizeof(float) * (size_t)(W + 2 * Wo + 2)), *yal = (float *)malloc(sizeof(float) * (size_t)(H + 2 * Ho + 2));
+    area_tab(W, Wo, scale_x, xoff, xsi, xal);
+    area_tab(H, Ho, scale_y, yoff, ysi, yal);
     for (int y = 0; y < Ho; y++)
         for (int x = 0; x < Wo; x++) {
-            float v;
-            if (rh == 1 && rw == 1) {
-                v = conv[((int64_t)y * W + x) * 3 + ch];
-            } else if (rh == 2 && rw == 2) {
-                const float *r0 = conv + ((int64_t)(2 * y) * W + 2 * x) * 3 + ch;
-                const float *r1 = r0 + (int64_t)W * 3;
-                v = ((r0[0] + r0[3]) + (r1[0] + r1[3])) * 0.25f;
-            } else {
-                float sum = 0.f;
-                for (int dy = 0; dy < rh; dy++)
-                    for (int dx = 0; dx < rw; dx++)
-                        sum += conv[((int64_t)(y * rh + dy) * W + (x * rw + dx)) * 3 + ch];
-                v = sum * (1.f / (float)(rh * rw));
+            float sum = 0.f;
+            for (int j = yoff[y]; j < yoff[y + 1]; j++) {
+                const float *S = conv + (int64_t)ysi[j] * W * 3 + ch;
+                float buf = 0.f;
+                for (int k = xoff[x]; k < xoff[x + 1]; k++) { float t = S[(int64_t)xsi[k] * 3] * xal[k]; buf = buf + t; }
+                float t = yal[j] * buf;
+                sum = sum + t;
             }
-            out[(int64_t)y * Wo + x] = v;
+            out[(int64_t)y * Wo + x] = sum;
         }
+    free(xoff); free(yoff); free(xsi); free(ysi); free(xal); free(yal);
     return 0;
 }
 

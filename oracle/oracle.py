@@ -96,7 +96,7 @@ def downsample(conv_hw3, ch, rh, rw):
     out = np.empty((H // rh, W // rw), dtype=np.float32)
     rc = lib().orc_downsample(_p(conv), H, W, ch, rh, rw, _p(out))
     if rc != 0:
-        raise ValueError("oracle: fractional INTER_AREA ratios are not restated (H, W must divide by the ratios)")
+        raise ValueError("oracle: bad down-sampling geometry")
     return out
 
 

@@ -133,3 +133,36 @@ def test_quadtree_structure_properties(oracle):
             elif st == 1:
                 stack.extend([size // 2] * 4)
         assert sizes == leaves[:, 2].tolist()
+
+
+def test_general_inter_area_against_float64_integration(oracle):
+    """odd sizes: cv.resize(INTER_AREA) is an area-weighted mean over [d*scale, (d+1)*scale) (clipped at the image edge)."""
+    rng = np.random.default_rng(0)
+
+    def area_ref(a, Ho, Wo):
+        H, W = a.shape
+        sy, sx = H / Ho, W / Wo
+        out = np.zeros((Ho, Wo))
+        for y in range(Ho):
+            for x in range(Wo):
+                y0, y1, x0, x1 = y * sy, min((y + 1) * sy, H), x * sx, min((x + 1) * sx, W)
+                acc = area = 0.0
+                for yy in range(int(np.floor(y0)), int(np.ceil(y1))):
+                    wy = min(yy + 1, y1) - max(yy, y0)
+                    for xx in range(int(np.floor(x0)), int(np.ceil(x1))):
+                        wx = min(xx + 1, x1) - max(xx, x0)
+                        acc += a[yy, xx] * wy * wx
+                        area += wy * wx
+                out[y, x] = acc / area
+        return out
+
+    for (H, W, rh, rw) in ((7, 9, 2, 2), (33, 35, 2, 2), (12, 50, 1, 4), (5, 9, 2, 2), (10, 10, 2, 2), (9, 8, 1, 4)):
+        conv = rng.random((H, W, 3), dtype=np.float32)
+        for ch in (0, 2):
+            got = oracle.downsample(conv, ch, rh, rw)
+            assert got.shape == (H // rh, W // rw)
+            assert np.abs(got - area_ref(conv[:, :, ch].astype(np.float64), H // rh, W // rw)).max() < 5e-7
+    flat = np.full((11, 13, 3), 0.3, np.float32)
+    assert np.abs(oracle.downsample(flat, 1, 2, 2) - np.float32(0.3)).max() < 1e-7
+    same = oracle.downsample(rng.random((6, 6, 3), dtype=np.float32), 0, 1, 1)
+    assert same.shape == (6, 6)
