@@ -147,8 +147,18 @@ def main():
     dom = max(kernels, key=kernels.get)
     local_px = B * H * W
     achieved = ALGO_BYTES_PER_PX[dom] * local_px / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
+    # HBM bytes of the dominant kernel from the PMC passes (tests/traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # runs of this same workload; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_color_planes' known read volume)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if (tj.get("batch"), tj.get("height"), tj.get("width")) == (B, H, W) and space == "YCbCr" and brange == (4, 64):
+            names = {"color_planes": ["k_color_planes"], "clahe_blur": ["k_clahe_blur"], "sobel_nms": ["k_sobel_nms"],
+                     "hysteresis": ["k_hyst_pass"], "quadtree": ["k_qt_"], "dct": ["k_dct_"]}[dom]
+            traffic = sum(v["hbm_bytes"] for k, v in tj["kernels"].items() if any(k.startswith(n) for n in names))
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX[dom] * local_px, "avg_launch_ms": round(kernels[dom], 4)}
     whole = WHOLE_PATH_BYTES_PER_PX * local_px / (ms_per_step * 1e-3) / 1e9
     per_stage = {k: {"ms": round(v, 4), "GBps": round(ALGO_BYTES_PER_PX[k] * local_px / (v * 1e-3) / 1e9, 1) if v > 0 else None}

@@ -7,5 +7,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag 
 f=$(ls gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1)
 cp $f gpurun_out/prof_${tag}_kernel_stats.csv
 rm -rf gpurun_out/prof_$tag
-python3 tests/kstats.py $f
+python3 tests/kstats.py gpurun_out/prof_${tag}_kernel_stats.csv
 python3 -c "import json;d=json.load(open('gpurun_out/prof_$tag.json'));print(d['value'],d['ms_per_step'],{k:v['ms'] for k,v in d['stages'].items()})"
