@@ -1,7 +1,7 @@
 """``color.convert`` / ``apply_normalization`` / ``get_color_spaces`` (src/color/conversion.py:86-157) on the GPU.
 
-Forward transforms (sRGB -> space) run in the HIP kernels of csrc/color.hip through ``aej_color_convert``.
-Inverse transforms belong to the decode path and are not built yet.
+Forward transforms (sRGB -> space) run in the HIP kernels of csrc/color.hip through ``aej_color_convert``, inverse
+transforms (decode path) in csrc/decode.hip through ``aej_color_convert_inverse``.
 """
 import ctypes
 
@@ -59,7 +59,15 @@ def convert(from_space: str, to_space: str, data: np.ndarray) -> np.ndarray:
         ctx.check(ctx.lib.aej_color_convert(ctx.handle, SPACE_IDS[to_space], x.data_ptr(), out.data_ptr(),
                                             ctypes.c_int64(x.shape[0])))
         return out.cpu().numpy()
-    raise NotImplementedError(f"{from_space} -> sRGB belongs to the decode path (not built in this round)")
+    if from_space == "XYZ":
+        raise NotImplementedError("XYZ -> sRGB is not on the codec path and is not built")
+    ctx = get_context()
+    t = ctx.torch
+    x = ctx.to_device(data, t.float32)
+    out = t.empty_like(x)
+    ctx.check(ctx.lib.aej_color_convert_inverse(ctx.handle, SPACE_IDS[from_space], x.data_ptr(), out.data_ptr(),
+                                                ctypes.c_int64(x.shape[0])))
+    return out.cpu().numpy()
 
 
 def apply_normalization(color_space: str, data: np.ndarray, inverse: bool) -> np.ndarray:

@@ -84,4 +84,23 @@ void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const 
 // builds a work list from a leaf table (stand-alone aej_dct_quant_zigzag)
 void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int bmin, int plane, LeafWork *const *work, int *work_count);
 
+
+// decode.hip
+struct IdctArgs {
+    const int *coeffs;        // [B][coeff_stride] zigzag-ordered quantised coefficients
+    float *planes;            // out [B][pstride] de-normalised layers
+    const LeafWork *work;
+    const int *work_count;    // [nplanes][kMaxSizes]
+    int k, nplanes;
+    const float *D;           // [s][s]
+    const int *zz, *zzinv;    // zigzag order and its inverse
+    const int *qm[3];
+    float mid[3], scale[3];
+};
+void launch_work_from_tables(hipStream_t st, const Geom &g, const QtGeom &q, const int *leaves, const long long *counts, LeafWork *const *work,
+                             int *work_count);
+void launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const IdctArgs &a, long long max_items);
+int launch_color_inverse(hipStream_t st, int space, const float *in, float *out, long long n);
+int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float *planes, float *rgb);
+
 }  // namespace aej

@@ -1,6 +1,6 @@
 """``Jpeg`` -- the reference's codec object (src/jpeg/jpeg.py:177-800) with the encode hot path on the GPU.
 
-``compress(img)`` keeps the reference signature (Image -> .ajpg bytes).  Stages a-1 ... a-15 of SURVEY.md
+``compress(img)`` / ``decompress(bytes)`` keep the reference signatures (Image <-> .ajpg bytes).  Stages a-1 ... a-15 of SURVEY.md
 section 8 (colour convert, down-sample, Canny, quadtree, normalise, DCT, quantise, zigzag) run as HIP kernels
 behind ``aej_encode_batch``; the ``.ajpg`` container (JSON header, 2-bit state packing, per-layer zlib-9;
 jpeg.py:531-597) is written on the host from the kernel outputs.  ``compress_batch`` is the throughput entry:
@@ -132,8 +132,72 @@ class Jpeg:
         layers = [enc.layer(0, l) for l in range(3)]
         return self._entropy_encode(layers)
 
+    # ------------------------------------------------------------------ decode (jpeg.py:274-297)
+    def decompress_batch(self, enc: EncodedBatch):
+        """Device round trip: decode an EncodedBatch in place -> torch float32 [B, H, W, 3] in [0, 1] on the GPU."""
+        ctx = self._bind()
+        t = ctx.torch
+        p = enc.plan
+        out = ctx.empty((p.batch, p.H, p.W, 3), t.float32)
+        nbytes = ctx.lib.aej_decode_workspace_bytes(ctx.handle, p.batch, p.H, p.W)
+        ws = ctx.workspace(nbytes)
+        ctx.check(ctx.lib.aej_decode_batch(ctx.handle, enc.coeffs.data_ptr(), enc.leaves.data_ptr(), enc.counts.data_ptr(), p.batch,
+                                           p.H, p.W, out.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes)))
+        return out
+
     def decompress(self, img_encoded: bytes) -> Image:
-        raise NotImplementedError("decode path (jpeg.py:274-297) is the next scope row (SURVEY.md 8f-2); not built yet")
+        """Decompresses encoded image data (jpeg.py:274-297): container parsing and zlib on the host, everything else on the GPU."""
+        meta, layers = self._entropy_decode(img_encoded)
+        H, W = self.layer_shape
+        ctx = self._bind()
+        t = ctx.torch
+        plan = ctx.plan(1, H, W)
+        coeffs = np.zeros(plan.coeff_stride, np.int32)
+        leaves = np.zeros((plan.leaf_stride, 4), np.int32)
+        counts = np.zeros((1, 3, 4), np.int64)
+        for l, L in enumerate(layers):
+            h, w = (int(v) for v in self.layer_shapes[l])
+            sizes = np.asarray(Jpeg._decode_leaf_sizes(L["states"], L["root_size"]), dtype=np.int32)
+            root = tables.largest_power_of_2(max(h, w)) * 2                     # jpeg.py:425
+            xy = np.zeros((len(sizes), 2), np.int32)
+            placed = ctx.lib.aej_leaf_positions_host(sizes.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(sizes)), root, h, w,
+                                                     xy.ctypes.data_as(ctypes.c_void_p))
+            if placed != len(sizes):
+                raise ValueError("corrupt stream: quadtree header does not tile the layer")
+            offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64) ** 2)])
+            if offs[-1] != L["coeffs"].size or offs[-1] > plan.coeff_stride:
+                raise ValueError("corrupt stream: coefficient count does not match the quadtree header")
+            co, lo = plan.coeff_off[l], plan.leaf_off[l]
+            coeffs[co:co + offs[-1]] = L["coeffs"]
+            leaves[lo:lo + len(sizes), 0:2] = xy
+            leaves[lo:lo + len(sizes), 2] = sizes
+            leaves[lo:lo + len(sizes), 3] = offs[:-1]
+            counts[0, l] = (offs[-1], len(sizes), len(L["states"]), L["root_size"])
+        enc = EncodedBatch(plan, ctx.to_device(coeffs, t.int32), ctx.to_device(leaves, t.int32), None, ctx.to_device(counts, t.int64))
+        rgb = self.decompress_batch(enc)[0].cpu().numpy()
+        return Image.from_array(rgb, rgb.shape, self.extension)
+
+    def _entropy_decode(self, encoded_data: bytes):
+        """Container parsing of jpeg.py:599-661: restores settings from the JSON header (jpeg.py:613-631) and returns the
+        per-layer state symbols, root size and zigzag-ordered coefficients."""
+        s = BytesIO(encoded_data)
+        mlen = int.from_bytes(s.read(4), byteorder="big")
+        meta = json.loads(s.read(mlen).decode("utf-8"))
+        self.extension = meta["extension"]
+        self.update_settings(JpegCompressionSettings(color_space=meta["color_space"],
+                                                     quality_range=(meta["quality_min"], meta["quality_max"]),
+                                                     block_size_range=(meta["block_size_min"], meta["block_size_max"])),
+                             (meta["height"], meta["width"]))
+        layers = []
+        for _ in range(meta["num_layers"]):
+            bits_len = int.from_bytes(s.read(4), byteorder="big")
+            root_size = int.from_bytes(s.read(4), byteorder="big")
+            packed = np.frombuffer(s.read((bits_len + 7) // 8), dtype=np.uint8)
+            st = np.stack([(packed >> 6) & 3, (packed >> 4) & 3, (packed >> 2) & 3, packed & 3], 1).reshape(-1)[: bits_len // 2]
+            clen = int.from_bytes(s.read(4), byteorder="big")
+            coeffs = np.frombuffer(zlib.decompress(s.read(clen)), dtype=np.int32)
+            layers.append({"states": st.tolist(), "root_size": root_size, "coeffs": coeffs})
+        return meta, layers
 
     # ------------------------------------------------------------------ .ajpg container (jpeg.py:531-597)
     def _entropy_encode(self, layers) -> bytes:

@@ -135,6 +135,19 @@ AEJ_API int aej_quadtree(aej_ctx *ctx, const uint8_t *edge, int H, int W, int mi
 AEJ_API int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, int layer, const int32_t *leaves,
                          int64_t n_leaves, int32_t *coeffs, float *dct_f32);
 
+/* ---- decode path: Jpeg.decompress after the host-side entropy decode (jpeg.py:285-296) ------
+ * coeffs / leaves / counts use the layout of aej_encode_batch's outputs (so an encoded batch can be decoded in
+ * place); counts is a DEVICE array [batch][3][4], only n_leaves is read.  rgb_out: [batch][H][W][3] float32 in [0,1]
+ * (Jpeg._dequantize, _apply_inverse_dct, _block_merge, _upsample, _convert_color_space_inverse). */
+AEJ_API uint64_t aej_decode_workspace_bytes(aej_ctx *ctx, int batch, int H, int W);
+AEJ_API int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32_t *leaves, const int64_t *counts, int batch, int H,
+                             int W, float *rgb_out, void *workspace, uint64_t workspace_bytes);
+/* color.convert(space, "sRGB", x) (conversion.py:122-124): in [n][3] -> sRGB [n][3], float32 */
+AEJ_API int aej_color_convert_inverse(aej_ctx *ctx, int space, const float *in, float *out_rgb, int64_t n);
+/* HOST helper (no device): leaf positions from leaf sizes, the walk of Jpeg._block_merge (jpeg.py:424-448).
+ * sizes_host [n] -> xy_host [n][2]; returns the number of leaves placed. */
+AEJ_API int64_t aej_leaf_positions_host(const int32_t *sizes_host, int64_t n, int root, int H, int W, int32_t *xy_host);
+
 #ifdef __cplusplus
 }
 #endif

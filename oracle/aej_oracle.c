@@ -750,3 +750,245 @@ ORC_API int orc_blocks_encode(const float *norm, int H, int W, const int32_t *le
     free(X);
     return rc;
 }
+
+/* ==========================================================================================
+ * DECODE path (src/jpeg/jpeg.py:274-297) -- next-scope row, restated the same way.
+ * ======================================================================================== */
+#include "aej_inv_constants.h"
+
+static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float idot3(const uint32_t *m, float a, float b, float c)   /* np.dot float32 row, k-ordered fma chain */
+{
+    float acc = a * bits2f(m[0]);
+    acc = fmaf(b, bits2f(m[1]), acc);
+    return fmaf(c, bits2f(m[2]), acc);
+}
+static inline float clip01(float v) { return v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v; }   /* np.clip (NaN stays NaN) */
+
+/* common.py:62-92: float64 under numba typing, then max(0.0, min(1.0, x)) on the stored float32 (NaN -> 1.0) */
+static inline float linear_to_srgb(float v)
+{
+    double d = (double)v, r;
+    if (d <= 0.0031308) r = d * 12.92;
+    else r = 1.055 * orc_pow(d, 1.0 / 2.4) - 0.055;
+    float f = (float)r;
+    float m = (f < 1.0f) ? f : 1.0f;      /* min(1.0, f): f if f < 1.0 else 1.0 */
+    return (m > 0.0f) ? m : 0.0f;         /* max(0.0, m) */
+}
+
+/* common.py:94-129 */
+static inline double pq_eotf(double v, double m2)
+{
+    const double c1 = 3424.0 / 4096.0, c2 = 2413.0 / 128.0, c3 = 2392.0 / 128.0, m1 = 2610.0 / 16384.0;
+    double tmp = orc_pow(v, 1.0 / m2);
+    double num = tmp - c1, den = c2 - c3 * tmp;
+    if (num < 0.0) num = 0.0;
+    if (den <= 0.0) den = 1e-12;
+    return 10000.0 * orc_pow(num / den, 1.0 / m1);
+}
+
+static inline float ilin3(const uint32_t *m, float a, float b, float c)   /* float32 m0*a + m1*b + m2*c, no fma */
+{
+    float t = bits2f(m[0]) * a, u = bits2f(m[1]) * b;
+    t = t + u;
+    u = bits2f(m[2]) * c;
+    return t + u;
+}
+static inline double ilin3d(const uint32_t *m, double a, double b, double c)
+{
+    double t = (double)bits2f(m[0]) * a, u = (double)bits2f(m[1]) * b;
+    t = t + u;
+    u = (double)bits2f(m[2]) * c;
+    return t + u;
+}
+
+static void xyz_to_srgb(float X, float Y, float Z, float *o)   /* xyz.py:83-84 */
+{
+    float r = idot3(INV_XYZ_RGB_BITS + 0, X, Y, Z), g = idot3(INV_XYZ_RGB_BITS + 3, X, Y, Z), b = idot3(INV_XYZ_RGB_BITS + 6, X, Y, Z);
+    o[0] = linear_to_srgb(r); o[1] = linear_to_srgb(g); o[2] = linear_to_srgb(b);
+}
+
+static void color_inv_px(int space, float a, float b, float c, float *o)
+{
+    const uint32_t *m = NULL;
+    switch (space) {
+    case SP_YCBCR: m = INV_YCBCR_BITS; break;       /* ycbcr.py:80-83 */
+    case SP_YCOCG: m = INV_YCOCG_BITS; break;       /* ycocg.py:101-104 */
+    case SP_YCOCG_R: m = INV_YCOCG_R_BITS; break;   /* ycocg.py:140-143 */
+    default: break;
+    }
+    if (m) {
+        o[0] = clip01(idot3(m + 0, a, b, c)); o[1] = clip01(idot3(m + 3, a, b, c)); o[2] = clip01(idot3(m + 6, a, b, c));
+        return;
+    }
+    if (space == SP_OKLAB) {   /* oklab.py:92-96 */
+        float lp = idot3(INV_OK_LAB_LMSP_BITS + 0, a, b, c), mp = idot3(INV_OK_LAB_LMSP_BITS + 3, a, b, c), sp = idot3(INV_OK_LAB_LMSP_BITS + 6, a, b, c);
+        /* np.power(f32, 3): x^3 rounded once from float64 */
+        double dl = lp, dm = mp, ds = sp;
+        float l = (float)(dl * dl * dl), mm = (float)(dm * dm * dm), s = (float)(ds * ds * ds);
+        float X = idot3(INV_OK_LMS_XYZ_BITS + 0, l, mm, s), Y = idot3(INV_OK_LMS_XYZ_BITS + 3, l, mm, s), Z = idot3(INV_OK_LMS_XYZ_BITS + 6, l, mm, s);
+        xyz_to_srgb(X, Y, Z, o);
+        return;
+    }
+    if (space == SP_ICTCP || space == SP_ICACB) {   /* ictcp.py:101-137, icacb.py:101-137 */
+        const uint32_t *m2 = space == SP_ICTCP ? INV_ICT_LMSP_BITS : INV_ICA_RGBP_BITS;
+        const uint32_t *m1 = space == SP_ICTCP ? INV_ICT_LMS_XYZ_BITS : INV_ICA_RGB_XYZ_BITS;
+        float Lp = ilin3(m2 + 0, a, b, c), Mp = ilin3(m2 + 3, a, b, c), Sp = ilin3(m2 + 6, a, b, c);
+        const double pm2 = 2523.0 / 32.0;
+        double L = pq_eotf((double)Lp, pm2), M = pq_eotf((double)Mp, pm2), S = pq_eotf((double)Sp, pm2);
+        float X = (float)ilin3d(m1 + 0, L, M, S), Y = (float)ilin3d(m1 + 3, L, M, S), Z = (float)ilin3d(m1 + 6, L, M, S);
+        xyz_to_srgb(X, Y, Z, o);
+        return;
+    }
+    {   /* JzAzBz, jzazbz.py:136-176 */
+        const double bb = 1.15, gg = 0.66, d = -0.56, d0 = 1.6295499532821566e-11, p = 1.7 * 2523.0 / 32.0;
+        const uint32_t *m2 = INV_JZ_LMSP_BITS, *m1 = INV_JZ_LMS_XYZ_BITS;
+        double Iz = ((double)a + d0) / (1.0 + d - d * ((double)a + d0));
+        /* numba typing: M[i,0]*Iz is float64, M[i,1]*Az and M[i,2]*Bz are float32 products */
+        double Lp = ((double)bits2f(m2[0]) * Iz + (double)(bits2f(m2[1]) * b)) + (double)(bits2f(m2[2]) * c);
+        double Mp = ((double)bits2f(m2[3]) * Iz + (double)(bits2f(m2[4]) * b)) + (double)(bits2f(m2[5]) * c);
+        double Sp = ((double)bits2f(m2[6]) * Iz + (double)(bits2f(m2[7]) * b)) + (double)(bits2f(m2[8]) * c);
+        double L = pq_eotf(Lp, p), M = pq_eotf(Mp, p), S = pq_eotf(Sp, p);
+        double Xp = ilin3d(m1 + 0, L, M, S), Yp = ilin3d(m1 + 3, L, M, S), Zp = ilin3d(m1 + 6, L, M, S);
+        double X = (Xp + (bb - 1.0) * Zp) / bb;
+        double Y = (Yp + (gg - 1.0) * X) / gg;
+        xyz_to_srgb((float)X, (float)Y, (float)Zp, o);
+    }
+}
+
+ORC_API void orc_color_inverse(int space, const float *in, float *out, int64_t n)
+{
+    for (int64_t i = 0; i < n; i++) color_inv_px(space, in[3 * i], in[3 * i + 1], in[3 * i + 2], out + 3 * i);
+}
+
+/* Jpeg._block_merge's walk (jpeg.py:424-448): positions of the leaves from their sizes + geometry */
+ORC_API int64_t orc_leaf_positions(const int32_t *sizes, int64_t n, int root, int H, int W, int32_t *xy)
+{
+    int64_t cap = 64 * 4 + 16, sp = 0, li = 0;
+    qitem *stack = (qitem *)malloc(sizeof(qitem) * (size_t)cap);
+    stack[sp++] = (qitem){ 0, 0, root };
+    while (sp > 0 && li < n) {
+        qitem it = stack[--sp];
+        if (it.x >= W || it.y >= H || it.s == 0) continue;
+        if (it.s == sizes[li]) { xy[2 * li] = it.x; xy[2 * li + 1] = it.y; li++; }
+        else {
+            int h = it.s / 2;
+            if (sp + 4 > cap) { cap *= 2; stack = (qitem *)realloc(stack, sizeof(qitem) * (size_t)cap); }
+            stack[sp++] = (qitem){ it.x + h, it.y + h, h };
+            stack[sp++] = (qitem){ it.x, it.y + h, h };
+            stack[sp++] = (qitem){ it.x + h, it.y, h };
+            stack[sp++] = (qitem){ it.x, it.y, h };
+        }
+    }
+    free(stack);
+    return li;
+}
+
+/* inverse zigzag + _dequantize (jpeg.py:663-670, 508-529) + cv.idct (jpeg.py:483) + merge/crop + _denormalize
+ * (jpeg.py:441-455, common.py:176-189).  IDCT contract: T = D^T.Y, X = T.D as k-ordered float32 fma chains from +0. */
+ORC_API int orc_blocks_decode(const int32_t *coeffs, const int32_t *leaves, int64_t n_leaves, const int32_t *const *qm_by_log2,
+                              const int32_t *const *zz_by_log2, float mid, float scale, int H, int W, float *plane)
+{
+    float *Dm[16] = { 0 };
+    int maxs = 1;
+    for (int64_t i = 0; i < n_leaves; i++) if (leaves[3 * i + 2] > maxs) maxs = leaves[3 * i + 2];
+    float *Y = (float *)malloc(sizeof(float) * (size_t)maxs * maxs * 3);
+    float *T = Y + (size_t)maxs * maxs, *X = T + (size_t)maxs * maxs;
+    int64_t off = 0;
+    int rc = 0;
+    for (int64_t li = 0; li < n_leaves; li++) {
+        int x = leaves[3 * li], y = leaves[3 * li + 1], s = leaves[3 * li + 2];
+        int lg = 0; while ((1 << lg) < s) lg++;
+        if ((1 << lg) != s || lg >= 16 || !qm_by_log2[lg] || !zz_by_log2[lg]) { rc = -3; break; }
+        if (!Dm[lg]) { Dm[lg] = (float *)malloc(sizeof(float) * (size_t)s * s); orc_dct_matrix(s, Dm[lg]); }
+        const float *D = Dm[lg];
+        const int32_t *qm = qm_by_log2[lg], *zz = zz_by_log2[lg];
+        for (int i = 0; i < s * s; i++) Y[zz[i]] = (float)(coeffs[off + i] * qm[zz[i]]);
+        for (int n = 0; n < s; n++) {          /* T[n][j] = sum_k D[k][n] Y[k][j] */
+            float *t = T + n * s;
+            for (int j = 0; j < s; j++) t[j] = 0.f;
+            for (int k = 0; k < s; k++) {
+                float d = D[k * s + n];
+                const float *yr = Y + k * s;
+                for (int j = 0; j < s; j++) t[j] = fmaf(d, yr[j], t[j]);
+            }
+        }
+        for (int n = 0; n < s; n++) {          /* X[n][m] = sum_k T[n][k] D[k][m] */
+            float *xr = X + n * s;
+            for (int m = 0; m < s; m++) xr[m] = 0.f;
+            for (int k = 0; k < s; k++) {
+                float t = T[n * s + k];
+                const float *dr = D + k * s;
+                for (int m = 0; m < s; m++) xr[m] = fmaf(t, dr[m], xr[m]);
+            }
+        }
+        for (int n = 0; n < s && y + n < H; n++)
+            for (int m = 0; m < s && x + m < W; m++) {
+                float v = X[n * s + m] / scale;
+                plane[(int64_t)(y + n) * W + x + m] = v + mid;
+            }
+        off += (int64_t)s * s;
+    }
+    for (int i = 0; i < 16; i++) free(Dm[i]);
+    free(Y);
+    return rc;
+}
+
+/* Jpeg._upsample (jpeg.py:340-354): cv.resize(layer, (W, H), INTER_LINEAR), float32.  OpenCV 4.x resizeGeneric_ with
+ * HResizeLinear / VResizeLinear: half-pixel centres; x index clamped with the weight forced to 0 at both ends, y rows
+ * clipped with the weight left as computed; horizontal pass then vertical pass, separate mul / add. */
+ORC_API void orc_upsample_linear(const float *src, int h, int w, float *dst, int H, int W)
+{
+    if (h == H && w == W) { memcpy(dst, src, sizeof(float) * (size_t)H * W); return; }
+    double scale_x = 1.0 / ((double)W / (double)w), scale_y = 1.0 / ((double)H / (double)h);
+    int *xofs = (int *)malloc(sizeof(int) * (size_t)W);
+    float *xa = (float *)malloc(sizeof(float) * (size_t)W * 2);
+    for (int dx = 0; dx < W; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= w - 1) { fx = 0.f; sx = w - 1; }
+        xofs[dx] = sx; xa[2 * dx] = 1.f - fx; xa[2 * dx + 1] = fx;
+    }
+    float *r0 = (float *)malloc(sizeof(float) * (size_t)W * 2), *r1 = r0 + W;
+    for (int dy = 0; dy < H; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        float b0 = 1.f - fy, b1 = fy;
+        int y0 = sy < 0 ? 0 : sy > h - 1 ? h - 1 : sy, y1 = sy + 1 < 0 ? 0 : sy + 1 > h - 1 ? h - 1 : sy + 1;
+        const float *s0 = src + (int64_t)y0 * w, *s1 = src + (int64_t)y1 * w;
+        for (int dx = 0; dx < W; dx++) {
+            int sx = xofs[dx];
+            int sx1 = sx + 1 < w ? sx + 1 : sx;          /* weight is 0 there */
+            float a0 = xa[2 * dx], a1 = xa[2 * dx + 1];
+            if (sx + 1 < w) {
+                float p = s0[sx] * a0, q = s0[sx1] * a1; r0[dx] = p + q;
+                p = s1[sx] * a0; q = s1[sx1] * a1; r1[dx] = p + q;
+            } else {                                     /* dx >= xmax: D = S[sx] * ONE */
+                r0[dx] = s0[sx] * 1.0f; r1[dx] = s1[sx] * 1.0f;
+            }
+        }
+        float *d = dst + (int64_t)dy * W;
+        for (int dx = 0; dx < W; dx++) { float p = r0[dx] * b0, q = r1[dx] * b1; d[dx] = p + q; }
+    }
+    free(xofs); free(xa); free(r0);
+}
+
+/* bare IDCT contract on one float block (used by the fixture generator as the cv2.idct stand-in) */
+ORC_API void orc_idct_block(const float *D, const float *Y, float *X, int s)
+{
+    float *T = (float *)malloc(sizeof(float) * (size_t)s * s);
+    for (int n = 0; n < s; n++) {
+        float *t = T + n * s;
+        for (int j = 0; j < s; j++) t[j] = 0.f;
+        for (int k = 0; k < s; k++) { float d = D[k * s + n]; const float *yr = Y + k * s; for (int j = 0; j < s; j++) t[j] = fmaf(d, yr[j], t[j]); }
+    }
+    for (int n = 0; n < s; n++) {
+        float *xr = X + n * s;
+        for (int m = 0; m < s; m++) xr[m] = 0.f;
+        for (int k = 0; k < s; k++) { float t = T[n * s + k]; const float *dr = D + k * s; for (int m = 0; m < s; m++) xr[m] = fmaf(t, dr[m], xr[m]); }
+    }
+    free(T);
+}

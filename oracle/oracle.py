@@ -51,9 +51,10 @@ CHR = np.array([[17, 18, 24, 47, 99, 99, 99, 99], [18, 21, 26, 66, 99, 99, 99, 9
 
 def build(force=False):
     """Compile aej_oracle.c -> liboracle.so (gcc, no contraction, no fast-math)."""
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+    hdr = os.path.join(_HERE, "aej_inv_constants.h")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(_SRC), os.path.getmtime(hdr)):
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
-                               "-fvisibility=hidden", "-mfma", "-mavx2", "-o", _SO, _SRC, "-lm"])
+                               "-fvisibility=hidden", "-mfma", "-mavx2", "-I", _HERE, "-o", _SO, _SRC, "-lm"])
     return _SO
 
 
@@ -66,7 +67,8 @@ def lib():
         build()
         _lib = ctypes.CDLL(_SO)
         _lib.orc_root_size.restype = ctypes.c_int
-        for name in ("orc_downsample", "orc_quadtree", "orc_blocks_encode"):
+        _lib.orc_leaf_positions.restype = ctypes.c_int64
+        for name in ("orc_downsample", "orc_quadtree", "orc_blocks_encode", "orc_blocks_decode"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -376,3 +378,99 @@ def synth_image(H, W, seed, kind="mixed"):
         img[y0:y0 + h, x0:x0 + w, :] = col
     img += rng.normal(0.0, 1.5, size=img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ decode path (jpeg.py:274-297), next-scope row
+def color_inverse(space, data):
+    data = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 3)
+    out = np.empty_like(data)
+    lib().orc_color_inverse(ctypes.c_int(SPACES[space]), _p(data), _p(out), ctypes.c_int64(data.shape[0]))
+    return out
+
+
+def decode_leaf_sizes(states, root):
+    """Jpeg._decode_leaf_sizes (jpeg.py:768-800)"""
+    sizes, stack, i = [], [root], 0
+    states = list(states)
+    while stack and i < len(states):
+        size = stack.pop()
+        s = states[i]
+        i += 1
+        if s == 0:
+            sizes.append(size)
+        elif s == 1:
+            stack.extend([size // 2] * 4)
+    return sizes
+
+
+def leaf_positions(sizes, root, H, W):
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    xy = np.zeros((len(sizes), 2), np.int32)
+    n = lib().orc_leaf_positions(_p(sizes), ctypes.c_int64(len(sizes)), root, H, W, _p(xy))
+    assert n == len(sizes)
+    return xy
+
+
+def blocks_decode(coeffs, leaves, qm_by_size, zz_by_size, space, layer, H, W):
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int32)
+    leaves = np.ascontiguousarray(leaves, dtype=np.int32).reshape(-1, 3)
+    plane = np.zeros((H, W), np.float32)
+    qarr = (ctypes.c_void_p * 16)()
+    zarr = (ctypes.c_void_p * 16)()
+    keep = []
+    for s, q in qm_by_size.items():
+        q = np.ascontiguousarray(q, dtype=np.int32)
+        z = np.ascontiguousarray(zz_by_size[s], dtype=np.int32)
+        keep += [q, z]
+        lg = int(math.log2(s))
+        qarr[lg] = q.ctypes.data
+        zarr[lg] = z.ctypes.data
+    mid = np.array(NORM[space][0], dtype=np.float32)[layer]
+    sc = np.array(NORM[space][1], dtype=np.float32)[layer]
+    rc = lib().orc_blocks_decode(_p(coeffs), _p(leaves), ctypes.c_int64(leaves.shape[0]), qarr, zarr, ctypes.c_float(mid),
+                                 ctypes.c_float(sc), H, W, _p(plane))
+    if rc != 0:
+        raise RuntimeError(f"oracle blocks_decode rc={rc}")
+    return plane
+
+
+def upsample_linear(plane, H, W):
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    out = np.empty((H, W), np.float32)
+    lib().orc_upsample_linear(_p(plane), plane.shape[0], plane.shape[1], _p(out), H, W)
+    return out
+
+
+def parse_ajpg(data):
+    """Jpeg._entropy_decode's container parsing (jpeg.py:609-661) -> metadata, per-layer (states, root, coeffs)"""
+    s = BytesIO(data)
+    mlen = int.from_bytes(s.read(4), "big")
+    meta = json.loads(s.read(mlen).decode("utf-8"))
+    layers = []
+    for _ in range(meta["num_layers"]):
+        bits_len = int.from_bytes(s.read(4), "big")
+        root = int.from_bytes(s.read(4), "big")
+        packed = np.frombuffer(s.read((bits_len + 7) // 8), dtype=np.uint8)
+        st = np.stack([(packed >> 6) & 3, (packed >> 4) & 3, (packed >> 2) & 3, packed & 3], 1).reshape(-1)[: bits_len // 2]
+        clen = int.from_bytes(s.read(4), "big")
+        coeffs = np.frombuffer(zlib.decompress(s.read(clen)), dtype=np.int32)
+        layers.append({"states": st.astype(np.uint8), "root_size": root, "coeffs": coeffs})
+    return meta, layers
+
+
+def decode_image(data):
+    """Jpeg.decompress (jpeg.py:274-297) -> float32 (H, W, 3) in [0, 1]"""
+    meta, layers = parse_ajpg(data)
+    H, W, space = meta["height"], meta["width"], meta["color_space"]
+    qrange, brange = (meta["quality_min"], meta["quality_max"]), (meta["block_size_min"], meta["block_size_max"])
+    _, zz, qm = tables(space, qrange, brange)
+    planes = []
+    for i, (L, (h, w)) in enumerate(zip(layers, layer_shapes(H, W, space))):
+        sizes = decode_leaf_sizes(L["states"].tolist(), L["root_size"])
+        root = root_size(h, w)                     # jpeg.py:425 recomputes it from the layer shape
+        xy = leaf_positions(sizes, root, h, w)
+        leaves = np.concatenate([xy, np.asarray(sizes, np.int32)[:, None]], 1)
+        plane = blocks_decode(L["coeffs"], leaves, qm[i], zz, space, i, h, w)
+        planes.append(upsample_linear(plane, H, W))
+    img = np.stack(planes, axis=2)
+    return color_inverse(space, img.reshape(-1, 3)).reshape(H, W, 3)

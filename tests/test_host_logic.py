@@ -140,3 +140,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("the CPU oracle", "").replace("CPU oracle", ""), os.path.join(dirpath, f)
+
+
+def test_leaf_positions_host_helper(oracle):
+    """aej_leaf_positions_host (host code of the library, Jpeg._block_merge's walk) against the oracle and the encoder's own leaves."""
+    from adaptive_edge_aware_jpeg_amd import _lib
+    lib = _lib.load_library()
+    rng = np.random.default_rng(3)
+    for (h, w, mn, mx) in ((150, 211, 4, 64), (64, 64, 8, 8), (300, 77, 4, 128), (33, 50, 2, 16)):
+        edge = (rng.random((h, w)) < 0.01).astype(np.uint8)
+        leaves, states, root = oracle.quadtree(edge, mn, mx)
+        sizes = np.ascontiguousarray(leaves[:, 2], dtype=np.int32)
+        xy = np.zeros((len(sizes), 2), np.int32)
+        n = lib.aej_leaf_positions_host(sizes.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(sizes)), root, h, w,
+                                        xy.ctypes.data_as(ctypes.c_void_p))
+        assert n == len(sizes) and np.array_equal(xy, leaves[:, :2])
+        assert np.array_equal(oracle.leaf_positions(sizes, root, h, w), leaves[:, :2])

@@ -99,3 +99,35 @@ def test_full_compress_matches_reference_orchestration(oracle, lena):
         for key, ref in m["qm"].items():
             l, s = (int(v) for v in key.split("_"))
             assert qm[l][s].tolist() == ref
+
+
+# ------------------------------------------------------------------ decode path (next-scope row)
+@pytest.mark.parametrize("space", ["YCbCr", "YCoCg", "YCoCg-R", "ICtCp", "ICaCb", "JzAzBz"])
+def test_colour_inverse_bit_exact(oracle, space):
+    g = np.load(os.path.join(GOLDEN, "color_inverse.npz"))
+    assert np.array_equal(oracle.color_inverse(space, g[space + "_in"]), g[space])
+
+
+def test_colour_inverse_oklab(oracle):
+    """np.power(float32, 3) in NumPy's vectorised powf is 1 ulp off x*x*x on some inputs -> 6e-6 after the sRGB curve."""
+    g = np.load(os.path.join(GOLDEN, "color_inverse.npz"))
+    assert np.abs(oracle.color_inverse("OKLAB", g["OKLAB_in"]) - g["OKLAB"]).max() < 2e-5
+
+
+def test_full_decompress_matches_reference_orchestration(oracle):
+    """decode_cases.json holds the sha256 of what the REFERENCE's Jpeg.decompress returned (oracle as its cv2)."""
+    meta = json.load(open(os.path.join(GOLDEN, "decode_cases.json")))
+    crops = np.load(os.path.join(GOLDEN, "decode_cases.npz"))
+    for name, m in meta.items():
+        img = oracle.decode_image(open(os.path.join(GOLDEN, name + ".ajpg"), "rb").read())
+        assert list(img.shape) == m["shape"]
+        assert np.array_equal(img[:64, :64], crops[name])
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == m["sha256"], name
+
+
+def test_round_trip_quality(oracle, lena):
+    x = lena[128:256, 128:256]
+    for sp in ("YCbCr", "OKLAB", "ICtCp", "JzAzBz"):
+        L = oracle.encode_image(x, sp, (40, 80), (4, 64))
+        y = oracle.decode_image(oracle.write_ajpg(L, 128, 128, sp, (40, 80), (4, 64), ".png"))
+        assert 10 * np.log10(1.0 / np.mean((x - y) ** 2)) > 29.0 and not np.isnan(y).any()
