@@ -137,7 +137,7 @@ struct __attribute__((aligned(16))) BlurLds {
     unsigned int A[kAH * kAW4];      // CLAHE image
     unsigned int Bm[kBH * kAW4];     // Gaussian image
     float cw[3][256];                // space weight (radius 1, sqrt 2, 2) x colour weight: the product OpenCV forms per tap
-    unsigned int hist16[16 * 128];   // 16 lane-striped copies of 256 packed 16-bit counters
+    unsigned int hist16[16 * 129];   // 16 lane-striped copies of 256 packed 16-bit counters; odd stride => copies sit in different banks
     int colOff1[kAW], colOff2[kAW];
     float colXa[kAW], colXa1[kAW];
     int rowOff1[kAH], rowOff2[kAH];
@@ -149,7 +149,7 @@ struct __attribute__((aligned(16))) BlurLds {
 // regions would otherwise serialise 64-way); two 16-bit counters per word (a tile has 2048 pixels).
 __device__ __forceinline__ void hist_add(BlurLds &L, int v)
 {
-    atomicAdd(&L.hist16[(threadIdx.x & 15) * 128 + (v >> 1)], 1u << (16 * (v & 1)));
+    atomicAdd(&L.hist16[(threadIdx.x & 15) * 129 + (v >> 1)], 1u << (16 * (v & 1)));
 }
 
 __device__ __forceinline__ unsigned char clahe_px(const BlurLds &L, int v, int r1, int r2, int c1, int c2, float xa, float xa1, float ya, float ya1)
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
         L.cw[1][tid] = cb.space_w[1] * cwv;     // radius sqrt(2)
         L.cw[2][tid] = cb.space_w[0] * cwv;     // radius 2
     }
-    for (int i = tid; i < 16 * 128; i += 256) L.hist16[i] = 0;
+    for (int i = tid; i < 16 * 129; i += 256) L.hist16[i] = 0;
     if (tid >= 128 && tid < 128 + kAH) {      // row parameters of CLAHE_Interpolation_Body: fixed for the strip
         const int j = tid - 128;
         const int gy = reflect101(y0 - 3 + j, h);
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
     __syncthreads();
     unsigned int c = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) c += (L.hist16[k * 128 + (tid >> 1)] >> (16 * (tid & 1))) & 0xffffu;
+    for (int k = 0; k < 16; k++) c += (L.hist16[k * 129 + (tid >> 1)] >> (16 * (tid & 1))) & 0xffffu;
     if (c) atomicAdd(&cb.blur_hist[((long long)b * 3 + l) * 256 + tid], (int)c);
 }
 
