@@ -490,127 +490,145 @@ struct NmsLds {
     int G[kNMH * kNMW];        // dx (low 16 bits) | dy << 16
 };
 
+__device__ __forceinline__ void nms_prefetch(const unsigned char *src, int w, int x0, int y0, unsigned int (&raw)[kNRaw])
+{
+#pragma unroll
+    for (int k = 0; k < kNRaw; k++) {
+        int idx = threadIdx.x + k * 256;
+        if (idx < kNUH * kNW4) {
+            int j = idx / kNW4, i4 = idx - j * kNW4;
+            raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 2 + j) * w + (x0 - 4) + 4 * i4);
+        }
+    }
+}
+
+// workgroup = strip of kStrip tiles of one tile-row; the blurred bytes of the next tile are prefetched into registers while
+// the current tile is processed
 __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
 {
     __shared__ NmsLds L;
     const int tid = threadIdx.x;
     const long long wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles = gridDim.x / g.B;
-    const int b = (int)(wg / tiles);
-    int l, tx, ty, ntx, nty, tbase;
-    if (!locate_tile(g, kBlurTW, kBlurTH, (int)(wg - (long long)b * tiles), l, tx, ty, ntx, nty, tbase)) return;
+    const int strips = gridDim.x / g.B;
+    const int b = (int)(wg / strips);
+    int l, sx, ty;
+    if (!locate_strip(g, (int)(wg - (long long)b * strips), l, sx, ty)) return;
     const int w = g.w[l], h = g.h[l];
-    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
+    const int ntx = cdiv(w, kBlurTW);
+    const int y0 = ty * kBlurTH;
+    const int tx_begin = sx * kStrip, tx_end = min(ntx, tx_begin + kStrip);
     const long long pbase = (long long)b * g.pstride + g.poff[l];
     const unsigned char *src = cb.u8b + pbase;
     const int low = cb.thr[((long long)b * 3 + l) * 2], high = cb.thr[((long long)b * 3 + l) * 2 + 1];
-    const bool aligned = x0 >= 4 && y0 >= 2 && x0 + kBlurTW + 4 <= w && y0 + kBlurTH + 2 <= h && (w % 4) == 0;
-
-    // ---- stage 0
-    if (aligned) {
-        unsigned int raw[kNRaw];
-#pragma unroll
-        for (int k = 0; k < kNRaw; k++) {
-            int idx = tid + k * 256;
-            if (idx < kNUH * kNW4) {
-                int j = idx / kNW4, i4 = idx - j * kNW4;
-                raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 2 + j) * w + (x0 - 4) + 4 * i4);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kNRaw; k++) {
-            int idx = tid + k * 256;
-            if (idx < kNUH * kNW4) L.U[idx] = raw[k];
-        }
-    } else {
-        unsigned char *U8 = reinterpret_cast<unsigned char *>(L.U);
-        for (int idx = tid; idx < kNUH * kNW4 * 4; idx += 256) {
-            int j = idx / (kNW4 * 4), c = idx - j * (kNW4 * 4);
-            int gx = x0 - 4 + c, gy = y0 - 2 + j;
-            gx = gx < 0 ? 0 : gx >= w ? w - 1 : gx;
-            gy = gy < 0 ? 0 : gy >= h ? h - 1 : gy;
-            U8[idx] = src[(long long)gy * w + gx];
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1: 4 pixels per item; rows gy = y0-1+jm, columns gx = x0-4+4*i4 .. +3
-#pragma unroll
-    for (int k = 0; k < (kNMH * kNW4 + 255) / 256; k++) {
-        const int idx = tid + k * 256;
-        if (idx < kNMH * kNW4) {
-            const int jm = idx / kNW4, i4 = idx - jm * kNW4;
-            const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kNW4 - 1 ? i4 + 1 : kNW4 - 1;   // edge dwords feed unused columns only
-            const unsigned int M8 = 0x00FF00FFu;
-            unsigned int he[3], ho[3], vle = 0, vlo = 0, vre = 0, vro = 0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const unsigned int *row = L.U + (jm + r) * kNW4;
-                unsigned int m = row[i4], lf = row[il], rt = row[ir];
-                unsigned int sl = __builtin_amdgcn_alignbyte(m, lf, 3);    // columns -1, 0, 1, 2
-                unsigned int sr = __builtin_amdgcn_alignbyte(rt, m, 1);    // columns  1, 2, 3, 4
-                he[r] = (sl & M8) + 2u * (m & M8) + (sr & M8);             // horizontal [1 2 1] at columns 0, 2
-                ho[r] = ((sl >> 8) & M8) + 2u * ((m >> 8) & M8) + ((sr >> 8) & M8);   // columns 1, 3
-                const unsigned int wgt = r == 1 ? 2u : 1u;                 // vertical [1 2 1]
-                vle += wgt * (sl & M8);  vlo += wgt * ((sl >> 8) & M8);    // columns (-1, 1), (0, 2)
-                vre += wgt * (sr & M8);  vro += wgt * ((sr >> 8) & M8);    // columns ( 1, 3), (2, 4)
-            }
-            int dx[4], dy[4];
-            dx[0] = (int)(vre & 0xffffu) - (int)(vle & 0xffffu);
-            dx[1] = (int)(vro & 0xffffu) - (int)(vlo & 0xffffu);
-            dx[2] = (int)(vre >> 16) - (int)(vle >> 16);
-            dx[3] = (int)(vro >> 16) - (int)(vlo >> 16);
-            dy[0] = (int)(he[2] & 0xffffu) - (int)(he[0] & 0xffffu);
-            dy[1] = (int)(ho[2] & 0xffffu) - (int)(ho[0] & 0xffffu);
-            dy[2] = (int)(he[2] >> 16) - (int)(he[0] >> 16);
-            dy[3] = (int)(ho[2] >> 16) - (int)(ho[0] >> 16);
-            const int gy = y0 - 1 + jm;
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const int gx = x0 - 4 + 4 * i4 + p;
-                int m = dx[p] * dx[p] + dy[p] * dy[p];
-                if (!aligned && (gx < 0 || gx >= w || gy < 0 || gy >= h)) m = 0;      // magnitude outside the image is 0
-                L.M[jm * kNMW + 4 * i4 + p] = m;
-                L.G[jm * kNMW + 4 * i4 + p] = (dx[p] & 0xffff) | (dy[p] << 16);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 2: NMS, one wave per 64-pixel row segment
     unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
     unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
-    const int i = tid & 63;
-#pragma unroll 2
-    for (int j = tid >> 6; j < kBlurTH; j += 4) {
-        const int gx = x0 + i, gy = y0 + j;
-        int res = 1;
-        if (gx < w && gy < h) {
-            const int *ma = L.M + (j + 1) * kNMW + (i + 4), *mp = ma - kNMW, *mn = ma + kNMW;
-            int m = *ma;
-            if (m > low) {
-                const int gd = L.G[(j + 1) * kNMW + (i + 4)];
-                int xs = (int)(short)(gd & 0xffff), ys = gd >> 16;
-                int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << 15;
-                int tg22x = ax * 13573;
-                bool keep;
-                if (ay < tg22x) keep = (m > ma[-1] && m >= ma[1]);
-                else {
-                    int tg67x = tg22x + (ax << 16);
-                    if (ay > tg67x) keep = (m > mp[0] && m >= mn[0]);
-                    else {
-                        int s = ((xs ^ ys) < 0) ? -1 : 1;
-                        keep = (m > mp[-s] && m > mn[s]);
-                    }
-                }
-                if (keep) res = (m > high) ? 2 : 0;
+    auto is_aligned = [&](int tx) {
+        int x0 = tx * kBlurTW;
+        return x0 >= 4 && y0 >= 2 && x0 + kBlurTW + 4 <= w && y0 + kBlurTH + 2 <= h && (w % 4) == 0;
+    };
+    unsigned int raw[kNRaw];
+    if (is_aligned(tx_begin)) nms_prefetch(src, w, tx_begin * kBlurTW, y0, raw);
+
+    for (int tx = tx_begin; tx < tx_end; tx++) {
+        const int x0 = tx * kBlurTW;
+        const bool aligned = is_aligned(tx);
+        // ---- stage 0 (the previous tile's stage 2 reads only M / G, its stage 1 finished before the barrier below it)
+        if (aligned) {
+#pragma unroll
+            for (int k = 0; k < kNRaw; k++) {
+                int idx = tid + k * 256;
+                if (idx < kNUH * kNW4) L.U[idx] = raw[k];
+            }
+        } else {
+            unsigned char *U8 = reinterpret_cast<unsigned char *>(L.U);
+            for (int idx = tid; idx < kNUH * kNW4 * 4; idx += 256) {
+                int j = idx / (kNW4 * 4), c = idx - j * (kNW4 * 4);
+                int gx = x0 - 4 + c, gy = y0 - 2 + j;
+                gx = gx < 0 ? 0 : gx >= w ? w - 1 : gx;
+                gy = gy < 0 ? 0 : gy >= h ? h - 1 : gy;
+                U8[idx] = src[(long long)gy * w + gx];
             }
         }
-        unsigned long long wmask = __ballot(res == 0), smask = __ballot(res == 2);
-        if (i == 0 && gy < h) {
-            wk[bp_index(gy, tx, g.wpr[l])] = wmask;
-            sg[bp_index(gy, tx, g.wpr[l])] = smask;
+        __syncthreads();
+        if (tx + 1 < tx_end && is_aligned(tx + 1)) nms_prefetch(src, w, (tx + 1) * kBlurTW, y0, raw);
+
+        // ---- stage 1: 4 pixels per item; rows gy = y0-1+jm, columns gx = x0-4+4*i4 .. +3
+#pragma unroll
+        for (int k = 0; k < (kNMH * kNW4 + 255) / 256; k++) {
+            const int idx = tid + k * 256;
+            if (idx < kNMH * kNW4) {
+                const int jm = idx / kNW4, i4 = idx - jm * kNW4;
+                const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kNW4 - 1 ? i4 + 1 : kNW4 - 1;   // edge dwords feed unused columns only
+                const unsigned int M8 = 0x00FF00FFu;
+                unsigned int he[3], ho[3], vle = 0, vlo = 0, vre = 0, vro = 0;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const unsigned int *row = L.U + (jm + r) * kNW4;
+                    unsigned int m = row[i4], lf = row[il], rt = row[ir];
+                    unsigned int sl = __builtin_amdgcn_alignbyte(m, lf, 3);    // columns -1, 0, 1, 2
+                    unsigned int sr = __builtin_amdgcn_alignbyte(rt, m, 1);    // columns  1, 2, 3, 4
+                    he[r] = (sl & M8) + 2u * (m & M8) + (sr & M8);             // horizontal [1 2 1] at columns 0, 2
+                    ho[r] = ((sl >> 8) & M8) + 2u * ((m >> 8) & M8) + ((sr >> 8) & M8);   // columns 1, 3
+                    const unsigned int wgt = r == 1 ? 2u : 1u;                 // vertical [1 2 1]
+                    vle += wgt * (sl & M8);  vlo += wgt * ((sl >> 8) & M8);    // columns (-1, 1), (0, 2)
+                    vre += wgt * (sr & M8);  vro += wgt * ((sr >> 8) & M8);    // columns ( 1, 3), (2, 4)
+                }
+                int dx[4], dy[4];
+                dx[0] = (int)(vre & 0xffffu) - (int)(vle & 0xffffu);
+                dx[1] = (int)(vro & 0xffffu) - (int)(vlo & 0xffffu);
+                dx[2] = (int)(vre >> 16) - (int)(vle >> 16);
+                dx[3] = (int)(vro >> 16) - (int)(vlo >> 16);
+                dy[0] = (int)(he[2] & 0xffffu) - (int)(he[0] & 0xffffu);
+                dy[1] = (int)(ho[2] & 0xffffu) - (int)(ho[0] & 0xffffu);
+                dy[2] = (int)(he[2] >> 16) - (int)(he[0] >> 16);
+                dy[3] = (int)(ho[2] >> 16) - (int)(ho[0] >> 16);
+                const int gy = y0 - 1 + jm;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int gx = x0 - 4 + 4 * i4 + p;
+                    int m = dx[p] * dx[p] + dy[p] * dy[p];
+                    if (!aligned && (gx < 0 || gx >= w || gy < 0 || gy >= h)) m = 0;      // magnitude outside the image is 0
+                    L.M[jm * kNMW + 4 * i4 + p] = m;
+                    L.G[jm * kNMW + 4 * i4 + p] = (dx[p] & 0xffff) | (dy[p] << 16);
+                }
+            }
         }
+        __syncthreads();
+
+        // ---- stage 2: NMS, one wave per 64-pixel row segment
+        const int i = tid & 63;
+#pragma unroll 2
+        for (int j = tid >> 6; j < kBlurTH; j += 4) {
+            const int gx = x0 + i, gy = y0 + j;
+            int res = 1;
+            if (gx < w && gy < h) {
+                const int *ma = L.M + (j + 1) * kNMW + (i + 4), *mp = ma - kNMW, *mn = ma + kNMW;
+                int m = *ma;
+                if (m > low) {
+                    const int gd = L.G[(j + 1) * kNMW + (i + 4)];
+                    int xs = (int)(short)(gd & 0xffff), ys = gd >> 16;
+                    int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << 15;
+                    int tg22x = ax * 13573;
+                    bool keep;
+                    if (ay < tg22x) keep = (m > ma[-1] && m >= ma[1]);
+                    else {
+                        int tg67x = tg22x + (ax << 16);
+                        if (ay > tg67x) keep = (m > mp[0] && m >= mn[0]);
+                        else {
+                            int s = ((xs ^ ys) < 0) ? -1 : 1;
+                            keep = (m > mp[-s] && m > mn[s]);
+                        }
+                    }
+                    if (keep) res = (m > high) ? 2 : 0;
+                }
+            }
+            unsigned long long wmask = __ballot(res == 0), smask = __ballot(res == 2);
+            if (i == 0 && gy < h) {
+                wk[bp_index(gy, tx, g.wpr[l])] = wmask;
+                sg[bp_index(gy, tx, g.wpr[l])] = smask;
+            }
+        }
+        __syncthreads();       // M / G are rewritten by the next tile's stage 1
     }
 }
 
@@ -801,7 +819,11 @@ void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
-    long long t = tiles_per_image(g, kBlurTW, kBlurTH);
+    long long t = 0;
+    for (int l = 0; l < g.nl; l++) {
+        int ntx = (g.w[l] + kBlurTW - 1) / kBlurTW, nty = (g.h[l] + kBlurTH - 1) / kBlurTH;
+        t += (long long)((ntx + kStrip - 1) / kStrip) * nty;
+    }
     hipLaunchKernelGGL(k_sobel_nms, dim3((unsigned)(t * g.B)), dim3(256), 0, st, g, cb);
 }
 

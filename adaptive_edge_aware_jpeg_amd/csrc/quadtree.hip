@@ -57,20 +57,37 @@ __device__ __forceinline__ ChunkEdges chunk_edges(const Geom &g, const QtGeom &q
     const unsigned long long *src = edge_bits + (long long)b * g.bpstride + g.bpoff[l];
     ChunkEdges E;
     E.e0 = 0;
+    if (cell == 4 && ncell >= 16) {
+        // fast path (min block 4): the chunk is one 64x64 bit-plane tile = 64 contiguous words; this lane's four cells are the
+        // 8x8-pixel square at rows 8*ly.., bits 8*lx..: eight word loads issued together, then nibble tests
+        const int X0 = ccx * 64, Y0 = ccy * 64;
+        if (X0 < w && Y0 < h) {
+            const unsigned long long *tile = src + bp_index(Y0, X0 >> 6, wpr);
+            unsigned rows[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int cx = ccx * 16 + lx * 2 + (i & 1), cy = ccy * 16 + ly * 2 + (i >> 1);
-        if (cx < ncell && cy < ncell && cx * cell < w && cy * cell < h) {
-            int x0 = cx * cell, y0 = cy * cell;
-            int x1 = min(x0 + cell, w), y1 = min(y0 + cell, h);
-            bool e = false;
-            for (int y = y0; y < y1; y++)
-                for (int xw = x0 >> 6; xw <= (x1 - 1) >> 6; xw++) {
-                    int lo = max(x0, xw * 64) - xw * 64, hi = min(x1, xw * 64 + 64) - xw * 64;
-                    unsigned long long mask = (hi - lo == 64) ? ~0ull : (((1ull << (hi - lo)) - 1ull) << lo);
-                    e |= (src[bp_index(y, xw, wpr)] & mask) != 0;
-                }
-            E.e0 |= (e ? 1u : 0u) << i;
+            for (int r = 0; r < 8; r++) {
+                const int y = Y0 + 8 * ly + r;
+                rows[r] = y < h ? (unsigned)((tile[8 * ly + r] >> (8 * lx)) & 0xFFull) : 0u;
+            }
+            const unsigned top = rows[0] | rows[1] | rows[2] | rows[3], bot = rows[4] | rows[5] | rows[6] | rows[7];
+            E.e0 = ((top & 0x0Fu) ? 1u : 0u) | ((top & 0xF0u) ? 2u : 0u) | ((bot & 0x0Fu) ? 4u : 0u) | ((bot & 0xF0u) ? 8u : 0u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cx = ccx * 16 + lx * 2 + (i & 1), cy = ccy * 16 + ly * 2 + (i >> 1);
+            if (cx < ncell && cy < ncell && cx * cell < w && cy * cell < h) {
+                int x0 = cx * cell, y0 = cy * cell;
+                int x1 = min(x0 + cell, w), y1 = min(y0 + cell, h);
+                bool e = false;
+                for (int y = y0; y < y1; y++)
+                    for (int xw = x0 >> 6; xw <= (x1 - 1) >> 6; xw++) {
+                        int lo = max(x0, xw * 64) - xw * 64, hi = min(x1, xw * 64 + 64) - xw * 64;
+                        unsigned long long mask = (hi - lo == 64) ? ~0ull : (((1ull << (hi - lo)) - 1ull) << lo);
+                        e |= (src[bp_index(y, xw, wpr)] & mask) != 0;
+                    }
+                E.e0 |= (e ? 1u : 0u) << i;
+            }
         }
     }
     E.e1 = E.e0 != 0;
