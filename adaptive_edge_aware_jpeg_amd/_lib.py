@@ -45,6 +45,7 @@ SIGNATURES = {
     "aej_last_error": (ctypes.c_char_p, [_P]),
     "aej_synchronize": (_I, [_P]),
     "aej_last_hysteresis_passes": (_I, [_P]),
+    "aej_set_hysteresis_hint": (_I, [_P, _I, _I]),
     "aej_set_profiling": (_I, [_P, _I]),
     "aej_get_stage_ms": (_I, [_P, _P]),
     "aej_stage_name": (ctypes.c_char_p, [_I]),

@@ -28,6 +28,9 @@ struct aej_ctx {
     const float *d_space_w = nullptr, *d_color_w = nullptr;
     int *h_flag = nullptr;             // pinned host word for counter read-backs
     int last_hyst_passes = 0;
+    int hyst_hint = 0;                 // passes the previous encode needed (speculative enqueue, verified at the end of the call)
+    int hyst_margin = 8;               // extra passes enqueued on top of the hint
+    int hyst_enqueued = 0;             // passes enqueued speculatively by the current call (0 = verified path)
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;
     hipEvent_t ev[24] = {};
@@ -290,7 +293,7 @@ extern "C" aej_ctx *aej_create(int device, void *hip_stream)
     aej_ctx *ctx = new aej_ctx();
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -424,12 +427,24 @@ static int ensure_canny_tables(aej_ctx *ctx)
 }
 
 // ---- Canny chain on a prepared uint8 buffer (cb.u8a) ------------------------------------------------------
-static int run_hysteresis(aej_ctx *ctx, const Geom &g, CannyWs &w)
+// Hysteresis passes.  Verified mode: groups of 8 passes, one counter read-back per group until a pass queues nothing.
+// Speculative mode (whole-path encode, after a first call): enqueue as many passes as the previous call needed plus a
+// margin WITHOUT reading anything back -- a pass whose work list is empty is a ~2 us no-op -- and let the caller verify
+// pass_count[n] == 0 together with its final synchronisation (finish_hysteresis).
+static int run_hysteresis(aej_ctx *ctx, const Geom &g, CannyWs &w, bool speculate = false, int first_pass = 0)
 {
     hipStream_t st = ctx->stream;
-    // groups of passes, one counter read-back per group; a pass with an empty work list is a ~5 us no-op
     const int group = 8;
-    int pass = 0;
+    int pass = first_pass;
+    ctx->hyst_enqueued = 0;
+    if (speculate && ctx->hyst_hint > 0 && first_pass == 0) {
+        int n = ctx->hyst_hint + ctx->hyst_margin;
+        if (n > kMaxHystPasses - group) n = kMaxHystPasses - group;
+        for (int i = 0; i < n; i++) launch_hyst_pass(st, g, w.cb, pass++);
+        ctx->hyst_enqueued = n;
+        ctx->last_hyst_passes = n;
+        return 0;
+    }
     for (;;) {
         for (int i = 0; i < group; i++) launch_hyst_pass(st, g, w.cb, pass++);
         AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.cb.pass_count + pass, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -438,10 +453,11 @@ static int run_hysteresis(aej_ctx *ctx, const Geom &g, CannyWs &w)
         if (pass + group > kMaxHystPasses) return fail(ctx, AEJ_ERR_STATE, "hysteresis did not converge in %d passes", pass);
     }
     ctx->last_hyst_passes = pass;
+    ctx->hyst_hint = pass;
     return 0;
 }
 
-static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w)
+static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool speculate)
 {
     hipStream_t st = ctx->stream;
     launch_clahe_pad_hist(st, g, w.cb);
@@ -453,7 +469,7 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w)
     mark(ctx, AEJ_STAGE_THRESHOLDS);
     launch_sobel_nms(st, g, w.cb);
     mark(ctx, AEJ_STAGE_SOBEL_NMS);
-    int rc = run_hysteresis(ctx, g, w);
+    int rc = run_hysteresis(ctx, g, w, speculate);
     if (rc) return rc;
     mark(ctx, AEJ_STAGE_HYSTERESIS);
     AEJ_HIP_CHECK(hipGetLastError());
@@ -626,29 +642,46 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
 
     if ((rc = run_color_planes(ctx, rgb, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs))) return rc;
     mark(ctx, AEJ_STAGE_COLOR_PLANES);
-    if ((rc = run_canny_chain(ctx, g, w.canny))) return rc;
+    if ((rc = run_canny_chain(ctx, g, w.canny, true))) return rc;
 
     w.qt.qb.leaves = leaves;
     w.qt.qb.states = states;
     w.qt.qb.counts = reinterpret_cast<long long *>(counts);
-    if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
-    mark(ctx, AEJ_STAGE_QUADTREE);
-
-    int k = 0;
-    for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
-        DctArgs a;
-        a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
-        a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
-        a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
-        for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
-        launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k]);
-        mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
+    for (int attempt = 0;; attempt++) {
+        if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
+        mark(ctx, AEJ_STAGE_QUADTREE);
+        int k = 0;
+        for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
+            DctArgs a;
+            a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
+            a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
+            a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
+            for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
+            launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k]);
+            mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
+        }
+        AEJ_HIP_CHECK(hipGetLastError());
+        // one read-back for the whole call: the overflow flag and, when the hysteresis passes were enqueued speculatively,
+        // their work-list counters
+        const int n = ctx->hyst_enqueued;
+        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qt.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (n > 0) AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag + 1, w.canny.cb.pass_count, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+        AEJ_HIP_CHECK(hipStreamSynchronize(st));
+        if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
+        if (n == 0) break;
+        const int *pc = ctx->h_flag + 1;
+        if (pc[n] == 0) {                       // converged within the speculative passes: remember how many were needed
+            int used = n;
+            while (used > 1 && pc[used - 1] == 0) used--;
+            ctx->hyst_hint = used;
+            ctx->last_hyst_passes = used;
+            break;
+        }
+        // rare: the edge map was not at its fix-point when the quadtree ran -- finish the hysteresis, redo what follows
+        if (attempt > 0) return fail(ctx, AEJ_ERR_STATE, "hysteresis verification failed twice");
+        if ((rc = run_hysteresis(ctx, g, w.canny, false, n))) return rc;
     }
-    AEJ_HIP_CHECK(hipGetLastError());
-    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qt.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-    AEJ_HIP_CHECK(hipStreamSynchronize(st));
     if (ctx->profiling) collect_marks(ctx);
-    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
     return 0;
 }
 
@@ -935,6 +968,14 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
 }
 
 extern "C" int aej_last_hysteresis_passes(aej_ctx *ctx) { return ctx ? ctx->last_hyst_passes : -1; }
+
+extern "C" int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin)
+{
+    if (!ctx || passes < 0 || margin < 0) return AEJ_ERR_ARG;
+    ctx->hyst_hint = passes;       // 0 = next whole-path call runs in verified mode
+    ctx->hyst_margin = margin;
+    return 0;
+}
 
 extern "C" int aej_set_profiling(aej_ctx *ctx, int enable)
 {

@@ -81,6 +81,10 @@ enum {
     AEJ_STAGE_SOBEL_NMS, AEJ_STAGE_HYSTERESIS, AEJ_STAGE_QUADTREE, AEJ_STAGE_DCT_2, AEJ_STAGE_DCT_4, AEJ_STAGE_DCT_8,
     AEJ_STAGE_DCT_16, AEJ_STAGE_DCT_32, AEJ_STAGE_DCT_64, AEJ_STAGE_DCT_128, AEJ_N_STAGES
 };
+/* Diagnostic: aej_encode_batch enqueues (passes + margin) hysteresis passes without reading back and verifies convergence
+ * with its final synchronisation (falling back to the verified loop and redoing quadtree + DCT when they were too few).
+ * `passes` is normally learnt from the previous call; 0 forces the verified mode for the next call. */
+AEJ_API int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin);
 AEJ_API int aej_set_profiling(aej_ctx *ctx, int enable);
 AEJ_API int aej_get_stage_ms(aej_ctx *ctx, float *ms_host /* [AEJ_N_STAGES] */);
 AEJ_API const char *aej_stage_name(int stage);

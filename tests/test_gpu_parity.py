@@ -129,6 +129,32 @@ def test_hysteresis_long_chain(A, oracle):
     assert np.array_equal(got, oracle.edge_pipeline(plane))
 
 
+def test_speculative_hysteresis_falls_back_when_the_hint_is_too_small(A, ctx, oracle):
+    """aej_encode_batch enqueues as many hysteresis passes as the previous call needed (+ margin) without reading back and
+    verifies at the end; when they were too few it must finish the hysteresis and redo quadtree + DCT."""
+    H, W = 540, 960
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    img = synth(oracle, H, W, 20250718)
+    ref = oracle.encode_image(img, "YCbCr", (40, 80), (4, 64))
+    try:
+        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 0, 8))       # verified mode
+        codec.compress_batch(img[None])
+        need = ctx.lib.aej_last_hysteresis_passes(ctx.handle)
+        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))       # speculate with ONE pass: too few unless need == 1
+        enc = codec.compress_batch(img[None])
+        for l in range(3):
+            got = enc.layer(0, l)
+            assert np.array_equal(got["states"], ref[l]["states"]) and np.array_equal(got["leaves"], ref[l]["leaves"])
+            assert np.array_equal(got["coeffs"], ref[l]["coeffs"])
+        assert need > 1, "test image must need more than one hysteresis pass"
+        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, need, 8))    # enough passes: speculative path, same result
+        again = codec.compress_batch(img[None])
+        for l in range(3):
+            assert np.array_equal(again.layer(0, l)["coeffs"], ref[l]["coeffs"])
+    finally:
+        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 0, 8))
+
+
 # ------------------------------------------------------------------ a-9/a-10 quadtree
 def test_quadtree_reference_golden_cases(A):
     g = np.load(os.path.join(GOLDEN, "quadtree_cases.npz"))
