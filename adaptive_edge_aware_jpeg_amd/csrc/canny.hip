@@ -674,28 +674,24 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
         const unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
         const int y = ty * 64 + lane;
         const bool valid = y < h;
-        // tile-major layout: this tile's 64 row-words are contiguous; the left / right tiles are +-64 words away
+        // tile-major layout: this tile's 64 row-words are contiguous; the left / right tiles are +-64 words away.
+        // All ten loads are unconditional (addresses clamped into the plane, results masked afterwards) so that they are in
+        // flight together: a wave pays one memory latency per tile instead of one per halo piece.
+        const int yc = valid ? y : h - 1;
+        const int xl = tx > 0 ? tx - 1 : 0, xr = tx + 1 < wpr ? tx + 1 : wpr - 1;
+        const int yt = ty > 0 ? ty * 64 - 1 : 0, yb = ty * 64 + 64 < h ? ty * 64 + 64 : h - 1;
         const long long o = bp_index(ty * 64, tx, wpr) + lane;
-        unsigned long long S = 0, W = 0, SL = 0, SR = 0;
-        if (valid) {
-            S = sg[o]; W = wk[o];
-            if (tx > 0) SL = sg[o - 64] >> 63;
-            if (tx + 1 < wpr) SR = sg[o + 64] & 1ull;
-        }
-        // halo rows above / below the tile (wave-uniform addresses)
-        unsigned long long Tm = 0, Tl = 0, Tr = 0, Bm = 0, Bl = 0, Br = 0;
-        if (ty > 0) {
-            const long long ot = bp_index(ty * 64 - 1, tx, wpr);
-            Tm = sg[ot];
-            if (tx > 0) Tl = sg[ot - 64] >> 63;
-            if (tx + 1 < wpr) Tr = sg[ot + 64] & 1ull;
-        }
-        if (ty * 64 + 64 < h) {
-            const long long ob = bp_index(ty * 64 + 64, tx, wpr);
-            Bm = sg[ob];
-            if (tx > 0) Bl = sg[ob - 64] >> 63;
-            if (tx + 1 < wpr) Br = sg[ob + 64] & 1ull;
-        }
+        unsigned long long S = sg[bp_index(yc, tx, wpr)], W = wk[bp_index(yc, tx, wpr)];
+        unsigned long long SLw = sg[bp_index(yc, xl, wpr)], SRw = sg[bp_index(yc, xr, wpr)];
+        unsigned long long Tm = sg[bp_index(yt, tx, wpr)], Tlw = sg[bp_index(yt, xl, wpr)], Trw = sg[bp_index(yt, xr, wpr)];
+        unsigned long long Bm = sg[bp_index(yb, tx, wpr)], Blw = sg[bp_index(yb, xl, wpr)], Brw = sg[bp_index(yb, xr, wpr)];
+        if (!valid) { S = 0; W = 0; SLw = 0; SRw = 0; }
+        const bool hasL = tx > 0, hasR = tx + 1 < wpr, hasT = ty > 0, hasB = ty * 64 + 64 < h;
+        unsigned long long SL = hasL ? SLw >> 63 : 0ull, SR = hasR ? SRw & 1ull : 0ull;
+        unsigned long long Tl = (hasT && hasL) ? Tlw >> 63 : 0ull, Tr = (hasT && hasR) ? Trw & 1ull : 0ull;
+        unsigned long long Bl = (hasB && hasL) ? Blw >> 63 : 0ull, Br = (hasB && hasR) ? Brw & 1ull : 0ull;
+        if (!hasT) Tm = 0;
+        if (!hasB) Bm = 0;
         const unsigned long long S0 = S;
         for (;;) {
             unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
