@@ -208,17 +208,44 @@ struct MfmaCfg {
     static constexpr int MINW = S == 32 ? 4 : S == 64 ? 3 : 2;   // waves per SIMD the register budget is sized for
 };
 
+// X -> LDS by LDS-DMA (no VGPR staging): full leaves 1 KiB (256 floats) per wave instruction, clipped or unaligned ones one
+// dword per lane with the np.pad(reflect) index map applied to the source address
+template <int S, int NWAVES>
+__device__ __forceinline__ void dct_load_x(const float *src, int w, int h, const int4 &d, float *sX, int wave, int lane)
+{
+    constexpr int SS = S * S;
+    const int hc = min(S, h - d.z), wc = min(S, w - d.y);
+    if (hc == S && wc == S && (w & 3) == 0) {
+        constexpr int ROWS = 256 / S;                 // rows per wave instruction
+#pragma unroll
+        for (int t = 0; t < SS / 256 / NWAVES; t++) {
+            const int chunk = t * NWAVES + wave;
+            const int r = chunk * ROWS + lane / (S / 4), c = (lane % (S / 4)) * 4;
+            glds16(src + (long long)(d.z + r) * w + d.y + c, sX + chunk * 256);
+        }
+    } else {
+#pragma unroll 4
+        for (int t = 0; t < SS / 64 / NWAVES; t++) {
+            const int chunk = t * NWAVES + wave;
+            const int idx = chunk * 64 + lane;
+            const int r = idx / S, c = idx - r * S;
+            glds4(src + (long long)(d.z + reflect_pad_idx(r, hc)) * w + d.y + reflect_pad_idx(c, wc), sX + chunk * 64);
+        }
+    }
+}
+
 template <int S, bool WANT_DCT>
 __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
 {
     using C = MfmaCfg<S>;
     constexpr int NT = C::NT, TPW = C::TPW, NWAVES = C::NWAVES, NTHREADS = C::NTHREADS;
     constexpr int SS = S * S;
+    constexpr int NXB = S == 64 ? 2 : 1;          // X double-buffered (next leaf prefetched by LDS-DMA): pays only for 64x64 leaves
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sX = smem;            // [S][S]  X, later reused as int staging for the zigzag scatter
-    float *sP = smem + SS;       // [S][S]  P = T^T
-    LayerTab &lt = *reinterpret_cast<LayerTab *>(smem + 2 * SS);
-    int *s_pref = reinterpret_cast<int *>(smem + 2 * SS) + (sizeof(LayerTab) + 3) / 4;   // [nplanes + 1]
+    float *sXb = smem;                 // [NXB][S][S]  X, the current one later reused as int staging for the zigzag scatter
+    float *sP = smem + NXB * SS;       // [S][S]  P = T^T
+    LayerTab &lt = *reinterpret_cast<LayerTab *>(smem + (NXB + 1) * SS);
+    int *s_pref = reinterpret_cast<int *>(smem + (NXB + 1) * SS) + (sizeof(LayerTab) + 3) / 4;   // [nplanes + 1]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wj = wave % NT, wi0 = wave / NT;       // tile column; first tile row (the others are wi0 + t * NT / TPW)
@@ -234,39 +261,30 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
     long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
     const long long wstride = q.work_stride[a.k];
+    const long long step = gridDim.x;
     long long item = blockIdx.x;
-    int4 wk = make_int4(0, 0, 0, 0);
-    if (item < count) wk = fetch_item(a, wstride, lt, s_pref, item);
-    for (; item < count; item += gridDim.x) {
-        const int4 cur = wk;
+    int4 cur = make_int4(0, 0, 0, 0), nxt = make_int4(0, 0, 0, 0);
+    if (item < count) cur = fetch_item(a, wstride, lt, s_pref, item);
+    if (item + step < count) nxt = fetch_item(a, wstride, lt, s_pref, item + step);
+    int pb = 0;
+    if (NXB == 2 && item < count) {
+        const int b0 = cur.x / 3, l0 = cur.x - b0 * 3;
+        dct_load_x<S, NWAVES>(a.norm + (long long)b0 * g.pstride + lt.poff[l0], lt.w[l0], lt.h[l0], cur, sXb, wave, lane);
+    }
+    for (; item < count; item += step) {
         const int b = cur.x / 3, layer = cur.x - b * 3;
-        const int w = lt.w[layer], h = lt.h[layer];
-        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
-        const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
         const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
         const int *qm = a.qm[layer];
-
-        // X -> LDS by LDS-DMA (no VGPR staging): full leaves 1 KiB (256 floats) per wave instruction, clipped or
-        // unaligned ones one dword per lane with the np.pad(reflect) index map applied to the source address
-        if (hc == S && wc == S && (w & 3) == 0) {
-            constexpr int ROWS = 256 / S;                 // rows per wave instruction
-#pragma unroll
-            for (int t = 0; t < SS / 256 / NWAVES; t++) {
-                const int chunk = t * NWAVES + wave;
-                const int r = chunk * ROWS + lane / (S / 4), c = (lane % (S / 4)) * 4;
-                glds16(src + (long long)(cur.z + r) * w + cur.y + c, sX + chunk * 256);
-            }
-        } else {
-#pragma unroll 4
-            for (int t = 0; t < SS / 64 / NWAVES; t++) {
-                const int chunk = t * NWAVES + wave;
-                const int idx = chunk * 64 + lane;
-                const int r = idx / S, c = idx - r * S;
-                glds4(src + (long long)(cur.z + reflect_pad_idx(r, hc)) * w + cur.y + reflect_pad_idx(c, wc), sX + chunk * 64);
-            }
+        float *sX = sXb + pb * SS;
+        if (NXB == 1) dct_load_x<S, NWAVES>(a.norm + (long long)b * g.pstride + lt.poff[layer], lt.w[layer], lt.h[layer], cur, sX, wave, lane);
+        __syncthreads();                  // X of this leaf has landed (the barrier drains the LDS-DMA queue)
+        if (NXB == 2 && item + step < count) {
+            // prefetch the next leaf into the other buffer: it lands under this leaf's first MFMA chain
+            const int bn = nxt.x / 3, ln = nxt.x - bn * 3;
+            dct_load_x<S, NWAVES>(a.norm + (long long)bn * g.pstride + lt.poff[ln], lt.w[ln], lt.h[ln], nxt, sXb + (pb ^ 1) * SS, wave, lane);
         }
-        if (item + gridDim.x < count) wk = fetch_item(a, wstride, lt, s_pref, item + gridDim.x);
-        __syncthreads();
+        int4 nn = make_int4(0, 0, 0, 0);
+        if (item + 2 * step < count) nn = fetch_item(a, wstride, lt, s_pref, item + 2 * step);
 
         floatx16 acc[TPW];
 #pragma unroll
@@ -323,7 +341,8 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
         __syncthreads();
         for (int idx = tid * 4; idx < SS; idx += NTHREADS * 4)
             *reinterpret_cast<int4 *>(a.coeffs + out_base + idx) = *reinterpret_cast<const int4 *>(sQ + idx);
-        __syncthreads();
+        if (NXB == 1) __syncthreads();    // single buffer: the next leaf's DMA must not overwrite sQ before it is copied out
+        cur = nxt; nxt = nn; pb ^= (NXB - 1);
     }
 }
 
@@ -355,7 +374,7 @@ void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int
 template <int S, bool WANT_DCT>
 static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, int blocks)
 {
-    size_t lds = (size_t)2 * S * S * sizeof(float) + sizeof(LayerTab) + 8 + (size_t)(a.nplanes + 1) * sizeof(int);
+    size_t lds = (size_t)(S == 64 ? 3 : 2) * S * S * sizeof(float) + sizeof(LayerTab) + 8 + (size_t)(a.nplanes + 1) * sizeof(int);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dct_mfma<S, WANT_DCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
