@@ -197,16 +197,30 @@ __global__ __launch_bounds__(256) void k_color_planes(const float *__restrict__ 
                 v[1] = (((cc[1][0] + cc[1][1]) + cc[1][2]) + cc[1][3]) * 0.25f;
                 cx = px / 4; cy[0] = py; cy[1] = py + 1;
             }
+            if constexpr (RH == 2 && RW == 2) {      // the two outputs are x-neighbours: paired stores (cx is even)
+                long long o = ibase + g.poff[ch] + (long long)cy[0] * g.w[ch] + cx;
+                if (planes_norm)
+                    *reinterpret_cast<float2 *>(planes_norm + o) =
+                        make_float2((v[0] - nc.mid[ch]) * nc.scale[ch], (v[1] - nc.mid[ch]) * nc.scale[ch]);
+                if (planes_raw) *reinterpret_cast<float2 *>(planes_raw + o) = make_float2(v[0], v[1]);
+                uchar2 u;
+                u.x = scale_u8(v[0]); u.y = scale_u8(v[1]);
+                if (planes_u8) *reinterpret_cast<uchar2 *>(planes_u8 + o) = u;
+                if (do_hist) {
+                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, cx / g.ctw[ch], cy[0] / g.cth[ch], u.x);
+                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, (cx + 1) / g.ctw[ch], cy[0] / g.cth[ch], u.y);
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                int x = (RH == 2) ? cx + q : cx;
-                int y = cy[q];
-                long long o = ibase + g.poff[ch] + (long long)y * g.w[ch] + x;
-                if (planes_norm) planes_norm[o] = (v[q] - nc.mid[ch]) * nc.scale[ch];
-                if (planes_raw) planes_raw[o] = v[q];
-                unsigned char u = scale_u8(v[q]);
-                if (planes_u8) planes_u8[o] = u;
-                if (do_hist) hist_add(s_hist, ghist, ch, tx0_c, ty0_c, x / g.ctw[ch], y / g.cth[ch], u);
+                for (int q = 0; q < 2; q++) {
+                    int y = cy[q];
+                    long long o = ibase + g.poff[ch] + (long long)y * g.w[ch] + cx;
+                    if (planes_norm) planes_norm[o] = (v[q] - nc.mid[ch]) * nc.scale[ch];
+                    if (planes_raw) planes_raw[o] = v[q];
+                    unsigned char u = scale_u8(v[q]);
+                    if (planes_u8) planes_u8[o] = u;
+                    if (do_hist) hist_add(s_hist, ghist, ch, tx0_c, ty0_c, cx / g.ctw[ch], y / g.cth[ch], u);
+                }
             }
         }
     }
