@@ -131,25 +131,31 @@ constexpr int kBH = kBlurTH + 4;   // Gauss rows  [y0-2, y0+TH+2)
 __constant__ int c_bil_dy[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
 __constant__ int c_bil_dx[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
 
+constexpr int kBW2 = 2 * kAW4;     // Gaussian row stride in dwords: two pixels per dword (see BlurLds::Bm)
+constexpr int kHistCopies = 12;
+
 struct __attribute__((aligned(16))) BlurLds {
     unsigned char lut[16 * 256];
-    unsigned int R[kAH * kAW4];      // raw uint8 source
-    unsigned int A[kAH * kAW4];      // CLAHE image
-    unsigned int Bm[kBH * kAW4];     // Gaussian image
-    float cw[3][256];                // space weight (radius 1, sqrt 2, 2) x colour weight: the product OpenCV forms per tap
-    unsigned int hist16[16 * 129];   // 16 lane-striped copies of 256 packed 16-bit counters; odd stride => copies sit in different banks
+    unsigned int A[kAH * kAW4];      // CLAHE image, one byte per pixel
+    // Gaussian image, 16 bits per pixel holding 4*value: dword (c >> 1) of a row carries column c in its low (c even) or
+    // high (c odd) half.  The pre-scaled value is at once the byte offset into the weight table and (x4, exact in
+    // float32) the tap value of the bilateral sum.
+    unsigned int Bm[kBH * kBW2];
+    // space weight (radius 1, sqrt 2, 2) x colour weight: the float32 product OpenCV forms per tap, indexed by the SIGNED
+    // difference d + 256 so the filter needs no |d|
+    float cw[3][512];
+    unsigned int hist16[kHistCopies * 129];   // lane-striped copies of 256 packed 16-bit counters; odd stride => copies sit in different banks
     int colOff1[kAW], colOff2[kAW];
     float colXa[kAW], colXa1[kAW];
     int rowOff1[kAH], rowOff2[kAH];
     float rowYa[kAH], rowYa1[kAH];
-    int colSrc[kAW], rowSrc[kAH];    // REFLECT_101-mapped source column / row of every staged column / row
 };
 
 // Per-tile histogram: lane-striped copies keep same-value lanes of a wave off the same LDS word (flat image
 // regions would otherwise serialise 64-way); two 16-bit counters per word (a tile has 2048 pixels).
-__device__ __forceinline__ void hist_add(BlurLds &L, int v)
+__device__ __forceinline__ void hist_add(BlurLds &L, int copy_base, int v)
 {
-    atomicAdd(&L.hist16[(threadIdx.x & 15) * 129 + (v >> 1)], 1u << (16 * (v & 1)));
+    atomicAdd(&L.hist16[copy_base + (v >> 1)], 1u << (16 * (v & 1)));
 }
 
 __device__ __forceinline__ unsigned char clahe_px(const BlurLds &L, int v, int r1, int r2, int c1, int c2, float xa, float xa1, float ya, float ya1)
@@ -168,9 +174,11 @@ __device__ __forceinline__ unsigned char clahe_px(const BlurLds &L, int v, int r
 // 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2).  The weight of tap k is
 // space_w[k] * color_w[|delta|]; space_w takes 3 values (radius 1, sqrt 2, 2), so the float32 products are tabulated once
 // per workgroup (same multiplication, same rounding).  The centre tap has |delta| = 0 and both factors 1.
-__device__ __forceinline__ unsigned char bilateral_px(const BlurLds &L, const int (&v)[13])
+// v4[k] = 4 * tap value.  Scaling every tap by 4 scales each partial sum and the quotient by exactly 4 (powers of two
+// commute with float32 rounding away from the denormal range), so (sum4 / wsum) * 0.25f is bitwise sum / wsum.
+__device__ __forceinline__ unsigned int bilateral_px(const BlurLds &L, const int (&v4)[13])
 {
-    const int v0 = v[6];
+    const int c0 = v4[6] - 1024;         // v4[k] - c0 = 4 * (d + 256): byte offset into cw[t]
     float sum = 0.f, wsum = 0.f;
 #pragma unroll
     for (int k = 0; k < 13; k++) {
@@ -179,39 +187,49 @@ __device__ __forceinline__ unsigned char bilateral_px(const BlurLds &L, const in
             wgt = 1.0f;
         } else {
             const int t = (k == 0 || k == 4 || k == 8 || k == 12) ? 2 : (k == 1 || k == 3 || k == 9 || k == 11) ? 1 : 0;
-            int d = v[k] - v0;
-            d = d < 0 ? -d : d;
-            wgt = L.cw[t][d];
+            wgt = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(L.cw[t]) + (v4[k] - c0));
         }
         wsum = wsum + wgt;
-        sum = __builtin_fmaf((float)v[k], wgt, sum);
+        sum = __builtin_fmaf((float)v4[k], wgt, sum);
     }
-    int r = __float2int_rn(sum / wsum);
-    return (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+    int r = __float2int_rn((sum / wsum) * 0.25f);
+    return (unsigned int)(r < 0 ? 0 : r > 255 ? 255 : r);
 }
 
-// INTERIOR tiles: the whole halo is inside the image -> dword LDS traffic, 4 pixels per thread everywhere.
-// The raw bytes of a tile (38 rows x 18 aligned dwords = 684 dwords, <= 3 per thread) are prefetched into
-// registers one tile ahead by the strip loop, so their HBM latency hides under the previous tile's compute.
+// The raw bytes of a tile (38 rows x 18 dwords = 684 dwords, <= 3 per thread) are fetched into registers one tile
+// ahead by the strip loop, so their HBM latency hides under the previous tile's Gaussian and bilateral stages; the
+// thread that fetched a dword is the one that CLAHE-maps it.  `aligned` tiles (window inside the image, w % 4 == 0)
+// use dword loads; tiles on the image border gather bytes at REFLECT_101-mapped coordinates, which yields the padded
+// CLAHE image the Gaussian needs.
 constexpr int kRawPerThread = (kAH * kAW4 + 255) / 256;
 
-__device__ __forceinline__ void blur_prefetch(const unsigned char *src, int w, int x0, int y0, unsigned int (&raw)[kRawPerThread])
+__device__ __forceinline__ void blur_prefetch(const unsigned char *src, int w, int h, int x0, int y0, bool aligned, unsigned int (&raw)[kRawPerThread])
 {
 #pragma unroll
     for (int k = 0; k < kRawPerThread; k++) {
         int idx = threadIdx.x + k * 256;
         if (idx < kAH * kAW4) {
             int j = idx / kAW4, i4 = idx - j * kAW4;
-            raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 3 + j) * w + (x0 - 4) + 4 * i4);
+            if (aligned) {
+                raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 3 + j) * w + (x0 - 4) + 4 * i4);
+            } else {
+                const unsigned char *row = src + (long long)reflect101(y0 - 3 + j, h) * w;
+                unsigned int v = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) v |= (unsigned int)row[reflect101(x0 - 4 + 4 * i4 + q, w)] << (8 * q);
+                raw[k] = v;
+            }
         }
     }
 }
 
-// One 64x32 tile from the staged raw bytes in L.R.  For tiles that touch the image border the staging (and the
+// One 64x32 tile from the fetched raw bytes in raw[].  For tiles that touch the image border the fetch (and the
 // CLAHE parameter arrays) already hold REFLECT_101-mapped data, i.e. the padded CLAHE image; because the Gaussian
 // kernel is symmetric, Gaussian(pad(A)) at a mirrored position equals the mirrored Gaussian, so the padded Gaussian
 // image the bilateral filter needs comes out of the same code.  `full` = the 64x32 outputs all lie inside the image.
-__device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb, BlurLds &L, int l, int b, int x0, int y0, bool full)
+template <typename NEXT>
+__device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb, BlurLds &L, int l, int b, int x0, int y0, bool full,
+                                          unsigned int (&raw)[kRawPerThread], NEXT &&fetch_next)
 {
     const int tid = threadIdx.x;
     const int w = g.w[l], h = g.h[l];
@@ -222,7 +240,7 @@ __device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb,
         const int idx = tid + kk * 256;
         if (idx >= kAH * kAW4) break;
         int j = idx / kAW4, i4 = idx - j * kAW4;
-        unsigned int rv = L.R[idx];
+        unsigned int rv = raw[kk];
 #if defined(AEJ_ABLATE) && (AEJ_ABLATE == 3 || AEJ_ABLATE == 5)
         L.A[idx] = rv; continue;
 #endif
@@ -236,6 +254,7 @@ __device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb,
         unsigned int o3 = clahe_px(L, rv >> 24, r1, r2, c1.w, c2.w, xa.w, xa1.w, ya, ya1);
         L.A[idx] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
     }
+    fetch_next();          // raw[] is free again: next tile's bytes fly while this tile runs stages B and C
     __syncthreads();
     if (cb.dump_clahe)
         for (int idx = tid; idx < kBlurTH * kBlurTW; idx += 256) {
@@ -251,7 +270,7 @@ __device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb,
         int j = idx / kAW4, i4 = idx - j * kAW4;
         const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kAW4 - 1 ? i4 + 1 : kAW4 - 1;   // edge dwords feed unused columns only
 #if defined(AEJ_ABLATE) && (AEJ_ABLATE == 4 || AEJ_ABLATE == 5)
-        L.Bm[idx] = L.A[(j + 1) * kAW4 + i4]; continue;
+        L.Bm[2 * idx] = L.A[(j + 1) * kAW4 + i4]; continue;
 #endif
         unsigned int he[3], ho[3];
 #pragma unroll
@@ -266,55 +285,61 @@ __device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb,
         }
         unsigned int ve = he[0] + 2u * he[1] + he[2] + 0x00080008u;
         unsigned int vo = ho[0] + 2u * ho[1] + ho[2] + 0x00080008u;
-        L.Bm[idx] = ((ve >> 4) & 0x00FF00FFu) | (((vo >> 4) & 0x00FF00FFu) << 8);
+        const unsigned int e4 = (ve >> 2) & 0x03FC03FCu;     // 4 * pixel 0 | 4 * pixel 2 << 16
+        const unsigned int o4 = (vo >> 2) & 0x03FC03FCu;     // 4 * pixel 1 | 4 * pixel 3 << 16
+        *reinterpret_cast<uint2 *>(&L.Bm[2 * idx]) = make_uint2((e4 & 0xffffu) | (o4 << 16), (e4 >> 16) | (o4 & 0xffff0000u));
     }
     __syncthreads();
     if (cb.dump_gauss)
         for (int idx = tid; idx < kBlurTH * kBlurTW; idx += 256) {
             int j = idx / kBlurTW, i = idx - j * kBlurTW;
             if (x0 + i < w && y0 + j < h)
-                cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] = reinterpret_cast<const unsigned char *>(L.Bm)[(j + 2) * kAW + i + 4];
+                cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] =
+                    (unsigned char)(reinterpret_cast<const unsigned short *>(L.Bm)[(j + 2) * kAW + i + 4] >> 2);
         }
-    // ---- stage C: bilateral, 4 consecutive pixels per thread; 5 rows x 12 bytes of the Gaussian image in registers
+    // ---- stage C: bilateral, 4 consecutive pixels per thread; the window columns 4*c4 + 2 .. 4*c4 + 9 of 5 Gaussian rows
+    // are 4 dwords per row (rows -2 / +2 are only tapped at dx = 0: the middle 2 dwords)
     unsigned char *dst = cb.u8b + pbase;
-    const int c4 = tid & 15;           // output pixels x0 + 4*c4 .. +3  <->  window bytes 2..9 of dwords c4 .. c4+2
+    const int c4 = tid & 15;           // output pixels x0 + 4*c4 .. +3
+    const int hbase = (tid % kHistCopies) * 129;
 #pragma unroll 1
     for (int pass = 0; pass < kBlurTH / 16; pass++) {
         const int j = (tid >> 4) + pass * 16;
-        unsigned int rw[5][3];
+        unsigned int rw[5][4];
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            const unsigned int *p = L.Bm + (j + r) * kAW4 + c4;
-            rw[r][0] = p[0]; rw[r][1] = p[1]; rw[r][2] = p[2];
+            const unsigned int *p = L.Bm + (j + r) * kBW2 + 2 * c4 + 1;
+            if (r == 0 || r == 4) { rw[r][0] = rw[r][3] = 0; rw[r][1] = p[1]; rw[r][2] = p[2]; }
+            else { rw[r][0] = p[0]; rw[r][1] = p[1]; rw[r][2] = p[2]; rw[r][3] = p[3]; }
         }
         unsigned int o[4];
 #pragma unroll
         for (int px = 0; px < 4; px++) {
 #if defined(AEJ_ABLATE) && (AEJ_ABLATE == 2 || AEJ_ABLATE == 5)
-            o[px] = (rw[2][(px + 4) >> 2] >> (8 * ((px + 4) & 3))) & 0xffu; continue;
+            o[px] = ((rw[2][(px + 2) >> 1] >> (16 * (px & 1))) & 0xffffu) >> 2; continue;
 #endif
             constexpr int dys[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
             constexpr int dxs[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
-            int v[13];
+            int v4[13];
 #pragma unroll
             for (int k = 0; k < 13; k++) {
-                const int rr = 2 + dys[k], c = px + 4 + dxs[k];
-                v[k] = (int)((rw[rr][c >> 2] >> (8 * (c & 3))) & 0xffu);
+                const int rr = 2 + dys[k], c = px + 2 + dxs[k];      // column relative to 4*c4 + 2
+                v4[k] = (c & 1) ? (int)(rw[rr][c >> 1] >> 16) : (int)(rw[rr][c >> 1] & 0xffffu);
             }
-            o[px] = bilateral_px(L, v);
+            o[px] = bilateral_px(L, v4);
         }
         if (full) {
             *reinterpret_cast<unsigned int *>(dst + (long long)(y0 + j) * w + x0 + 4 * c4) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
 #if !defined(AEJ_ABLATE) || (AEJ_ABLATE != 1 && AEJ_ABLATE != 5)
 #pragma unroll
-            for (int px = 0; px < 4; px++) hist_add(L, (int)o[px]);
+            for (int px = 0; px < 4; px++) hist_add(L, hbase, (int)o[px]);
 #endif
         } else if (y0 + j < h) {
 #pragma unroll
             for (int px = 0; px < 4; px++)
                 if (x0 + 4 * c4 + px < w) {
                     dst[(long long)(y0 + j) * w + x0 + 4 * c4 + px] = (unsigned char)o[px];
-                    hist_add(L, (int)o[px]);
+                    hist_add(L, hbase, (int)o[px]);
                 }
         }
     }
@@ -333,7 +358,10 @@ __device__ __forceinline__ bool locate_strip(const Geom &g, int t, int &layer, i
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
+#ifndef AEJ_BLUR_OCC
+#define AEJ_BLUR_OCC 5
+#endif
+__global__ __launch_bounds__(256, AEJ_BLUR_OCC) void k_clahe_blur(Geom g, CannyBuffers cb)
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;
@@ -349,13 +377,15 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
     const unsigned char *src = cb.u8a + (long long)b * g.pstride + g.poff[l];
 
     reinterpret_cast<uint4 *>(L.lut)[tid] = reinterpret_cast<const uint4 *>(cb.lut + ((long long)b * 3 + l) * 4096)[tid];
-    {
-        const float cwv = cb.color_w[tid];
-        L.cw[0][tid] = cb.space_w[5] * cwv;     // radius 1
-        L.cw[1][tid] = cb.space_w[1] * cwv;     // radius sqrt(2)
-        L.cw[2][tid] = cb.space_w[0] * cwv;     // radius 2
+#pragma unroll
+    for (int i = tid; i < 512; i += 256) {
+        const int d = i - 256;
+        const float cwv = i == 0 ? 0.f : cb.color_w[d < 0 ? -d : d];     // slot 0 (d = -256) is never addressed
+        L.cw[0][i] = cb.space_w[5] * cwv;       // radius 1
+        L.cw[1][i] = cb.space_w[1] * cwv;       // radius sqrt(2)
+        L.cw[2][i] = cb.space_w[0] * cwv;       // radius 2
     }
-    for (int i = tid; i < 16 * 129; i += 256) L.hist16[i] = 0;
+    for (int i = tid; i < kHistCopies * 129; i += 256) L.hist16[i] = 0;
     if (tid >= 128 && tid < 128 + kAH) {      // row parameters of CLAHE_Interpolation_Body: fixed for the strip
         const int j = tid - 128;
         const int gy = reflect101(y0 - 3 + j, h);
@@ -367,7 +397,6 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
         if (ty1 < 0) ty1 = 0;
         if (ty2 > 3) ty2 = 3;
         L.rowOff1[j] = ty1 * 1024; L.rowOff2[j] = ty2 * 1024;
-        L.rowSrc[j] = gy;
     }
     // a tile is "aligned" when its staged window [x0-4, x0+68) x [y0-3, y0+35) lies inside the image: dword prefetch
     auto is_aligned = [&](int tx) {
@@ -375,11 +404,10 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
         return x0 >= 4 && y0 >= 3 && x0 + kBlurTW + 4 <= w && y0 + kBlurTH + 3 <= h && (w % 4) == 0;
     };
     unsigned int raw[kRawPerThread];
-    if (is_aligned(tx_begin)) blur_prefetch(src, w, tx_begin * kBlurTW, y0, raw);
+    blur_prefetch(src, w, h, tx_begin * kBlurTW, y0, is_aligned(tx_begin), raw);
 
     for (int tx = tx_begin; tx < tx_end; tx++) {
         const int x0 = tx * kBlurTW;
-        const bool aligned = is_aligned(tx);
         if (tid < kAW) {                       // column parameters for this tile (reflected at the image border)
             const int gx = reflect101(x0 - 4 + tid, w);
             const float inv_tw = 1.0f / (float)g.ctw[l];
@@ -390,30 +418,16 @@ __global__ __launch_bounds__(256) void k_clahe_blur(Geom g, CannyBuffers cb)
             if (tx1 < 0) tx1 = 0;
             if (tx2 > 3) tx2 = 3;
             L.colOff1[tid] = tx1 * 256; L.colOff2[tid] = tx2 * 256;
-            L.colSrc[tid] = gx;
-        }
-        if (aligned) {
-#pragma unroll
-            for (int k = 0; k < kRawPerThread; k++) {
-                int idx = tid + k * 256;
-                if (idx < kAH * kAW4) L.R[idx] = raw[k];
-            }
-        } else {
-            __syncthreads();                   // colSrc / rowSrc visible
-            unsigned char *R8 = reinterpret_cast<unsigned char *>(L.R);
-            for (int idx = tid; idx < kAH * kAW; idx += 256) {
-                int j = idx / kAW, c = idx - j * kAW;
-                R8[idx] = src[(long long)L.rowSrc[j] * w + L.colSrc[c]];
-            }
         }
         __syncthreads();
-        if (tx + 1 < tx_end && is_aligned(tx + 1)) blur_prefetch(src, w, (tx + 1) * kBlurTW, y0, raw);
-        blur_tile(g, cb, L, l, b, x0, y0, x0 + kBlurTW <= w && y0 + kBlurTH <= h && (w % 4) == 0);
+        blur_tile(g, cb, L, l, b, x0, y0, x0 + kBlurTW <= w && y0 + kBlurTH <= h && (w % 4) == 0, raw, [&]() {
+            if (tx + 1 < tx_end) blur_prefetch(src, w, h, (tx + 1) * kBlurTW, y0, is_aligned(tx + 1), raw);
+        });
     }
     __syncthreads();
     unsigned int c = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) c += (L.hist16[k * 129 + (tid >> 1)] >> (16 * (tid & 1))) & 0xffffu;
+    for (int k = 0; k < kHistCopies; k++) c += (L.hist16[k * 129 + (tid >> 1)] >> (16 * (tid & 1))) & 0xffffu;
     if (c) atomicAdd(&cb.blur_hist[((long long)b * 3 + l) * 256 + tid], (int)c);
 }
 
