@@ -6,7 +6,7 @@ namespace aej {
 
 // color.hip
 int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out, long long n);
-int launch_color_planes(hipStream_t st, int space, const float *rgb, const Geom &g, const float *mid, const float *scale,
+int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                         float *raw, float *norm, unsigned char *u8, int *tile_hist);
 // tables of cv.resize(INTER_AREA) for the chroma layers when the ratios are not exact 2x2 (device arrays)
 struct AreaTabs {
@@ -15,7 +15,7 @@ struct AreaTabs {
     const int *xoff, *xsi, *yoff, *ysi;
     const float *xal, *yal;
 };
-int launch_color_planes_generic(hipStream_t st, int space, const float *rgb, const Geom &g, const float *mid, const float *scale,
+int launch_color_planes_generic(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                                 const AreaTabs &tabs, float *raw, float *norm, unsigned char *u8, int *tile_hist);
 void launch_plane_u8(hipStream_t st, const float *plane, const Geom &g, unsigned char *u8, int *tile_hist);
 

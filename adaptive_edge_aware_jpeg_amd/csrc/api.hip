@@ -531,12 +531,13 @@ static bool planes_fast_ok(const Geom &g)
     return ok;
 }
 
-static int run_color_planes(aej_ctx *ctx, const float *rgb, const Geom &g, float *raw, float *norm, unsigned char *u8, int *hist, int *tab_ws)
+static int run_color_planes(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g, float *raw, float *norm, unsigned char *u8, int *hist,
+                            int *tab_ws)
 {
     float mid[3], scale[3];
     for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
     if (planes_fast_ok(g)) {
-        if (launch_color_planes(ctx->stream, ctx->space, rgb, g, mid, scale, raw, norm, u8, hist)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+        if (launch_color_planes(ctx->stream, ctx->space, rgb, in_u8, g, mid, scale, raw, norm, u8, hist)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
         return 0;
     }
     AreaTabs t;
@@ -564,7 +565,7 @@ static int run_color_planes(aej_ctx *ctx, const float *rgb, const Geom &g, float
         t.xoff = tab_ws + o1; t.xsi = tab_ws + o2; t.xal = reinterpret_cast<const float *>(tab_ws + o3);
         t.yoff = tab_ws + o4; t.ysi = tab_ws + o5; t.yal = reinterpret_cast<const float *>(tab_ws + o6);
     }
-    if (launch_color_planes_generic(ctx->stream, ctx->space, rgb, g, mid, scale, t, raw, norm, u8, hist)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+    if (launch_color_planes_generic(ctx->stream, ctx->space, rgb, in_u8, g, mid, scale, t, raw, norm, u8, hist)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
     return 0;
 }
 
@@ -618,8 +619,8 @@ extern "C" int aej_encode_plan(aej_ctx *ctx, int batch, int H, int W, aej_plan *
     return 0;
 }
 
-extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
-                                uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
+static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                             uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
 {
     int rc = check_encode_args(ctx, batch, H, W);
     if (rc) return rc;
@@ -640,7 +641,7 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
     if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
     mark(ctx, AEJ_STAGE_CLEAR);
 
-    if ((rc = run_color_planes(ctx, rgb, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs))) return rc;
+    if ((rc = run_color_planes(ctx, rgb, in_u8, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs))) return rc;
     mark(ctx, AEJ_STAGE_COLOR_PLANES);
     if ((rc = run_canny_chain(ctx, g, w.canny, true))) return rc;
 
@@ -685,6 +686,18 @@ extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H
     return 0;
 }
 
+extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                                uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
+{
+    return encode_batch_impl(ctx, rgb, false, batch, H, W, coeffs, leaves, states, counts, dct_f32, workspace, workspace_bytes);
+}
+
+extern "C" int aej_encode_batch_u8(aej_ctx *ctx, const uint8_t *rgb_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                                   uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
+{
+    return encode_batch_impl(ctx, rgb_u8, true, batch, H, W, coeffs, leaves, states, counts, dct_f32, workspace, workspace_bytes);
+}
+
 // ---- stage entry points ---------------------------------------------------------------------------------------
 extern "C" int aej_color_convert(aej_ctx *ctx, int space, const float *rgb, float *out, int64_t n)
 {
@@ -707,7 +720,7 @@ extern "C" int aej_color_planes(aej_ctx *ctx, const float *rgb, int batch, int H
     if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
     int *tabs = nullptr;
     if (!planes_fast_ok(g)) AEJ_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&tabs), (size_t)area_tab_ints(g) * 4));   // stage entry only
-    rc = run_color_planes(ctx, rgb, g, planes_raw, planes_norm, planes_u8, nullptr, tabs);
+    rc = run_color_planes(ctx, rgb, false, g, planes_raw, planes_norm, planes_u8, nullptr, tabs);
     if (tabs) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tabs); }
     if (rc) return rc;
     AEJ_HIP_CHECK(hipGetLastError());

@@ -128,8 +128,11 @@ __device__ __forceinline__ void hist_add(int *lds_hist, int *__restrict__ ghist,
     else atomicAdd(&ghist[((layer * 16) + ty * 4 + tx) * 256 + v], 1);
 }
 
-template <int SPACE, int RH, int RW>
-__global__ __launch_bounds__(256) void k_color_planes(const float *__restrict__ rgb, Geom g, NormConst nc,
+// IN = float: [B][H][W][3] float32 in [0, 1].  IN = unsigned char: the same image as uint8; the kernel forms
+// float32(v) / 255.0f per channel (image.py:80, `imread(path).astype(np.float32) / 255.0`) from a 256-entry LDS table
+// of exactly those quotients, so both ingest paths produce identical planes for images that came from 8-bit files.
+template <int SPACE, int RH, int RW, typename IN>
+__global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb, Geom g, NormConst nc,
                                                       float *__restrict__ planes_raw, float *__restrict__ planes_norm,
                                                       unsigned char *__restrict__ planes_u8, int *__restrict__ tile_hist)
 {
@@ -139,10 +142,13 @@ __global__ __launch_bounds__(256) void k_color_planes(const float *__restrict__ 
     const int px = (blockIdx.x * 32 + (tid & 31)) * 4;
     const int py = (blockIdx.y * 8 + (tid >> 5)) * 2;
     const bool do_hist = tile_hist != nullptr;
+    constexpr bool kU8 = sizeof(IN) == 1;
+    __shared__ float s_u8f[kU8 ? 256 : 1];
+    if (kU8) s_u8f[tid] = (float)tid / 255.0f;
     if (do_hist) {
         for (int i = tid; i < 3 * 4 * 256; i += 256) s_hist[i] = 0;
-        __syncthreads();
     }
+    if (do_hist || kU8) __syncthreads();
     // first CLAHE tile touched by this block, per layer
     const int bx0 = blockIdx.x * 128, by0 = blockIdx.y * 16;
     const int tx0_l = bx0 / g.ctw[0], ty0_l = by0 / g.cth[0];
@@ -153,9 +159,18 @@ __global__ __launch_bounds__(256) void k_color_planes(const float *__restrict__ 
         float c0[2][4], c1[2][4], c2[2][4];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const float4 *p = reinterpret_cast<const float4 *>(rgb + (((long long)b * g.H + (py + r)) * g.W + px) * 3);
-            float4 a = p[0], bq = p[1], c = p[2];
-            float in[12] = { a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x, c.y, c.z, c.w };
+            float in[12];
+            if constexpr (kU8) {      // 4 pixels = 12 bytes = 3 aligned dwords (px % 4 == 0, W % 4 == 0)
+                const unsigned int *p = reinterpret_cast<const unsigned int *>(rgb + (((long long)b * g.H + (py + r)) * g.W + px) * 3);
+                const unsigned int d[3] = { p[0], p[1], p[2] };
+#pragma unroll
+                for (int k = 0; k < 12; k++) in[k] = s_u8f[(d[k >> 2] >> (8 * (k & 3))) & 0xffu];
+            } else {
+                const float4 *p = reinterpret_cast<const float4 *>(rgb + (((long long)b * g.H + (py + r)) * g.W + px) * 3);
+                float4 a = p[0], bq = p[1], c = p[2];
+                in[0] = a.x; in[1] = a.y; in[2] = a.z; in[3] = a.w; in[4] = bq.x; in[5] = bq.y; in[6] = bq.z; in[7] = bq.w;
+                in[8] = c.x; in[9] = c.y; in[10] = c.z; in[11] = c.w;
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) color_px<SPACE>(in[3 * k], in[3 * k + 1], in[3 * k + 2], c0[r][k], c1[r][k], c2[r][k]);
         }
@@ -244,22 +259,23 @@ __global__ __launch_bounds__(256) void k_color_planes(const float *__restrict__ 
 //   per destination pixel: sum = 0; for each vertical tap: buf = 0; for each horizontal tap: buf += S * alpha; sum += beta * buf
 // One thread per destination pixel of a layer; source pixels are colour-converted on the fly.
 // ------------------------------------------------------------------------------------------------
-template <int SPACE>
-__global__ __launch_bounds__(256) void k_color_planes_generic(const float *__restrict__ rgb, Geom g, NormConst nc, AreaTabs tabs,
+template <int SPACE, typename IN>
+__global__ __launch_bounds__(256) void k_color_planes_generic(const IN *__restrict__ rgb, Geom g, NormConst nc, AreaTabs tabs,
                                                               float *__restrict__ planes_raw, float *__restrict__ planes_norm,
                                                               unsigned char *__restrict__ planes_u8, int *__restrict__ tile_hist)
 {
     const int l = blockIdx.y, b = blockIdx.z;
     const int w = g.w[l], h = g.h[l];
     const long long n = (long long)w * h;
-    const float *img = rgb + (long long)b * g.H * g.W * 3;
+    const IN *img = rgb + (long long)b * g.H * g.W * 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int y = (int)(i / w), x = (int)(i - (long long)y * w);
         float v;
         auto chan = [&](int sy, int sx) {
-            const float *p = img + ((long long)sy * g.W + sx) * 3;
+            const IN *p = img + ((long long)sy * g.W + sx) * 3;
             float o0, o1, o2;
-            color_px<SPACE>(p[0], p[1], p[2], o0, o1, o2);
+            if constexpr (sizeof(IN) == 1) color_px<SPACE>((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, o0, o1, o2);
+            else color_px<SPACE>(p[0], p[1], p[2], o0, o1, o2);
             return l == 0 ? o0 : l == 1 ? o1 : o2;
         };
         if (h == g.H && w == g.W) {
@@ -333,54 +349,64 @@ int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out
 }
 
 template <int SPACE, int RH, int RW>
-static void launch_planes_t(hipStream_t st, const float *rgb, const Geom &g, const NormConst &nc, float *raw, float *norm,
+static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const Geom &g, const NormConst &nc, float *raw, float *norm,
                             unsigned char *u8, int *hist)
 {
     dim3 grid((g.W + 127) / 128, (g.H + 15) / 16, g.B);
-    hipLaunchKernelGGL((k_color_planes<SPACE, RH, RW>), grid, dim3(256), 0, st, rgb, g, nc, raw, norm, u8, hist);
+    if (in_u8)
+        hipLaunchKernelGGL((k_color_planes<SPACE, RH, RW, unsigned char>), grid, dim3(256), 0, st, static_cast<const unsigned char *>(rgb), g, nc,
+                           raw, norm, u8, hist);
+    else
+        hipLaunchKernelGGL((k_color_planes<SPACE, RH, RW, float>), grid, dim3(256), 0, st, static_cast<const float *>(rgb), g, nc, raw, norm, u8,
+                           hist);
 }
 
-int launch_color_planes(hipStream_t st, int space, const float *rgb, const Geom &g, const float *mid, const float *scale,
+int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                         float *raw, float *norm, unsigned char *u8, int *hist)
 {
     NormConst nc;
     for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
     switch (space) {
-    case 0: launch_planes_t<0, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
-    case 1: launch_planes_t<1, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
-    case 2: launch_planes_t<2, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
-    case 3: launch_planes_t<3, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
-    case 4: launch_planes_t<4, 1, 4>(st, rgb, g, nc, raw, norm, u8, hist); break;
-    case 5: launch_planes_t<5, 1, 4>(st, rgb, g, nc, raw, norm, u8, hist); break;
-    case 6: launch_planes_t<6, 2, 2>(st, rgb, g, nc, raw, norm, u8, hist); break;
+    case 0: launch_planes_t<0, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
+    case 1: launch_planes_t<1, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
+    case 2: launch_planes_t<2, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
+    case 3: launch_planes_t<3, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
+    case 4: launch_planes_t<4, 1, 4>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
+    case 5: launch_planes_t<5, 1, 4>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
+    case 6: launch_planes_t<6, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
     default: return -1;
     }
     return 0;
 }
 
 template <int SPACE>
-static void launch_generic_t(hipStream_t st, const float *rgb, const Geom &g, const NormConst &nc, const AreaTabs &tabs, float *raw,
+static void launch_generic_t(hipStream_t st, const void *rgb, bool in_u8, const Geom &g, const NormConst &nc, const AreaTabs &tabs, float *raw,
                              float *norm, unsigned char *u8, int *hist)
 {
     long long n = (long long)g.W * g.H;
     int bx = (int)((n + 255) / 256);
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(k_color_planes_generic<SPACE>, dim3(bx, 3, g.B), dim3(256), 0, st, rgb, g, nc, tabs, raw, norm, u8, hist);
+    if (in_u8)
+        hipLaunchKernelGGL((k_color_planes_generic<SPACE, unsigned char>), dim3(bx, 3, g.B), dim3(256), 0, st, static_cast<const unsigned char *>(rgb),
+                           g, nc, tabs, raw, norm, u8, hist);
+    else
+        hipLaunchKernelGGL((k_color_planes_generic<SPACE, float>), dim3(bx, 3, g.B), dim3(256), 0, st, static_cast<const float *>(rgb), g, nc, tabs,
+                           raw, norm, u8, hist);
 }
 
-int launch_color_planes_generic(hipStream_t st, int space, const float *rgb, const Geom &g, const float *mid, const float *scale,
+int launch_color_planes_generic(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                                 const AreaTabs &tabs, float *raw, float *norm, unsigned char *u8, int *hist)
 {
     NormConst nc;
     for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
     switch (space) {
-    case 0: launch_generic_t<0>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
-    case 1: launch_generic_t<1>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
-    case 2: launch_generic_t<2>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
-    case 3: launch_generic_t<3>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
-    case 4: launch_generic_t<4>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
-    case 5: launch_generic_t<5>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
-    case 6: launch_generic_t<6>(st, rgb, g, nc, tabs, raw, norm, u8, hist); break;
+    case 0: launch_generic_t<0>(st, rgb, in_u8, g, nc, tabs, raw, norm, u8, hist); break;
+    case 1: launch_generic_t<1>(st, rgb, in_u8, g, nc, tabs, raw, norm, u8, hist); break;
+    case 2: launch_generic_t<2>(st, rgb, in_u8, g, nc, tabs, raw, norm, u8, hist); break;
+    case 3: launch_generic_t<3>(st, rgb, in_u8, g, nc, tabs, raw, norm, u8, hist); break;
+    case 4: launch_generic_t<4>(st, rgb, in_u8, g, nc, tabs, raw, norm, u8, hist); break;
+    case 5: launch_generic_t<5>(st, rgb, in_u8, g, nc, tabs, raw, norm, u8, hist); break;
+    case 6: launch_generic_t<6>(st, rgb, in_u8, g, nc, tabs, raw, norm, u8, hist); break;
     default: return -1;
     }
     return 0;

@@ -95,11 +95,13 @@ class Jpeg:
 
     # ------------------------------------------------------------------ encode
     def compress_batch(self, batch, want_dct: bool = False) -> EncodedBatch:
-        """batch: float32 [B, H, W, 3] in [0, 1] -- a torch tensor already on the GPU (throughput path) or a
-        numpy array (copied).  Returns device-resident outputs; nothing is copied back."""
+        """batch: float32 [B, H, W, 3] in [0, 1], or uint8 [B, H, W, 3] (8-bit ingest: the GPU forms float32(v) / 255 as
+        Image.load does, image.py:80, at a quarter of the input traffic) -- a torch tensor already on the GPU (throughput
+        path) or a numpy array (copied).  Returns device-resident outputs; nothing is copied back."""
         ctx = self._bind()
         t = ctx.torch
-        x = ctx.to_device(batch, t.float32)
+        is_u8 = str(getattr(batch, "dtype", "")) in ("uint8", "torch.uint8")
+        x = ctx.to_device(batch, t.uint8 if is_u8 else t.float32)
         if x.ndim != 4 or x.shape[3] != 3:
             raise ValueError("Input batch must be [B, H, W, 3].")
         B, H, W, _ = x.shape
@@ -115,7 +117,8 @@ class Jpeg:
     def encode_into(self, ctx, x, plan, coeffs, leaves, states, counts, dct=None) -> None:
         """One pass of the hot path into caller-owned device buffers (what bench.py times)."""
         ws = ctx.workspace(plan.workspace_bytes)
-        ctx.check(ctx.lib.aej_encode_batch(
+        entry = ctx.lib.aej_encode_batch_u8 if x.dtype == ctx.torch.uint8 else ctx.lib.aej_encode_batch
+        ctx.check(entry(
             ctx.handle, x.data_ptr(), plan.batch, plan.H, plan.W, coeffs.data_ptr(), leaves.data_ptr(), states.data_ptr(),
             counts.data_ptr(), dct.data_ptr() if dct is not None else None, ws.data_ptr(), ctypes.c_uint64(plan.workspace_bytes)))
 

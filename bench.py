@@ -11,7 +11,7 @@ weak scaling).  Inputs are in HBM before the timed region; outputs stay in HBM.
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, HIP-event
-timed on the launch stream inside the library) and `cpu_baseline` (the C oracle on one host core, bounded sample).
+timed on the launch stream inside the library) and `cpu_baseline` (the C oracle, one image per host core, bounded sample).
 """
 import argparse
 import json
@@ -30,7 +30,7 @@ H4K, W4K = 2160, 3840
 
 # algorithmic HBM bytes per INPUT pixel of each stage for 4:2:0-type spaces (1.5 plane-pixels per pixel); DESIGN.md
 ALGO_BYTES_PER_PX = {
-    "color_planes": 12.0 + 1.5 * 4 + 1.5 * 1,   # f32 RGB in; normalised f32 planes + u8 planes out
+    "color_planes": 12.0 + 1.5 * 4 + 1.5 * 1,   # f32 RGB in (3 B with --ingest u8); normalised f32 planes + u8 planes out
     "clahe_blur": 1.5 * (1 + 1),                 # u8 in, u8 out
     "sobel_nms": 1.5 * (1 + 1),                  # u8 in, u8 map out
     "hysteresis": 1.5 * (1 + 1),                 # map in, map out (one sweep is the algorithmic minimum)
@@ -79,8 +79,10 @@ def main():
     ap.add_argument("--space", default="YCbCr")
     ap.add_argument("--blocks", type=int, nargs=2, default=[4, 64])
     ap.add_argument("--quality", type=int, nargs=2, default=[40, 80])
+    ap.add_argument("--ingest", choices=["f32", "u8"], default="f32",
+                    help="f32 = the BASELINE metric's float32 RGB input; u8 = 8-bit ingest (aej_encode_batch_u8, 3 B/px in), reported as a variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=6, help="4K images encoded by the CPU oracle for cpu_baseline")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads (one image each) for cpu_baseline; 0 = all cores")
     args = ap.parse_args()
 
     import torch
@@ -103,6 +105,9 @@ def main():
     space, qrange, brange = args.space, tuple(args.quality), tuple(args.blocks)
     dev = torch.device("cuda", local_rank)
     x = synth_batch(torch, B, H, W, 20250718 + rank * B, dev)
+    x_f32 = x
+    if args.ingest == "u8":
+        x = (x * 255.0).round().to(torch.uint8)
 
     jpeg = A.Jpeg(A.JpegCompressionSettings(space, qrange, brange), device=local_rank)
     ctx = jpeg._bind()
@@ -146,6 +151,8 @@ def main():
     kernels["dct"] = dct_ms
     dom = max(kernels, key=kernels.get)
     local_px = B * H * W
+    if args.ingest == "u8":
+        ALGO_BYTES_PER_PX["color_planes"] -= 9.0
     achieved = ALGO_BYTES_PER_PX[dom] * local_px / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
     # HBM bytes of the dominant kernel from the PMC passes (tests/traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     # runs of this same workload; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_color_planes' known read volume)
@@ -160,40 +167,64 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX[dom] * local_px, "avg_launch_ms": round(kernels[dom], 4)}
-    whole = WHOLE_PATH_BYTES_PER_PX * local_px / (ms_per_step * 1e-3) / 1e9
+    whole_bpp = WHOLE_PATH_BYTES_PER_PX - (9.0 if args.ingest == "u8" else 0.0)
+    whole = whole_bpp * local_px / (ms_per_step * 1e-3) / 1e9
     per_stage = {k: {"ms": round(v, 4), "GBps": round(ALGO_BYTES_PER_PX[k] * local_px / (v * 1e-3) / 1e9, 1) if v > 0 else None}
                  for k, v in kernels.items()}
 
     cnt = counts.cpu().numpy()
+    # leaf-size histogram of this rank's batch ("report the leaf-size histogram with every number")
+    lv = leaves.view(B, plan.leaf_stride, 4)
+    leaf_hist = {}
+    for l in range(3):
+        n_l = torch.from_numpy(cnt[:, l, 1].copy()).to(dev)
+        lo = int(plan.leaf_off[l])
+        cap = int(cnt[:, l, 1].max())
+        sz = lv[:, lo:lo + cap, 2]
+        valid = torch.arange(cap, device=dev)[None, :] < n_l[:, None]
+        s = brange[0]
+        while s <= brange[1]:
+            leaf_hist[s] = leaf_hist.get(s, 0) + int(((sz == s) & valid).sum().item())
+            s *= 2
+    leaf_area = sum(k * k * v for k, v in leaf_hist.items())
     out = {
         "metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic ('mixed' images generated on the GPU, SURVEY.md 8d recipe)",
-        "config": {"workload": f"{B} x {W}x{H} float32 RGB per GPU, {space}, blocks {brange[0]}-{brange[1]}, quality {qrange[0]}-{qrange[1]} "
+        "config": {"workload": f"{B} x {W}x{H} {'uint8' if args.ingest == 'u8' else 'float32'} RGB per GPU, {space}, blocks {brange[0]}-{brange[1]}, quality {qrange[0]}-{qrange[1]} "
                                f"(BASELINE config 4: 512 4K images / 8 GPUs)",
                    "images_per_gpu": B, "height": H, "width": W, "color_space": space,
                    "block_size_range": list(brange), "quality_range": list(qrange)},
         "roofline": roofline,
-        "whole_path": {"bytes_per_px": WHOLE_PATH_BYTES_PER_PX, "achieved_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4)},
+        "whole_path": {"bytes_per_px": whole_bpp, "achieved_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4)},
         "stages": per_stage,
         "hysteresis_passes": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle)),
         "leaves_per_image": {"luma": int(cnt[:, 0, 1].mean()), "chroma": int(cnt[:, 1:, 1].mean())},
+        "leaf_histogram": {"per_image": {str(k): round(v / B, 1) for k, v in leaf_hist.items()},
+                           "area_share": {str(k): round(k * k * v / leaf_area, 4) for k, v in leaf_hist.items()}},
     }
 
-    # ---- CPU baseline: the C oracle (a scalar port of the reference algorithm), one host core, bounded sample ----
+    # ---- CPU baseline: the C oracle (a scalar port of the reference algorithm) on the host cores, bounded sample:
+    # one image per thread (ctypes releases the GIL inside the C call), the fan-out the reference's own sweep uses
+    # (one image per worker process); the single-core rate is reported beside it ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
         O.build()
-        n_img = max(1, min(args.cpu_images, B))
-        imgs = x[:n_img].cpu().numpy()
+        cores = max(1, min(args.cpu_threads or (os.cpu_count() or 1), B))
+        imgs = x_f32[:cores].cpu().numpy()
         t0 = time.perf_counter()
-        for i in range(n_img):
-            O.encode_image(imgs[i], space, qrange, brange)
+        O.encode_image(imgs[0], space, qrange, brange)
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            list(ex.map(lambda im: O.encode_image(im, space, qrange, brange), [imgs[i] for i in range(cores)]))
         cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(n_img * H * W / cdt / 1e6, 2), "unit": "MP/s", "cores": 1, "kind": "port",
-                               "sample": f"{n_img} of the {B} bench images ({W}x{H}), whole path a-1..a-15 in the C oracle, {cdt:.1f} s",
-                               "host_cpus": os.cpu_count()}
+        out["cpu_baseline"] = {"value": round(cores * H * W / cdt / 1e6, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+                               "sample": f"{cores} of the {B} bench images ({W}x{H}), one per thread, whole path a-1..a-15 in the C oracle, "
+                                         f"{cdt:.1f} s; single core: 1 image in {t1:.1f} s",
+                               "single_core_value": round(H * W / t1 / 1e6, 2), "host_cpus": os.cpu_count()}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -106,6 +106,13 @@ AEJ_API int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H, i
                      int32_t *coeffs, int32_t *leaves, uint8_t *states, int64_t *counts,
                      float *dct_f32, void *workspace, uint64_t workspace_bytes);
 
+/* Same call for images that are still 8-bit: rgb_u8 is [batch][H][W][3] uint8 and the library forms
+ * float32(v) / 255.0f itself (image.py:80, Image.load: `iio.imread(path).astype(np.float32) / 255.0`), so the
+ * result is identical to aej_encode_batch on that float image while the input costs 3 B/px instead of 12. */
+AEJ_API int aej_encode_batch_u8(aej_ctx *ctx, const uint8_t *rgb_u8, int batch, int H, int W,
+                     int32_t *coeffs, int32_t *leaves, uint8_t *states, int64_t *counts,
+                     float *dct_f32, void *workspace, uint64_t workspace_bytes);
+
 /* ---- stage entry points (same kernels; used by the Python mirrors and the parity tests) -------- */
 
 /* color.convert("sRGB", space, x)  (conversion.py:95-124): rgb [n][3] -> out [n][3], float32 */

@@ -304,6 +304,23 @@ def test_batch_equals_single_and_is_deterministic(A, oracle):
     assert (noise["leaves"][:, 2] == 4).mean() > 0.5 and 64 not in set(noise["leaves"][:, 2].tolist())   # white noise: small leaves
 
 
+@pytest.mark.parametrize("space,H,W", [("YCbCr", 256, 384), ("ICtCp", 128, 256), ("OKLAB", 67, 101), ("YCoCg", 50, 33)])
+def test_uint8_ingest_equals_float_ingest(A, oracle, space, H, W):
+    """aej_encode_batch_u8 forms float32(v) / 255 itself (image.py:80): identical to the float path and to the oracle,
+    on the 4x2-patch kernel and on the general INTER_AREA kernel (ragged sizes)."""
+    u8 = np.stack([oracle.synth_image(H, W, 11 + i, k) for i, k in enumerate(("mixed", "noise"))]).astype(np.uint8)
+    f32 = u8.astype(np.float32) / np.float32(255.0)
+    codec = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), (4, 64)))
+    a, b = codec.compress_batch(u8), codec.compress_batch(f32)
+    for i in range(len(u8)):
+        ref = oracle.encode_image(f32[i], space, (40, 80), (4, 64))
+        for l in range(3):
+            x, y = a.layer(i, l), b.layer(i, l)
+            for k in ("states", "leaves", "coeffs"):
+                assert np.array_equal(x[k], y[k]), (space, i, l, k)
+            assert np.array_equal(x["coeffs"], ref[l]["coeffs"]) and np.array_equal(x["leaves"], ref[l]["leaves"])
+
+
 @pytest.mark.parametrize("H,W,B", [(1080, 1920, 2), (2160, 3840, 1)])
 def test_full_size_properties(A, oracle, H, W, B):
     """BASELINE sizes: structural invariants instead of an oracle run per pixel (the 1080p oracle comparison is
