@@ -53,6 +53,8 @@ SIGNATURES = {
     "aej_encode_plan": (_I, [_P, _I, _I, _I, ctypes.POINTER(AejPlan)]),
     "aej_encode_batch": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _U64]),
     "aej_encode_batch_u8": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _U64]),
+    "aej_metrics_workspace_bytes": (_U64, [_I, _I, _I]),
+    "aej_metrics_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _U64]),
     "aej_color_convert": (_I, [_P, _I, _P, _P, _I64]),
     "aej_color_planes": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "aej_canny_workspace_bytes": (_U64, [_I, _I]),

@@ -55,6 +55,12 @@ constexpr int kChunkInts = 4 + kMaxSizes;   // per-chunk record: nsym, nleaf, nc
 constexpr int kMaxPlanes = 3072;            // planes (3 x images) one DCT launch can address
 
 // One unit of DCT work (a leaf), appended by the quadtree emit kernel.
+// accumulator slots (doubles) per image pair of the evaluation metrics (metrics.hip): 0 = sum of squared differences;
+// kMetricSlotGrey + {0, 1} = ssim / cs sums of the grey SSIM map; kMetricSlotScales + (scale * 3 + channel) * 2 + {0, 1} likewise per scale
+constexpr int kMetricSlots = 40;
+constexpr int kMetricSlotGrey = 2;
+constexpr int kMetricSlotScales = 4;
+
 struct LeafWork {
     int plane;      // b * 3 + layer
     int x, y;       // origin in the layer

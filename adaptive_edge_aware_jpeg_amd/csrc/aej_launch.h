@@ -103,4 +103,14 @@ void launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const
 int launch_color_inverse(hipStream_t st, int space, const float *in, float *out, long long n);
 int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float *planes, float *rgb);
 
+// metrics.hip
+void launch_metric_prep(hipStream_t st, const float *a, const float *b, int B, long long npx, double *acc, unsigned char *ga, unsigned char *gb);
+void launch_metric_pool_grey(hipStream_t st, const unsigned char *ga, const unsigned char *gb, int B, int H, int W, int f, int hp, int wp, float *xa,
+                             float *xb);
+void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const float *xb, int B, int C, int h, int w, const float *g11, double *acc,
+                       int slot);
+void launch_pool2(hipStream_t st, bool interleaved, const float *in, int B, int C, int h, int w, int p, int h2, int w2, float *out);
+void launch_metric_final(hipStream_t st, const double *acc, int B, long long npx, long long n_ssim, const long long *n_level, double *out);
+
+
 }  // namespace aej

@@ -980,6 +980,96 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
     return 0;
 }
 
+// ---- evaluation metrics (evaluation_metrics.py:50-89) ------------------------------------------------------------
+struct MetricsWs {
+    double *acc;
+    unsigned char *ga, *gb;
+    float *xa, *xb;
+    float *pyr[2][4];            // MS-SSIM scales 1..4 of both images, planar [B][3][h][w]
+    int f, hp, wp;
+    int lh[5], lw[5], lp[5];     // scale dimensions; lp[l] = padding applied when going from scale l-1 to l
+    unsigned long long bytes;
+};
+
+static void carve_metrics(void *base, int B, int H, int W, MetricsWs &w)
+{
+    unsigned long long off = 0;
+    auto take = [&](unsigned long long n) { void *p = base ? (char *)base + off : nullptr; off += (unsigned long long)align_up((long long)n, 256); return p; };
+    w.acc = (double *)take((unsigned long long)B * kMetricSlots * sizeof(double));
+    w.ga = (unsigned char *)take((unsigned long long)B * H * W);
+    w.gb = (unsigned char *)take((unsigned long long)B * H * W);
+    // piq.ssim: f = max(1, round(min(H, W) / 256)) -- Python round(): ties to even
+    w.f = (int)nearbyint((double)(H < W ? H : W) / 256.0);
+    if (w.f < 1) w.f = 1;
+    w.hp = H / w.f; w.wp = W / w.f;
+    w.xa = (float *)take((unsigned long long)B * w.hp * w.wp * 4);
+    w.xb = (float *)take((unsigned long long)B * w.hp * w.wp * 4);
+    w.lh[0] = H; w.lw[0] = W; w.lp[0] = 0;
+    for (int l = 1; l < 5; l++) {
+        const int p = (w.lh[l - 1] % 2) > (w.lw[l - 1] % 2) ? (w.lh[l - 1] % 2) : (w.lw[l - 1] % 2);
+        w.lp[l] = p;
+        w.lh[l] = (w.lh[l - 1] + p) / 2;
+        w.lw[l] = (w.lw[l - 1] + p) / 2;
+        for (int i = 0; i < 2; i++) w.pyr[i][l - 1] = (float *)take((unsigned long long)B * 3 * w.lh[l] * w.lw[l] * 4);
+    }
+    w.bytes = off;
+}
+
+extern "C" uint64_t aej_metrics_workspace_bytes(int batch, int H, int W)
+{
+    if (batch < 1 || H < 1 || W < 1) return 0;
+    MetricsWs w;
+    carve_metrics(nullptr, batch, H, W, w);
+    return w.bytes;
+}
+
+extern "C" int aej_metrics_batch(aej_ctx *ctx, const float *img_a, const float *img_b, int batch, int H, int W, int which, double *out,
+                                 void *workspace, uint64_t workspace_bytes)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (!img_a || !img_b || !out || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    if (batch < 1 || H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "bad shape %d x %d x %d", batch, H, W);
+    if ((which & ~7) || !(which & 7)) return fail(ctx, AEJ_ERR_ARG, "which must be a combination of AEJ_METRIC_PSNR | AEJ_METRIC_SSIM | AEJ_METRIC_MS_SSIM");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    MetricsWs w;
+    carve_metrics(workspace, batch, H, W, w);
+    if (w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", w.bytes, (unsigned long long)workspace_bytes);
+    const bool want_ssim = which & AEJ_METRIC_SSIM, want_ms = which & AEJ_METRIC_MS_SSIM;
+    // piq/ssim.py _ssim_per_channel / piq/ms_ssim.py _multi_scale_ssim raise ValueError for these
+    if (want_ssim && (w.hp < 11 || w.wp < 11)) return fail(ctx, AEJ_ERR_ARG, "Kernel size can't be greater than actual input size. Input size: %dx%d. Kernel size: 11x11", w.hp, w.wp);
+    if (want_ms && (H < 161 || W < 161)) return fail(ctx, AEJ_ERR_ARG, "Invalid size of the input images, expected at least 161x161.");
+    hipStream_t st = ctx->stream;
+    float g11[11];
+    {
+        double e[11], sum = 0.0;
+        for (int i = 0; i < 11; i++) { double c = (double)i - 5.0; e[i] = exp(-(c * c) / (2.0 * 1.5 * 1.5)); sum += e[i]; }
+        for (int i = 0; i < 11; i++) g11[i] = (float)(e[i] / sum);
+    }
+    AEJ_HIP_CHECK(hipMemsetAsync(w.acc, 0, (size_t)batch * kMetricSlots * sizeof(double), st));
+    launch_metric_prep(st, img_a, img_b, batch, (long long)H * W, w.acc, want_ssim ? w.ga : nullptr, want_ssim ? w.gb : nullptr);
+    long long n_ssim = 0, n_level[5] = { 0, 0, 0, 0, 0 };
+    if (want_ssim) {
+        launch_metric_pool_grey(st, w.ga, w.gb, batch, H, W, w.f, w.hp, w.wp, w.xa, w.xb);
+        launch_ssim_level(st, false, w.xa, w.xb, batch, 1, w.hp, w.wp, g11, w.acc, kMetricSlotGrey);
+        n_ssim = (long long)(w.hp - 10) * (w.wp - 10);
+    }
+    if (want_ms) {
+        for (int l = 0; l < 5; l++) {
+            const float *xa = l == 0 ? img_a : w.pyr[0][l - 1], *xb = l == 0 ? img_b : w.pyr[1][l - 1];
+            if (l > 0) {
+                const float *pa = l == 1 ? img_a : w.pyr[0][l - 2], *pb = l == 1 ? img_b : w.pyr[1][l - 2];
+                launch_pool2(st, l == 1, pa, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[0][l - 1]);
+                launch_pool2(st, l == 1, pb, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[1][l - 1]);
+            }
+            launch_ssim_level(st, l == 0, xa, xb, batch, 3, w.lh[l], w.lw[l], g11, w.acc, kMetricSlotScales + l * 6);
+            n_level[l] = (long long)(w.lh[l] - 10) * (w.lw[l] - 10);
+        }
+    }
+    launch_metric_final(st, w.acc, batch, (long long)H * W, n_ssim, n_level, out);
+    AEJ_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int aej_last_hysteresis_passes(aej_ctx *ctx) { return ctx ? ctx->last_hyst_passes : -1; }
 
 extern "C" int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin)

@@ -1,0 +1,301 @@
+// metrics.hip -- EvaluationMetrics (src/image/evaluation_metrics.py:50-89) for batches of image pairs on the GPU:
+//   psnr()    = piq.psnr(x, y, data_range=1.0)                       -10 log10(mean((x - y)^2) + 1e-8), all channels
+//   ssim()    = piq.ssim(grey(x), grey(y), data_range=255.0)         8-bit grey (Image.get_uint8 + cv.cvtColor RGB2GRAY),
+//                                                                    average-pooled by round(min(H, W) / 256), 11x11 Gaussian
+//   ms_ssim() = piq.multi_scale_ssim(x, y, data_range=1.0)           5 scales, 2x2 average pooling between them
+// piq 0.8.0 is not under /root/reference (requirements.txt:22); this file restates its published algorithm (piq/psnr.py,
+// piq/ssim.py, piq/ms_ssim.py, piq/functional/filters.py); tests/test_metrics.py compares it with a numpy restatement.  These are float32 reductions whose summation order torch does not define, so parity here is to a stated
+// tolerance, not bitwise.  The window is the normalised Gaussian exp(-(i^2 + j^2) / (2 sigma^2)) / sum, applied as two
+// separable passes through LDS ('valid' convolution: no padding).
+#include "aej_common.h"
+#include "aej_launch.h"
+
+namespace aej {
+
+constexpr int kSsimK = 11;               // window size
+constexpr int kSsimT = 32;               // output tile (square)
+constexpr int kSsimIn = kSsimT + kSsimK - 1;   // 42 input rows / columns per tile
+
+__device__ __forceinline__ double block_sum(double v, double *s_red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__device__ __forceinline__ unsigned char to_u8(float v)      // Image.get_uint8 (image.py:120-127): (data * 255).astype(np.uint8)
+{
+    return (unsigned char)((int)(v * 255.0f) & 0xFF);
+}
+
+__device__ __forceinline__ unsigned char grey_u8(float r, float g, float b)
+{
+    // cv.cvtColor(COLOR_RGB2GRAY) on uint8: fixed point, 14 fractional bits (OpenCV color_rgb.simd.hpp RGB2Gray<uchar>)
+    const int R = to_u8(r), G = to_u8(g), B = to_u8(b);
+    return (unsigned char)((R * 4899 + G * 9617 + B * 1868 + (1 << 13)) >> 14);
+}
+
+// ---- pass over both images: squared error (psnr) and the two 8-bit grey planes (ssim) ----
+__global__ __launch_bounds__(256) void k_metric_prep(const float *__restrict__ a, const float *__restrict__ b, long long npx, double *__restrict__ acc,
+                                                     unsigned char *__restrict__ ga, unsigned char *__restrict__ gb)
+{
+    __shared__ double s_red[4];
+    const int img = blockIdx.y;
+    const float *pa = a + (long long)img * npx * 3, *pb = b + (long long)img * npx * 3;
+    double sum = 0.0;
+    const long long stride = (long long)gridDim.x * 256;
+    if ((npx & 3) == 0) {           // 4 pixels = 3 float4 per image
+        for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < npx / 4; q += stride) {
+            float va[12], vb[12];
+            const float4 *qa = reinterpret_cast<const float4 *>(pa) + q * 3, *qb = reinterpret_cast<const float4 *>(pb) + q * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float4 t = qa[k], u = qb[k];
+                va[4 * k] = t.x; va[4 * k + 1] = t.y; va[4 * k + 2] = t.z; va[4 * k + 3] = t.w;
+                vb[4 * k] = u.x; vb[4 * k + 1] = u.y; vb[4 * k + 2] = u.z; vb[4 * k + 3] = u.w;
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 12; k++) { float d = va[k] - vb[k]; s += d * d; }
+            sum += (double)s;
+            if (ga) {
+                uchar4 oa, ob;
+                oa.x = grey_u8(va[0], va[1], va[2]); oa.y = grey_u8(va[3], va[4], va[5]); oa.z = grey_u8(va[6], va[7], va[8]); oa.w = grey_u8(va[9], va[10], va[11]);
+                ob.x = grey_u8(vb[0], vb[1], vb[2]); ob.y = grey_u8(vb[3], vb[4], vb[5]); ob.z = grey_u8(vb[6], vb[7], vb[8]); ob.w = grey_u8(vb[9], vb[10], vb[11]);
+                reinterpret_cast<uchar4 *>(ga + (long long)img * npx)[q] = oa;
+                reinterpret_cast<uchar4 *>(gb + (long long)img * npx)[q] = ob;
+            }
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npx; i += stride) {
+            float s = 0.f, va[3], vb[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { va[k] = pa[3 * i + k]; vb[k] = pb[3 * i + k]; float d = va[k] - vb[k]; s += d * d; }
+            sum += (double)s;
+            if (ga) {
+                ga[(long long)img * npx + i] = grey_u8(va[0], va[1], va[2]);
+                gb[(long long)img * npx + i] = grey_u8(vb[0], vb[1], vb[2]);
+            }
+        }
+    }
+    sum = block_sum(sum, s_red);
+    if (threadIdx.x == 0) atomicAdd(&acc[(long long)img * kMetricSlots + 0], sum);
+}
+
+// ---- piq.ssim: x / data_range, then F.avg_pool2d(kernel_size = f) when f > 1 ----
+__global__ __launch_bounds__(256) void k_metric_pool_grey(const unsigned char *__restrict__ ga, const unsigned char *__restrict__ gb, int H, int W, int f,
+                                                          int hp, int wp, float *__restrict__ xa, float *__restrict__ xb)
+{
+    const int img = blockIdx.y;
+    const long long n = (long long)hp * wp;
+    const float inv = 1.0f / (float)(f * f);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / wp), x = (int)(i - (long long)y * wp);
+        float sa = 0.f, sb = 0.f;
+        for (int dy = 0; dy < f; dy++) {
+            const long long row = (long long)img * H * W + (long long)(y * f + dy) * W + (long long)x * f;
+            for (int dx = 0; dx < f; dx++) { sa += (float)ga[row + dx] / 255.0f; sb += (float)gb[row + dx] / 255.0f; }
+        }
+        xa[(long long)img * n + i] = sa * inv;
+        xb[(long long)img * n + i] = sb * inv;
+    }
+}
+
+// ---- one SSIM scale: 'valid' Gaussian means of x, y, x^2, y^2, xy; cs and ss maps; their sums ----
+// INTERLEAVED: the images are [B][h][w][C] (the caller's float32 RGB); otherwise planar [B][C][h][w].
+struct SsimArgs {
+    const float *xa, *xb;
+    int h, w, C;
+    float g[kSsimK];          // normalised 1-D Gaussian: g[i] * g[j] is piq's 2-D window
+    float c1, c2;
+    double *acc;              // [B][kMetricSlots]
+    int slot;                 // first slot: channel c adds ss to slot + 2c, cs to slot + 2c + 1
+    int ntx;
+};
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(256) void k_ssim_level(SsimArgs A)
+{
+    __shared__ float sx[kSsimIn][kSsimIn + 1], sy[kSsimIn][kSsimIn + 1];
+    __shared__ float hb[5][kSsimIn][kSsimT + 1];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y, img = blockIdx.z;
+    const int ty = blockIdx.x / A.ntx, tx = blockIdx.x - ty * A.ntx;
+    const int x0 = tx * kSsimT, y0 = ty * kSsimT;
+    const int oh = A.h - (kSsimK - 1), ow = A.w - (kSsimK - 1);
+
+    for (int idx = tid; idx < kSsimIn * kSsimIn; idx += 256) {
+        const int r = idx / kSsimIn, q = idx - r * kSsimIn;
+        const int gy = y0 + r, gx = x0 + q;
+        float va = 0.f, vb = 0.f;
+        if (gy < A.h && gx < A.w) {
+            const long long o = INTERLEAVED ? (((long long)img * A.h + gy) * A.w + gx) * A.C + c
+                                            : (((long long)img * A.C + c) * A.h + gy) * A.w + gx;
+            va = A.xa[o]; vb = A.xb[o];
+        }
+        sx[r][q] = va; sy[r][q] = vb;
+    }
+    __syncthreads();
+    // horizontal pass: 4 adjacent outputs per item share 14 staged values of a row
+    for (int item = tid; item < kSsimIn * (kSsimT / 4); item += 256) {
+        const int r = item / (kSsimT / 4), q0 = (item - r * (kSsimT / 4)) * 4;
+        float xv[kSsimK + 3], yv[kSsimK + 3];
+#pragma unroll
+        for (int k = 0; k < kSsimK + 3; k++) { xv[k] = sx[r][q0 + k]; yv[k] = sy[r][q0 + k]; }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float mx = 0.f, my = 0.f, mxx = 0.f, myy = 0.f, mxy = 0.f;
+#pragma unroll
+            for (int t = 0; t < kSsimK; t++) {
+                const float gw = A.g[t], x = xv[o + t], y = yv[o + t];
+                mx += gw * x; my += gw * y; mxx += gw * (x * x); myy += gw * (y * y); mxy += gw * (x * y);
+            }
+            hb[0][r][q0 + o] = mx; hb[1][r][q0 + o] = my; hb[2][r][q0 + o] = mxx; hb[3][r][q0 + o] = myy; hb[4][r][q0 + o] = mxy;
+        }
+    }
+    __syncthreads();
+    // vertical pass: thread = one column x 4 adjacent rows
+    const int q = tid & 31, r0 = (tid >> 5) * 4;
+    float res[5][4];
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        float v[kSsimK + 3];
+#pragma unroll
+        for (int k = 0; k < kSsimK + 3; k++) v[k] = hb[m][r0 + k][q];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < kSsimK; t++) s += A.g[t] * v[o + t];
+            res[m][o] = s;
+        }
+    }
+    double ss_sum = 0.0, cs_sum = 0.0;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        if (y0 + r0 + o < oh && x0 + q < ow) {
+            const float mu_x = res[0][o], mu_y = res[1][o];
+            const float mu_xx = mu_x * mu_x, mu_yy = mu_y * mu_y, mu_xy = mu_x * mu_y;
+            const float s_xx = res[2][o] - mu_xx, s_yy = res[3][o] - mu_yy, s_xy = res[4][o] - mu_xy;
+            const float cs = (2.f * s_xy + A.c2) / (s_xx + s_yy + A.c2);
+            const float ss = (2.f * mu_xy + A.c1) / (mu_xx + mu_yy + A.c1) * cs;
+            ss_sum += (double)ss; cs_sum += (double)cs;
+        }
+    }
+    ss_sum = block_sum(ss_sum, s_red);
+    cs_sum = block_sum(cs_sum, s_red);
+    if (tid == 0) {
+        double *acc = A.acc + (long long)img * kMetricSlots + A.slot + 2 * c;
+        atomicAdd(&acc[0], ss_sum);
+        atomicAdd(&acc[1], cs_sum);
+    }
+}
+
+// ---- next MS-SSIM scale: F.pad(replicate, left / top by p = max(h % 2, w % 2)) then F.avg_pool2d(2) -> planar ----
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(256) void k_pool2(const float *__restrict__ in, int h, int w, int C, int p, int h2, int w2, float *__restrict__ out)
+{
+    const int c = blockIdx.y, img = blockIdx.z;
+    const long long n = (long long)h2 * w2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / w2), x = (int)(i - (long long)y * w2);
+        float s = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                int sy = 2 * y + dy - p, sx = 2 * x + dx - p;
+                sy = sy < 0 ? 0 : sy; sx = sx < 0 ? 0 : sx;
+                const long long o = INTERLEAVED ? (((long long)img * h + sy) * w + sx) * C + c : (((long long)img * C + c) * h + sy) * w + sx;
+                s += in[o];
+            }
+        out[((long long)img * C + c) * n + i] = s * 0.25f;
+    }
+}
+
+// ---- final: sums -> the three scores per image pair ----
+struct FinalArgs {
+    double npx3;              // H * W * 3
+    double n_ssim;            // outputs of the grey SSIM map (0 = not computed)
+    double n_level[5];        // outputs per MS-SSIM scale (0 = not computed)
+    double weights[5];
+};
+
+__global__ void k_metric_final(const double *__restrict__ acc, FinalArgs F, int B, double *__restrict__ out)
+{
+    const int img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= B) return;
+    const double *a = acc + (long long)img * kMetricSlots;
+    out[img * 3 + 0] = -10.0 * log10(a[0] / F.npx3 + 1e-8);
+    out[img * 3 + 1] = F.n_ssim > 0 ? a[kMetricSlotGrey] / F.n_ssim : nan("");
+    if (F.n_level[0] > 0) {
+        double mean = 0.0;
+        for (int c = 0; c < 3; c++) {
+            double prod = 1.0;
+            for (int l = 0; l < 5; l++) {
+                double v = a[kMetricSlotScales + (l * 3 + c) * 2 + (l == 4 ? 0 : 1)] / F.n_level[l];     // cs for scales 0..3, ssim for the last
+                v = v > 0.0 ? v : 0.0;                                                   // torch.relu
+                prod *= pow(v, F.weights[l]);
+            }
+            mean += prod;
+        }
+        out[img * 3 + 2] = mean / 3.0;
+    } else {
+        out[img * 3 + 2] = nan("");
+    }
+}
+
+// ---- launchers ----
+static int grid_for(long long n)
+{
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);
+}
+
+void launch_metric_prep(hipStream_t st, const float *a, const float *b, int B, long long npx, double *acc, unsigned char *ga, unsigned char *gb)
+{
+    hipLaunchKernelGGL(k_metric_prep, dim3(grid_for((npx & 3) == 0 ? npx / 4 : npx), B), dim3(256), 0, st, a, b, npx, acc, ga, gb);
+}
+
+void launch_metric_pool_grey(hipStream_t st, const unsigned char *ga, const unsigned char *gb, int B, int H, int W, int f, int hp, int wp, float *xa, float *xb)
+{
+    hipLaunchKernelGGL(k_metric_pool_grey, dim3(grid_for((long long)hp * wp), B), dim3(256), 0, st, ga, gb, H, W, f, hp, wp, xa, xb);
+}
+
+void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const float *xb, int B, int C, int h, int w, const float *g11, double *acc, int slot)
+{
+    SsimArgs A;
+    A.xa = xa; A.xb = xb; A.h = h; A.w = w; A.C = C;
+    for (int i = 0; i < kSsimK; i++) A.g[i] = g11[i];
+    A.c1 = (float)(0.01 * 0.01); A.c2 = (float)(0.03 * 0.03);
+    A.acc = acc; A.slot = slot;
+    const int oh = h - (kSsimK - 1), ow = w - (kSsimK - 1);
+    A.ntx = (ow + kSsimT - 1) / kSsimT;
+    const int nty = (oh + kSsimT - 1) / kSsimT;
+    dim3 grid(A.ntx * nty, C, B);
+    if (interleaved) hipLaunchKernelGGL(k_ssim_level<true>, grid, dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(k_ssim_level<false>, grid, dim3(256), 0, st, A);
+}
+
+void launch_pool2(hipStream_t st, bool interleaved, const float *in, int B, int C, int h, int w, int p, int h2, int w2, float *out)
+{
+    dim3 grid(grid_for((long long)h2 * w2), C, B);
+    if (interleaved) hipLaunchKernelGGL(k_pool2<true>, grid, dim3(256), 0, st, in, h, w, C, p, h2, w2, out);
+    else hipLaunchKernelGGL(k_pool2<false>, grid, dim3(256), 0, st, in, h, w, C, p, h2, w2, out);
+}
+
+void launch_metric_final(hipStream_t st, const double *acc, int B, long long npx, long long n_ssim, const long long *n_level, double *out)
+{
+    FinalArgs F;
+    F.npx3 = (double)npx * 3.0;
+    F.n_ssim = (double)n_ssim;
+    const double wts[5] = { 0.0448, 0.2856, 0.3001, 0.2363, 0.1333 };      // piq/ms_ssim.py default scale_weights (float32 tensor)
+    for (int l = 0; l < 5; l++) { F.n_level[l] = (double)n_level[l]; F.weights[l] = (double)(float)wts[l]; }
+    hipLaunchKernelGGL(k_metric_final, dim3((B + 63) / 64), dim3(64), 0, st, acc, F, B, out);
+}
+
+}  // namespace aej

@@ -113,6 +113,16 @@ AEJ_API int aej_encode_batch_u8(aej_ctx *ctx, const uint8_t *rgb_u8, int batch, 
                      int32_t *coeffs, int32_t *leaves, uint8_t *states, int64_t *counts,
                      float *dct_f32, void *workspace, uint64_t workspace_bytes);
 
+/* ---- EvaluationMetrics(original, compressed).psnr() / .ssim() / .ms_ssim() (evaluation_metrics.py:50-89) for a batch
+ * of image pairs.  img_a, img_b: [batch][H][W][3] float32 in [0,1].  out: device [batch][3] float64 = {psnr (dB), ssim of
+ * the 8-bit grey images, ms_ssim}; entries not requested in `which` are NaN.  The metrics are piq 0.8.0's (requirements.txt:22)
+ * with the reference's arguments; AEJ_ERR_ARG where piq raises ValueError (image smaller than the 11x11 window after
+ * pooling, or smaller than 161x161 for MS-SSIM).  lpips() is not offered: its AlexNet weights are a download. */
+enum { AEJ_METRIC_PSNR = 1, AEJ_METRIC_SSIM = 2, AEJ_METRIC_MS_SSIM = 4 };
+AEJ_API uint64_t aej_metrics_workspace_bytes(int batch, int H, int W);
+AEJ_API int aej_metrics_batch(aej_ctx *ctx, const float *img_a, const float *img_b, int batch, int H, int W, int which,
+                      double *out, void *workspace, uint64_t workspace_bytes);
+
 /* ---- stage entry points (same kernels; used by the Python mirrors and the parity tests) -------- */
 
 /* color.convert("sRGB", space, x)  (conversion.py:95-124): rgb [n][3] -> out [n][3], float32 */
