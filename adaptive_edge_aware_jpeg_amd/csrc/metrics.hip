@@ -123,11 +123,13 @@ __global__ __launch_bounds__(256) void k_ssim_level(SsimArgs A)
     __shared__ float hb[5][kSsimIn][kSsimT + 1];
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
-    const int c = blockIdx.y, img = blockIdx.z;
+    const int img = blockIdx.z;
     const int ty = blockIdx.x / A.ntx, tx = blockIdx.x - ty * A.ntx;
     const int x0 = tx * kSsimT, y0 = ty * kSsimT;
     const int oh = A.h - (kSsimK - 1), ow = A.w - (kSsimK - 1);
-
+    // interleaved input: one workgroup walks the channels of its tile, so the 12-byte pixels are fetched from HBM once
+    const int c_begin = INTERLEAVED ? 0 : blockIdx.y, c_end = INTERLEAVED ? A.C : c_begin + 1;
+    for (int c = c_begin; c < c_end; c++) {
     for (int idx = tid; idx < kSsimIn * kSsimIn; idx += 256) {
         const int r = idx / kSsimIn, q = idx - r * kSsimIn;
         const int gy = y0 + r, gx = x0 + q;
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(256) void k_ssim_level(SsimArgs A)
         double *acc = A.acc + (long long)img * kMetricSlots + A.slot + 2 * c;
         atomicAdd(&acc[0], ss_sum);
         atomicAdd(&acc[1], cs_sum);
+    }
+    __syncthreads();       // the staging arrays are rewritten for the next channel
     }
 }
 
@@ -276,7 +280,7 @@ void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const 
     const int oh = h - (kSsimK - 1), ow = w - (kSsimK - 1);
     A.ntx = (ow + kSsimT - 1) / kSsimT;
     const int nty = (oh + kSsimT - 1) / kSsimT;
-    dim3 grid(A.ntx * nty, C, B);
+    dim3 grid(A.ntx * nty, interleaved ? 1 : C, B);
     if (interleaved) hipLaunchKernelGGL(k_ssim_level<true>, grid, dim3(256), 0, st, A);
     else hipLaunchKernelGGL(k_ssim_level<false>, grid, dim3(256), 0, st, A);
 }
