@@ -153,6 +153,16 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
     const int bx0 = blockIdx.x * 128, by0 = blockIdx.y * 16;
     const int tx0_l = bx0 / g.ctw[0], ty0_l = by0 / g.cth[0];
     const int tx0_c = (bx0 / RW) / g.ctw[1], ty0_c = (by0 / RH) / g.cth[1];
+    // A CLAHE tile is a quarter of the layer, so for all but tiny images the 128 x 16 block meets at most one tile boundary per
+    // axis and the tile of a pixel is a comparison; `wide` is uniform over the launch.  (An integer division per histogram
+    // update made this kernel VALU-bound.)
+    const bool wide = g.ctw[0] >= 128 && g.cth[0] >= 16 && g.ctw[1] * RW >= 128 && g.cth[1] * RH >= 16;
+    const int xb_l = (tx0_l + 1) * g.ctw[0], yb_l = (ty0_l + 1) * g.cth[0];
+    const int xb_c = (tx0_c + 1) * g.ctw[1], yb_c = (ty0_c + 1) * g.cth[1];
+    auto tile_lx = [&](int x) { return wide ? tx0_l + (x >= xb_l ? 1 : 0) : x / g.ctw[0]; };
+    auto tile_ly = [&](int y) { return wide ? ty0_l + (y >= yb_l ? 1 : 0) : y / g.cth[0]; };
+    auto tile_cx = [&](int x) { return wide ? tx0_c + (x >= xb_c ? 1 : 0) : x / g.ctw[1]; };
+    auto tile_cy = [&](int y) { return wide ? ty0_c + (y >= yb_c ? 1 : 0) : y / g.cth[1]; };
     int *ghist = do_hist ? tile_hist + (long long)b * 3 * 16 * 256 : nullptr;
 
     if (px < g.W && py < g.H) {
@@ -190,11 +200,11 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
             u.x = scale_u8(c0[r][0]); u.y = scale_u8(c0[r][1]); u.z = scale_u8(c0[r][2]); u.w = scale_u8(c0[r][3]);
             if (planes_u8) *reinterpret_cast<uchar4 *>(planes_u8 + o) = u;
             if (do_hist) {
-                int ty = (py + r) / g.cth[0];
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 0) / g.ctw[0], ty, u.x);
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 1) / g.ctw[0], ty, u.y);
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 2) / g.ctw[0], ty, u.z);
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, (px + 3) / g.ctw[0], ty, u.w);
+                int ty = tile_ly(py + r);
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 0), ty, u.x);
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 1), ty, u.y);
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 2), ty, u.z);
+                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 3), ty, u.w);
             }
         }
         // ---- layers 1, 2 (chroma): INTER_AREA box mean
@@ -222,8 +232,9 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
                 u.x = scale_u8(v[0]); u.y = scale_u8(v[1]);
                 if (planes_u8) *reinterpret_cast<uchar2 *>(planes_u8 + o) = u;
                 if (do_hist) {
-                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, cx / g.ctw[ch], cy[0] / g.cth[ch], u.x);
-                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, (cx + 1) / g.ctw[ch], cy[0] / g.cth[ch], u.y);
+                    const int tyc = tile_cy(cy[0]);          // layers 1 and 2 share their geometry
+                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx), tyc, u.x);
+                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx + 1), tyc, u.y);
                 }
             } else {
 #pragma unroll
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
                     if (planes_raw) planes_raw[o] = v[q];
                     unsigned char u = scale_u8(v[q]);
                     if (planes_u8) planes_u8[o] = u;
-                    if (do_hist) hist_add(s_hist, ghist, ch, tx0_c, ty0_c, cx / g.ctw[ch], y / g.cth[ch], u);
+                    if (do_hist) hist_add(s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx), tile_cy(y), u);
                 }
             }
         }
