@@ -143,13 +143,12 @@ __device__ __forceinline__ bool node_edge(const QtGeom &q, int l, const ChunkEdg
     }
 }
 
-__device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, int h, const ChunkEdges &E, const unsigned char *__restrict__ pyr, unsigned gidx)
+__device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, int h, const ChunkEdges &E, const unsigned char *__restrict__ pyr, unsigned gidx,
+                                               int cx, int cy)
 {
     CellNodes r;
     r.nsym = 0; r.syms = 0; r.leaf_lvl = -1;
     const int ltot = q.ltot[l], cell = q.cell, i = (int)(gidx & 3u);
-    int cx, cy;
-    morton_decode(gidx, cx, cy);
     int a = gidx == 0 ? ltot : min((int)(__ffs((int)gidx) - 1) >> 1, ltot);
     if (a < ltot) {
         // the level-a node exists only if its parent is in bounds and splits
@@ -179,6 +178,36 @@ __device__ __forceinline__ CellNodes eval_cell(const QtGeom &q, int l, int w, in
         }
     }
     return r;
+}
+
+// The four sibling cells of a lane.  Cell 0 may be the origin of nodes of any level (general walk); cells 1..3 can only
+// originate their own level-0 node, which exists iff the lane's level-1 node is in bounds and splits -- the same test
+// eval_cell makes, evaluated once for the three of them.
+__device__ __forceinline__ void eval_lane(const QtGeom &q, int l, int w, int h, const ChunkEdges &E, const unsigned char *__restrict__ pyr, unsigned chunk,
+                                          int lane, long long ncell2, CellNodes (&c)[4], int &cx0, int &cy0)
+{
+    int ccx, ccy, lx, ly;
+    morton_decode(chunk, ccx, ccy);
+    morton_decode((unsigned)lane, lx, ly);
+    cx0 = ccx * 16 + lx * 2; cy0 = ccy * 16 + ly * 2;
+    const unsigned g0 = chunk * 256u + (unsigned)lane * 4u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c[i].nsym = 0; c[i].syms = 0; c[i].leaf_lvl = -1; }
+    if ((long long)g0 >= ncell2) return;
+    c[0] = eval_cell(q, l, w, h, E, pyr, g0, cx0, cy0);
+    const int cell = q.cell;
+    bool split1 = 2 * cell > q.bmax;
+    if (!split1 && 2 * cell > q.bmin) split1 = E.e1;
+    if (!(split1 && cx0 * cell < w && cy0 * cell < h)) return;
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        if ((long long)(g0 + i) >= ncell2) continue;
+        const int cx = cx0 + (i & 1), cy = cy0 + (i >> 1);
+        c[i].nsym = 1;
+        if (cx * cell >= w || cy * cell >= h) c[i].syms = 2u;                                           // absent child '10'
+        else if (cell > q.bmax || (cell > q.bmin && ((E.e0 >> i) & 1u))) c[i].syms = 1u;                // '01'
+        else c[i].leaf_lvl = 0;                                                                         // '00'
+    }
 }
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
@@ -213,19 +242,19 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
     int nsz[kMaxSizes];
 #pragma unroll
     for (int k = 0; k < kMaxSizes; k++) nsz[k] = 0;
+    CellNodes cn[4];
+    int cx0, cy0;
+    eval_lane(q, l, g.w[l], g.h[l], E, pyr, chunk, lane, ncell2, cn, cx0, cy0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const unsigned gidx = chunk * 256u + lane * 4u + i;
-        if ((long long)gidx < ncell2) {
-            CellNodes c = eval_cell(q, l, g.w[l], g.h[l], E, pyr, gidx);
-            nsym += c.nsym;
-            if (c.leaf_lvl >= 0) {
-                nleaf++;
-                int s = q.cell << c.leaf_lvl;
-                ncoef += s * s;
+        const CellNodes &c = cn[i];
+        nsym += c.nsym;
+        if (c.leaf_lvl >= 0) {
+            nleaf++;
+            int s = q.cell << c.leaf_lvl;
+            ncoef += s * s;
 #pragma unroll
-                for (int k = 0; k < kMaxSizes; k++) nsz[k] += (c.leaf_lvl == k) ? 1 : 0;
-            }
+            for (int k = 0; k < kMaxSizes; k++) nsz[k] += (c.leaf_lvl == k) ? 1 : 0;
         }
     }
     nsym = wave_sum(nsym); nleaf = wave_sum(nleaf); ncoef = wave_sum(ncoef);
@@ -301,12 +330,11 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
     const ChunkEdges E = chunk_edges(g, q, l, b, qb.edge_bits, chunk, lane);
 
     CellNodes c[4];
+    int cx0, cy0;
+    eval_lane(q, l, g.w[l], g.h[l], E, pyr, chunk, lane, ncell2, c, cx0, cy0);
     int nsym = 0, nleaf = 0, ncoef = 0, n0 = 0;   // n0: level-0 leaves of this lane (a lane has at most one larger leaf, at cell 0)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const unsigned gidx = chunk * 256u + lane * 4u + i;
-        c[i].nsym = 0; c[i].syms = 0; c[i].leaf_lvl = -1;
-        if ((long long)gidx < ncell2) c[i] = eval_cell(q, l, g.w[l], g.h[l], E, pyr, gidx);
         nsym += c[i].nsym;
         if (c[i].leaf_lvl >= 0) { nleaf++; int s = q.cell << c[i].leaf_lvl; ncoef += s * s; }
         if (c[i].leaf_lvl == 0) n0++;
@@ -332,9 +360,7 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
         }
         sym_pos += c[i].nsym;
         if (c[i].leaf_lvl >= 0) {
-            const unsigned gidx = chunk * 256u + lane * 4u + i;
-            int cx, cy;
-            morton_decode(gidx, cx, cy);
+            const int cx = cx0 + (i & 1), cy = cy0 + (i >> 1);
             const int size = q.cell << c[i].leaf_lvl;
             if (leaf_pos < q.leaf_cap[l] && (long long)coef_pos + (long long)size * size <= q.coeff_cap[l]) {
                 reinterpret_cast<int4 *>(leaves)[leaf_pos] = make_int4(cx * q.cell, cy * q.cell, size, coef_pos);
