@@ -53,6 +53,7 @@ struct QtBuffers {
     unsigned char *pyr;     // [B][pyr_stride] (only levels >= 5 are used)
     const unsigned long long *edge_bits;   // [B][bpstride] final edge bit-plane
     int *chunk_cnt;         // [B][chunk_stride][kChunkInts]: counts, then exclusive offsets after the scan
+    unsigned short *lane_code;   // [B][chunk_stride][64]: what the count pass found per lane (quadtree.hip pack_lane)
     int *leaves;            // out [B][leaf_stride][4]
     unsigned char *states;  // out [B][state_stride]
     long long *counts;      // out [B][3][4]

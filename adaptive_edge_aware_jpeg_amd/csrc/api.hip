@@ -270,6 +270,7 @@ static void carve_qt(Carver &c, const Geom &g, const QtGeom &q, bool with_work, 
     c.take<int>(0);
     w.zero_end = c.base ? c.base + c.off : nullptr;
     w.qb.chunk_cnt = c.take<int>((long long)g.B * q.chunk_stride * kChunkInts);
+    w.qb.lane_code = c.take<unsigned short>((long long)g.B * q.chunk_stride * 64);
     if (with_work) {
         w.qb.work_count = c.take<int>((long long)g.B * 3 * kMaxSizes);
         for (int k = 0; k < q.nsizes; k++) {

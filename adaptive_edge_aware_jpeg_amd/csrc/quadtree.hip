@@ -210,6 +210,47 @@ __device__ __forceinline__ void eval_lane(const QtGeom &q, int l, int w, int h, 
     }
 }
 
+// The count pass leaves what it found for the emit pass in 12 bits per lane, so the emit pass neither re-reads the edge
+// bit-plane nor walks the levels again.  Cell 0 originates k >= 0 split symbols '01' followed by a leaf '00' (type 1), nothing
+// (type 2), or it is a single absent child '10' (type 3); cells 1..3 originate at most one symbol (0 none, 1 '00', 2 '01', 3 '10').
+__device__ __forceinline__ unsigned pack_lane(const CellNodes (&c)[4])
+{
+    unsigned code = 0;
+    if (c[0].nsym > 0) {
+        if (c[0].nsym == 1 && c[0].syms == 2u) code = 3u;
+        else {
+            const int k = c[0].nsym - (c[0].leaf_lvl >= 0 ? 1 : 0);
+            code = (c[0].leaf_lvl >= 0 ? 1u : 2u) | ((unsigned)k << 2);
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        const unsigned ci = c[i].nsym == 0 ? 0u : (c[i].syms == 2u ? 3u : c[i].syms == 1u ? 2u : 1u);
+        code |= ci << (4 + 2 * i);
+    }
+    return code;
+}
+
+__device__ __forceinline__ void unpack_lane(unsigned code, unsigned g0, int ltot, CellNodes (&c)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c[i].nsym = 0; c[i].syms = 0; c[i].leaf_lvl = -1; }
+    const unsigned t = code & 3u;
+    const int k = (int)((code >> 2) & 15u);
+    if (t == 3u) { c[0].nsym = 1; c[0].syms = 2u; }
+    else if (t != 0u) {
+        const int a = g0 == 0 ? ltot : min((int)(__ffs((int)g0) - 1) >> 1, ltot);      // level of the largest node originating here
+        c[0].syms = 0x55555555u & ((1u << (2 * k)) - 1u);
+        c[0].nsym = k + (t == 1u ? 1 : 0);
+        if (t == 1u) c[0].leaf_lvl = a - k;
+    }
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        const unsigned ci = (code >> (4 + 2 * i)) & 3u;
+        if (ci) { c[i].nsym = 1; c[i].syms = ci == 3u ? 2u : ci == 2u ? 1u : 0u; c[i].leaf_lvl = ci == 1u ? 0 : -1; }
+    }
+}
+
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
 #pragma unroll
@@ -229,7 +270,8 @@ __device__ __forceinline__ int wave_sum(int v)
 
 // pass 2: per-chunk totals (symbols, leaves, coefficients, leaves per block size); one wave per chunk
 __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsigned long long *__restrict__ edge_bits,
-                                                  const unsigned char *__restrict__ pyr_all, int *__restrict__ chunk_cnt)
+                                                  const unsigned char *__restrict__ pyr_all, int *__restrict__ chunk_cnt,
+                                                  unsigned short *__restrict__ lane_code)
 {
     const int l = blockIdx.y, b = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -245,6 +287,7 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
     CellNodes cn[4];
     int cx0, cy0;
     eval_lane(q, l, g.w[l], g.h[l], E, pyr, chunk, lane, ncell2, cn, cx0, cy0);
+    lane_code[((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * 64 + lane] = (unsigned short)pack_lane(cn);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const CellNodes &c = cn[i];
@@ -324,14 +367,13 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
     const int lane = threadIdx.x & 63;
     const unsigned chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
     if ((long long)chunk >= q.nchunk[l]) return;
-    const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
-    const unsigned char *pyr = qb.pyr + (long long)b * q.pyr_stride + q.pyr_off[l];
     const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
-    const ChunkEdges E = chunk_edges(g, q, l, b, qb.edge_bits, chunk, lane);
-
     CellNodes c[4];
-    int cx0, cy0;
-    eval_lane(q, l, g.w[l], g.h[l], E, pyr, chunk, lane, ncell2, c, cx0, cy0);
+    unpack_lane(qb.lane_code[((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * 64 + lane], chunk * 256u + (unsigned)lane * 4u, q.ltot[l], c);
+    int ccx, ccy, lx, ly;
+    morton_decode(chunk, ccx, ccy);
+    morton_decode((unsigned)lane, lx, ly);
+    const int cx0 = ccx * 16 + lx * 2, cy0 = ccy * 16 + ly * 2;
     int nsym = 0, nleaf = 0, ncoef = 0, n0 = 0;   // n0: level-0 leaves of this lane (a lane has at most one larger leaf, at cell 0)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -402,7 +444,7 @@ void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsig
 }
 void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_count, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, qb.edge_bits, qb.pyr, qb.chunk_cnt);
+    hipLaunchKernelGGL(k_qt_count, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, qb.edge_bits, qb.pyr, qb.chunk_cnt, qb.lane_code);
 }
 void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
