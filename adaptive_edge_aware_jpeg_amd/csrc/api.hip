@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -672,6 +673,11 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
         if (n == 0) break;
         const int *pc = ctx->h_flag + 1;
+        if (getenv("AEJ_DEBUG_HYST")) {       // diagnostic: tiles queued per pass
+            fprintf(stderr, "[aej] hysteresis work lists:");
+            for (int i = 0; i <= n; i++) fprintf(stderr, " %d", pc[i]);
+            fprintf(stderr, "\n");
+        }
         if (pc[n] == 0) {                       // converged within the speculative passes: remember how many were needed
             int used = n;
             while (used > 1 && pc[used - 1] == 0) used--;

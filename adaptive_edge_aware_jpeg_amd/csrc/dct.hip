@@ -40,10 +40,22 @@ __device__ __forceinline__ int zigzag_pos(int r, int c)
     return before + ((d & 1) ? (S - 1 - c) : (S - 1 - r));
 }
 
+// np.round(block / q).astype(int32): float64 quotient, round half to even (jpeg.py:499-502).
 __device__ __forceinline__ int quantise(float y, int q)
 {
     double v = (double)y / (double)q;
     return (int)rint(v);
+}
+
+// The same for the large (MFMA) blocks, where most coefficients are far below q / 2 and the result is 0 whatever the
+// quotient's last bits are: when that holds for the whole wave the float64 division (about 15 VALU instructions) is skipped.
+// 0.499f leaves the float32 rounding of the product and of q orders of magnitude of margin.  (Not used for blocks <= 16:
+// their waves rarely qualify and the test costs more than it saves, measured.)
+__device__ __forceinline__ int quantise_sparse(float y, int q)
+{
+    const bool tiny = fabsf(y) < 0.499f * (float)q;
+    if (__all(tiny)) return 0;
+    return quantise(y, q);
 }
 
 // Work items of one block size are the concatenation, over planes (b, l), of that plane's Morton-ordered leaf list.
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
             for (int r = 0; r < 16; r++) {
                 int row = (wi0 + t * (NT / TPW)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (WANT_DCT) a.dct_f32[out_base + row * S + J0 + li] = acc[t][r];
-                sQ[zigzag_pos<S>(row, J0 + li)] = quantise(acc[t][r], qv[t][r]);
+                sQ[zigzag_pos<S>(row, J0 + li)] = quantise_sparse(acc[t][r], qv[t][r]);
             }
         __syncthreads();
         for (int idx = tid * 4; idx < SS; idx += NTHREADS * 4)
