@@ -29,7 +29,7 @@ for k, d in out.items():
     d["hbm_bytes"] = d["read_bytes"] + d["write_bytes"]
 json.dump({"batch": B, "height": 2160, "width": 3840, "note": "per aej_encode_batch call; reads = 2 x FETCH_SIZE KB (gfx950 correction), writes = WRITE_SIZE KB",
            "kernels": out}, open("gpurun_out/hbm_traffic.json", "w"), indent=1, sort_keys=True)
-cal = out.get("k_color_planes<0, 2, 2>", {})
+cal = next((d for k, d in out.items() if k.startswith("k_color_planes<0, 2, 2")), {})
 print("calibration: k_color_planes read_bytes", cal.get("read_bytes"), "expected", B * 2160 * 3840 * 12)
 for k, d in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes"]):
     print(f"{k:34s} read {d['read_bytes']/1e9:7.3f} GB  write {d['write_bytes']/1e9:7.3f} GB")
