@@ -29,9 +29,22 @@ __global__ __launch_bounds__(256) void k_work_from_tables(Geom g, QtGeom q, cons
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         int4 lf = tab[i];
         int k = (31 - __clz(lf.z)) - bmin_log2;
-        if (k < 0 || k >= q.nsizes || !wp.w[k]) continue;
-        int pos = atomicAdd(&work_count[plane * kMaxSizes + k], 1);
-        reinterpret_cast<int4 *>(wp.w[k])[(long long)b * q.work_stride[k] + q.work_off[l][k] + pos] = make_int4(plane, lf.x, lf.y, lf.w);
+        if (k < 0 || k >= q.nsizes || !wp.w[k]) k = -1;
+        // one atomic per wave and block size instead of one per leaf (all lanes of a wave work on the same plane): a few
+        // counters shared by 10^5 leaves per image serialise otherwise.  List order is irrelevant to the decode.
+        const int lane = threadIdx.x & 63;
+        int pos = 0;
+        for (int kk = 0; kk < q.nsizes; kk++) {
+            const unsigned long long m = __ballot(k == kk);
+            if (m == 0) continue;
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&work_count[plane * kMaxSizes + kk], __popcll(m));
+            base = __shfl(base, leader);
+            if (k == kk) pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        }
+        if (k >= 0)
+            reinterpret_cast<int4 *>(wp.w[k])[(long long)b * q.work_stride[k] + q.work_off[l][k] + pos] = make_int4(plane, lf.x, lf.y, lf.w);
     }
 }
 
