@@ -30,7 +30,7 @@ struct aej_ctx {
     int *h_flag = nullptr;             // pinned host word for counter read-backs
     int last_hyst_passes = 0;
     int hyst_hint = 0;                 // passes the previous encode needed (speculative enqueue, verified at the end of the call)
-    int hyst_margin = 8;               // extra passes enqueued on top of the hint
+    int hyst_margin = 4;               // extra passes enqueued on top of the hint
     int hyst_enqueued = 0;             // passes enqueued speculatively by the current call (0 = verified path)
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;

@@ -666,6 +666,14 @@ __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed,
     return gL | gR;
 }
 
+// CHASE (passes >= 1, short work lists): when a tile's border changed, the wave does not queue ALL affected neighbours for the
+// next pass but processes one of them itself straight away (up to kChaseDepth tiles in a row), so a long thin contour advances
+// many tiles per pass instead of one and the number of (launch-latency-bound) passes drops.  Two waves may then work on the same
+// tile at the same time, so CHASE writes words with atomicOr and reads them with agent-scope (cache-bypassing) loads; a missed
+// update is always repaired because whoever changes a border re-queues or re-processes the neighbour behind it.
+constexpr int kChaseDepth = 32;
+
+template <bool CHASE>
 __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int pass, long long tiles_per_img, long long total_tiles)
 {
     const int lane = threadIdx.x & 63;
@@ -676,64 +684,95 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
     int *flags_nxt = cb.hflags + (long long)((pass + 1) & 1) * total_tiles;
     const int *list_cur = cb.hlist + (long long)(pass & 1) * total_tiles;
     int *list_nxt = cb.hlist + (long long)((pass + 1) & 1) * total_tiles;
+    auto ldw = [](const unsigned long long *p) -> unsigned long long {
+        if constexpr (CHASE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p;
+    };
 
     for (long long item = wave; item < n; item += nwaves) {
-        const long long T = pass == 0 ? item : (long long)list_cur[item];
+        long long T = pass == 0 ? item : (long long)list_cur[item];
         if (lane == 0) flags_cur[T] = 0;
-        const int b = (int)(T / tiles_per_img);
-        int l, tx, ty, ntx, nty, tbase;
-        if (!locate_tile(g, kHystTile, kHystTile, (int)(T - (long long)b * tiles_per_img), l, tx, ty, ntx, nty, tbase)) continue;
-        const int h = g.h[l], wpr = g.wpr[l];
-        unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
-        const unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
-        const int y = ty * 64 + lane;
-        const bool valid = y < h;
-        // tile-major layout: this tile's 64 row-words are contiguous; the left / right tiles are +-64 words away.
-        // All ten loads are unconditional (addresses clamped into the plane, results masked afterwards) so that they are in
-        // flight together: a wave pays one memory latency per tile instead of one per halo piece.
-        const int yc = valid ? y : h - 1;
-        const int xl = tx > 0 ? tx - 1 : 0, xr = tx + 1 < wpr ? tx + 1 : wpr - 1;
-        const int yt = ty > 0 ? ty * 64 - 1 : 0, yb = ty * 64 + 64 < h ? ty * 64 + 64 : h - 1;
-        const long long o = bp_index(ty * 64, tx, wpr) + lane;
-        unsigned long long S = sg[bp_index(yc, tx, wpr)], W = wk[bp_index(yc, tx, wpr)];
-        unsigned long long SLw = sg[bp_index(yc, xl, wpr)], SRw = sg[bp_index(yc, xr, wpr)];
-        unsigned long long Tm = sg[bp_index(yt, tx, wpr)], Tlw = sg[bp_index(yt, xl, wpr)], Trw = sg[bp_index(yt, xr, wpr)];
-        unsigned long long Bm = sg[bp_index(yb, tx, wpr)], Blw = sg[bp_index(yb, xl, wpr)], Brw = sg[bp_index(yb, xr, wpr)];
-        if (!valid) { S = 0; W = 0; SLw = 0; SRw = 0; }
-        const bool hasL = tx > 0, hasR = tx + 1 < wpr, hasT = ty > 0, hasB = ty * 64 + 64 < h;
-        unsigned long long SL = hasL ? SLw >> 63 : 0ull, SR = hasR ? SRw & 1ull : 0ull;
-        unsigned long long Tl = (hasT && hasL) ? Tlw >> 63 : 0ull, Tr = (hasT && hasR) ? Trw & 1ull : 0ull;
-        unsigned long long Bl = (hasB && hasL) ? Blw >> 63 : 0ull, Br = (hasB && hasR) ? Brw & 1ull : 0ull;
-        if (!hasT) Tm = 0;
-        if (!hasB) Bm = 0;
-        const unsigned long long S0 = S;
-        for (;;) {
-            unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
-            unsigned long long upL = __shfl_up(SL, 1), dnL = __shfl_down(SL, 1);
-            unsigned long long upR = __shfl_up(SR, 1), dnR = __shfl_down(SR, 1);
-            if (lane == 0) { up = Tm; upL = Tl; upR = Tr; }
-            if (lane == 63) { dn = Bm; dnL = Bl; dnR = Br; }
-            unsigned long long m = S | up | dn;
-            unsigned long long mm = m | (m << 1) | (m >> 1) | (SL | upL | dnL) | ((SR | upR | dnR) << 63);
-            unsigned long long seed = W & mm & ~S;
-            unsigned long long f = fill_runs(seed, W);
-            unsigned long long nS = S | f;
-            bool ch = nS != S;
-            S = nS;
-            if (!__any(ch)) break;
-        }
-        const unsigned long long diff = S ^ S0;
-        if (diff && valid) sg[o] = S;
-        // border ring of the tile: first/last valid row, first/last column
-        const int last_row = min(63, h - 1 - ty * 64);
-        const bool border = diff && ((diff & 0x8000000000000001ull) || lane == 0 || lane == last_row);
-        if (__any(border) && lane < 8) {
+        for (int depth = 0;; depth++) {
+            const int b = (int)(T / tiles_per_img);
+            int l, tx, ty, ntx, nty, tbase;
+            if (!locate_tile(g, kHystTile, kHystTile, (int)(T - (long long)b * tiles_per_img), l, tx, ty, ntx, nty, tbase)) break;
+            const int h = g.h[l], wpr = g.wpr[l];
+            unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
+            const unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
+            const int y = ty * 64 + lane;
+            const bool valid = y < h;
+            // tile-major layout: this tile's 64 row-words are contiguous; the left / right tiles are +-64 words away.
+            // All ten loads are unconditional (addresses clamped into the plane, results masked afterwards) so that they are in
+            // flight together: a wave pays one memory latency per tile instead of one per halo piece.
+            const int yc = valid ? y : h - 1;
+            const int xl = tx > 0 ? tx - 1 : 0, xr = tx + 1 < wpr ? tx + 1 : wpr - 1;
+            const int yt = ty > 0 ? ty * 64 - 1 : 0, yb = ty * 64 + 64 < h ? ty * 64 + 64 : h - 1;
+            const long long o = bp_index(ty * 64, tx, wpr) + lane;
+            unsigned long long S = ldw(&sg[bp_index(yc, tx, wpr)]), W = wk[bp_index(yc, tx, wpr)];
+            unsigned long long SLw = ldw(&sg[bp_index(yc, xl, wpr)]), SRw = ldw(&sg[bp_index(yc, xr, wpr)]);
+            unsigned long long Tm = ldw(&sg[bp_index(yt, tx, wpr)]), Tlw = ldw(&sg[bp_index(yt, xl, wpr)]), Trw = ldw(&sg[bp_index(yt, xr, wpr)]);
+            unsigned long long Bm = ldw(&sg[bp_index(yb, tx, wpr)]), Blw = ldw(&sg[bp_index(yb, xl, wpr)]), Brw = ldw(&sg[bp_index(yb, xr, wpr)]);
+            if (!valid) { S = 0; W = 0; SLw = 0; SRw = 0; }
+            const bool hasL = tx > 0, hasR = tx + 1 < wpr, hasT = ty > 0, hasB = ty * 64 + 64 < h;
+            unsigned long long SL = hasL ? SLw >> 63 : 0ull, SR = hasR ? SRw & 1ull : 0ull;
+            unsigned long long Tl = (hasT && hasL) ? Tlw >> 63 : 0ull, Tr = (hasT && hasR) ? Trw & 1ull : 0ull;
+            unsigned long long Bl = (hasB && hasL) ? Blw >> 63 : 0ull, Br = (hasB && hasR) ? Brw & 1ull : 0ull;
+            if (!hasT) Tm = 0;
+            if (!hasB) Bm = 0;
+            const unsigned long long S0 = S;
+            for (;;) {
+                unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
+                unsigned long long upL = __shfl_up(SL, 1), dnL = __shfl_down(SL, 1);
+                unsigned long long upR = __shfl_up(SR, 1), dnR = __shfl_down(SR, 1);
+                if (lane == 0) { up = Tm; upL = Tl; upR = Tr; }
+                if (lane == 63) { dn = Bm; dnL = Bl; dnR = Br; }
+                unsigned long long m = S | up | dn;
+                unsigned long long mm = m | (m << 1) | (m >> 1) | (SL | upL | dnL) | ((SR | upR | dnR) << 63);
+                unsigned long long seed = W & mm & ~S;
+                unsigned long long f = fill_runs(seed, W);
+                unsigned long long nS = S | f;
+                bool ch = nS != S;
+                S = nS;
+                if (!__any(ch)) break;
+            }
+            const unsigned long long diff = S ^ S0;
+            if (diff && valid) {
+                if constexpr (CHASE) atomicOr(&sg[o], S);
+                else sg[o] = S;
+            }
+            // which of the 8 neighbours see a changed pixel next to them: new bits in the first / last valid row (and their end
+            // columns for the diagonal neighbours), in the first / last column
+            const int last_row = min(63, h - 1 - ty * 64);
+            const unsigned long long dtop = __shfl(diff, 0), dbot = __shfl(diff, last_row);
+            const bool dl = __any((diff & 1ull) != 0), dr = __any((diff >> 63) != 0);
+            unsigned dirs = 0;       // bit order: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1)
+            if (dtop) dirs |= 2u | ((dtop & 1ull) ? 1u : 0u) | ((dtop >> 63) ? 4u : 0u);
+            if (dbot) dirs |= 64u | ((dbot & 1ull) ? 32u : 0u) | ((dbot >> 63) ? 128u : 0u);
+            if (dl) dirs |= 8u;
+            if (dr) dirs |= 16u;
+            // keep the in-bounds ones
             const int ox[8] = { -1, 0, 1, -1, 1, -1, 0, 1 }, oy[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
-            int nx = tx + ox[lane], ny = ty + oy[lane];
-            if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty) {
+            unsigned inb = 0;
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                const int nx = tx + ox[d], ny = ty + oy[d];
+                if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty) inb |= 1u << d;
+            }
+            dirs &= inb;
+            if (dirs == 0) break;
+            int chase = -1;
+            if (CHASE && depth < kChaseDepth) {
+                // prefer a side neighbour over a corner: 4 (right), 3 (left), 6 (down), 1 (up), then the corners
+                const unsigned pref = (dirs & 16u) ? 4u : (dirs & 8u) ? 3u : (dirs & 64u) ? 6u : (dirs & 2u) ? 1u : (unsigned)(__ffs((int)dirs) - 1);
+                chase = (int)pref;
+            }
+            if (lane < 8 && ((dirs >> lane) & 1u) && lane != chase) {
+                const int nx = tx + ox[lane], ny = ty + oy[lane];
                 long long nT = (long long)b * tiles_per_img + tbase + (long long)ny * ntx + nx;
                 if (atomicExch(&flags_nxt[nT], 1) == 0) list_nxt[atomicAdd(&cb.pass_count[pass + 1], 1)] = (int)nT;
             }
+            if (chase < 0) break;
+            T = (long long)b * tiles_per_img + tbase + (long long)(ty + oy[chase]) * ntx + (tx + ox[chase]);
         }
     }
 }
@@ -844,7 +883,8 @@ void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int
     long long blocks = pass == 0 ? (total + 3) / 4 : 512;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_hyst_pass, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, pass, t, total);
+    if (pass == 0) hipLaunchKernelGGL(k_hyst_pass<false>, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, pass, t, total);
+    else hipLaunchKernelGGL(k_hyst_pass<true>, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, pass, t, total);
 }
 
 static int expand_blocks(const Geom &g)
