@@ -587,23 +587,25 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
                     vle += wgt * (sl & M8);  vlo += wgt * ((sl >> 8) & M8);    // columns (-1, 1), (0, 2)
                     vre += wgt * (sr & M8);  vro += wgt * ((sr >> 8) & M8);    // columns ( 1, 3), (2, 4)
                 }
-                int dx[4], dy[4];
-                dx[0] = (int)(vre & 0xffffu) - (int)(vle & 0xffffu);
-                dx[1] = (int)(vro & 0xffffu) - (int)(vlo & 0xffffu);
-                dx[2] = (int)(vre >> 16) - (int)(vle >> 16);
-                dx[3] = (int)(vro >> 16) - (int)(vlo >> 16);
-                dy[0] = (int)(he[2] & 0xffffu) - (int)(he[0] & 0xffffu);
-                dy[1] = (int)(ho[2] & 0xffffu) - (int)(ho[0] & 0xffffu);
-                dy[2] = (int)(he[2] >> 16) - (int)(he[0] >> 16);
-                dy[3] = (int)(ho[2] >> 16) - (int)(ho[0] >> 16);
+                // the 16-bit fields are pixel pairs (0, 2) and (1, 3): gradients as packed int16 subtractions, then one
+                // (dx | dy << 16) word per pixel -- the format stage 2 reads -- whose dot product with itself is the magnitude
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                auto sub2 = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); };
+                const unsigned dxe = sub2(vre, vle), dxo = sub2(vro, vlo);             // dx of pixels (0, 2), (1, 3)
+                const unsigned dye = sub2(he[2], he[0]), dyo = sub2(ho[2], ho[0]);     // dy
+                unsigned gv[4];
+                gv[0] = __builtin_amdgcn_perm(dye, dxe, 0x05040100u);                  // low halves:  dx0 | dy0 << 16
+                gv[2] = __builtin_amdgcn_perm(dye, dxe, 0x07060302u);                  // high halves: dx2 | dy2 << 16
+                gv[1] = __builtin_amdgcn_perm(dyo, dxo, 0x05040100u);
+                gv[3] = __builtin_amdgcn_perm(dyo, dxo, 0x07060302u);
                 const int gy = y0 - 1 + jm;
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int gx = x0 - 4 + 4 * i4 + p;
-                    int m = dx[p] * dx[p] + dy[p] * dy[p];
+                    int m = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, gv[p]), __builtin_bit_cast(s16x2, gv[p]), 0, false);   // dx^2 + dy^2
                     if (!aligned && (gx < 0 || gx >= w || gy < 0 || gy >= h)) m = 0;      // magnitude outside the image is 0
                     L.M[jm * kNMW + 4 * i4 + p] = m;
-                    L.G[jm * kNMW + 4 * i4 + p] = (dx[p] & 0xffff) | (dy[p] << 16);
+                    L.G[jm * kNMW + 4 * i4 + p] = (int)gv[p];
                 }
             }
         }
