@@ -573,19 +573,23 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
             if (idx < kNMH * kNW4) {
                 const int jm = idx / kNW4, i4 = idx - jm * kNW4;
                 const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kNW4 - 1 ? i4 + 1 : kNW4 - 1;   // edge dwords feed unused columns only
-                const unsigned int M8 = 0x00FF00FFu;
+                // Per source row, four words of two 16-bit fields each, made by byte permutes (selector 0x0C = zero byte) from the
+                // 6 bytes at columns -1 .. 4:  LE = (-1, 1), A = (0, 2), B = (1, 3), RO = (2, 4).  Outputs 0 and 2 have
+                // (left, mid, right) = (LE, A, B), outputs 1 and 3 have (A, B, RO).
                 unsigned int he[3], ho[3], vle = 0, vlo = 0, vre = 0, vro = 0;
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
                     const unsigned int *row = L.U + (jm + r) * kNW4;
-                    unsigned int m = row[i4], lf = row[il], rt = row[ir];
-                    unsigned int sl = __builtin_amdgcn_alignbyte(m, lf, 3);    // columns -1, 0, 1, 2
-                    unsigned int sr = __builtin_amdgcn_alignbyte(rt, m, 1);    // columns  1, 2, 3, 4
-                    he[r] = (sl & M8) + 2u * (m & M8) + (sr & M8);             // horizontal [1 2 1] at columns 0, 2
-                    ho[r] = ((sl >> 8) & M8) + 2u * ((m >> 8) & M8) + ((sr >> 8) & M8);   // columns 1, 3
-                    const unsigned int wgt = r == 1 ? 2u : 1u;                 // vertical [1 2 1]
-                    vle += wgt * (sl & M8);  vlo += wgt * ((sl >> 8) & M8);    // columns (-1, 1), (0, 2)
-                    vre += wgt * (sr & M8);  vro += wgt * ((sr >> 8) & M8);    // columns ( 1, 3), (2, 4)
+                    const unsigned int m = row[i4], lf = row[il], rt = row[ir];
+                    const unsigned int LE = __builtin_amdgcn_perm(m, lf, 0x0C050C03u);
+                    const unsigned int A = m & 0x00FF00FFu;
+                    const unsigned int B = __builtin_amdgcn_perm(m, m, 0x0C030C01u);
+                    const unsigned int RO = __builtin_amdgcn_perm(rt, m, 0x0C040C02u);
+                    he[r] = LE + 2u * A + B;                  // horizontal [1 2 1] at columns 0, 2
+                    ho[r] = A + 2u * B + RO;                  // columns 1, 3
+                    const unsigned int wgt = r == 1 ? 2u : 1u;    // vertical [1 2 1]
+                    vle += wgt * LE;  vre += wgt * B;         // left / right columns of outputs 0, 2
+                    vlo += wgt * A;   vro += wgt * RO;        // of outputs 1, 3
                 }
                 // the 16-bit fields are pixel pairs (0, 2) and (1, 3): gradients as packed int16 subtractions, then one
                 // (dx | dy << 16) word per pixel -- the format stage 2 reads -- whose dot product with itself is the magnitude
