@@ -275,13 +275,16 @@ __device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb,
         unsigned int he[3], ho[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
+            // two 16-bit fields per word by byte permutes (selector 0x0C = zero byte) of the 6 bytes at columns -1 .. 4:
+            // LE = (-1, 1), A = (0, 2), B = (1, 3), RO = (2, 4); outputs 0, 2 = LE + 2A + B, outputs 1, 3 = A + 2B + RO
             const unsigned int *row = L.A + (j + r) * kAW4;
-            unsigned int m = row[i4], lf = row[il], rt = row[ir];
-            unsigned int sl = __builtin_amdgcn_alignbyte(m, lf, 3);    // bytes b[-1], b0, b1, b2
-            unsigned int sr = __builtin_amdgcn_alignbyte(rt, m, 1);    // bytes b1, b2, b3, b4
-            const unsigned int M = 0x00FF00FFu;
-            he[r] = (sl & M) + 2u * (m & M) + (sr & M);
-            ho[r] = ((sl >> 8) & M) + 2u * ((m >> 8) & M) + ((sr >> 8) & M);
+            const unsigned int m = row[i4], lf = row[il], rt = row[ir];
+            const unsigned int LE = __builtin_amdgcn_perm(m, lf, 0x0C050C03u);
+            const unsigned int A = m & 0x00FF00FFu;
+            const unsigned int B = __builtin_amdgcn_perm(m, m, 0x0C030C01u);
+            const unsigned int RO = __builtin_amdgcn_perm(rt, m, 0x0C040C02u);
+            he[r] = LE + 2u * A + B;
+            ho[r] = A + 2u * B + RO;
         }
         unsigned int ve = he[0] + 2u * he[1] + he[2] + 0x00080008u;
         unsigned int vo = ho[0] + 2u * ho[1] + ho[2] + 0x00080008u;
