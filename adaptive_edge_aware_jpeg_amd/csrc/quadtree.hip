@@ -300,9 +300,23 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
             for (int k = 0; k < kMaxSizes; k++) nsz[k] += (c.leaf_lvl == k) ? 1 : 0;
         }
     }
-    nsym = wave_sum(nsym); nleaf = wave_sum(nleaf); ncoef = wave_sum(ncoef);
+    // wave totals: the symbol count (< 1024 per chunk) and the per-size leaf counts (<= 256) travel three to a word through the
+    // butterfly; leaves and coefficients follow from the per-size counts
+    static_assert(kMaxSizes <= 8, "three packed words hold the symbol count and 8 sizes");
+    unsigned pk[3] = { (unsigned)nsym, 0u, 0u };
 #pragma unroll
-    for (int k = 0; k < kMaxSizes; k++) nsz[k] = k < q.nsizes ? wave_sum(nsz[k]) : 0;
+    for (int k = 0; k < kMaxSizes; k++) pk[(k + 1) / 3] |= (unsigned)nsz[k] << (10 * ((k + 1) % 3));
+#pragma unroll
+    for (int i = 0; i < 3; i++) pk[i] = (unsigned)wave_sum((int)pk[i]);
+    nsym = (int)(pk[0] & 1023u);
+    nleaf = 0; ncoef = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxSizes; k++) {
+        nsz[k] = k < q.nsizes ? (int)((pk[(k + 1) / 3] >> (10 * ((k + 1) % 3))) & 1023u) : 0;
+        const int sz = q.cell << k;
+        nleaf += nsz[k];
+        ncoef += nsz[k] * sz * sz;
+    }
     if (lane == 0) {
         int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
         o[0] = nsym; o[1] = nleaf; o[2] = ncoef; o[3] = 0;
@@ -381,10 +395,13 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
         if (c[i].leaf_lvl >= 0) { nleaf++; int s = q.cell << c[i].leaf_lvl; ncoef += s * s; }
         if (c[i].leaf_lvl == 0) n0++;
     }
-    int sym_pos = coff[0] + wave_incl_scan(nsym, lane) - nsym;
-    int leaf_pos = coff[1] + wave_incl_scan(nleaf, lane) - nleaf;
+    // one scan for the three small counters (prefix sums < 1024 each), one for the coefficient offsets
+    const int pk = nsym | nleaf << 10 | n0 << 20;
+    const int pks = wave_incl_scan(pk, lane) - pk;
+    int sym_pos = coff[0] + (pks & 1023);
+    int leaf_pos = coff[1] + ((pks >> 10) & 1023);
+    int rank0 = (pks >> 20) & 1023;
     int coef_pos = coff[2] + wave_incl_scan(ncoef, lane) - ncoef;
-    int rank0 = wave_incl_scan(n0, lane) - n0;
     const int big = c[0].leaf_lvl;                     // > 0 when this lane holds a leaf larger than a cell
     int rank_big = 0;
     for (int k = 1; k < q.nsizes; k++) {
