@@ -129,6 +129,34 @@ def test_hysteresis_long_chain(A, oracle):
     assert np.array_equal(got, oracle.edge_pipeline(plane))
 
 
+@pytest.mark.parametrize("kind", ["noise", "maze", "texture"])
+def test_hysteresis_many_tiles_concurrent_chases(A, oracle, kind):
+    """Passes >= 1 let a wave follow a contour through up to 32 tiles while other waves work on the same tiles (atomicOr
+    writes); the fix-point must still be OpenCV's flood fill.  Large planes whose final edges are mostly weak pixels promoted
+    through long chains (maze: 1.8 K strong seeds -> 155 K edge pixels along 180 serpentine lines of slowly rising contrast)."""
+    H, W = 1100, 1500
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    if kind == "noise":
+        plane = rng.random((H, W), dtype=np.float32)
+    elif kind == "texture":
+        plane = (0.12 + 0.1 * np.sin(xx / 11.0 + yy / 17.0) * np.cos(yy / 7.0)).astype(np.float32)
+    else:
+        plane = np.repeat(np.linspace(0.0, 0.2, H, dtype=np.float32)[:, None], W, axis=1).copy()
+        amp = 0.036 + (0.05 - 0.036) * np.arange(W, dtype=np.float32) / W
+        for k, y in enumerate(range(8, H - 8, 6)):
+            plane[y, 6:W - 6] += amp[6:W - 6]
+            x = W - 7 if k % 2 == 0 else 6
+            plane[y:y + 6, x] += amp[x]
+        plane = plane.astype(np.float32)
+    edge, stages, thr = oracle.edge_pipeline(plane, return_stages=True)
+    _, nms = oracle.canny(stages[3], thr[0], thr[1], return_nms=True)
+    strong, weak = int((nms == 2).sum()), int((nms == 0).sum())
+    assert weak > 50000 and int(edge.sum()) > strong + 40000, "the pattern must depend on hysteresis propagation"
+    got = A.EdgeDetection.canny(plane).astype(np.uint8)
+    assert np.array_equal(got, edge)
+
+
 def test_speculative_hysteresis_falls_back_when_the_hint_is_too_small(A, ctx, oracle):
     """aej_encode_batch enqueues as many hysteresis passes as the previous call needed (+ margin) without reading back and
     verifies at the end; when they were too few it must finish the hysteresis and redo quadtree + DCT."""
