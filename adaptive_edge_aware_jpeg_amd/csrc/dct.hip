@@ -191,6 +191,77 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 4 x 4 blocks (the most numerous leaves): one THREAD per leaf, everything in registers.  Four 16-byte row loads, both
+// products as the same k-ordered fma chains, 16 quotients, zigzag as a compile-time permutation, four 16-byte stores
+// (consecutive leaves of a Morton-ordered list have consecutive coefficient offsets, so a wave writes 4 KiB contiguously).
+// No LDS transpose, no barriers; 25 instead of 61 VALU instructions per pixel.
+// ------------------------------------------------------------------------------------------------
+template <bool WANT_DCT>
+__global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long long max_items)
+{
+    __shared__ float sD[16];
+    __shared__ int sQm[3 * 16];
+    __shared__ LayerTab lt;
+    extern __shared__ int s_pref[];
+    const int tid = threadIdx.x;
+    if (tid < 16) sD[tid] = a.D[tid];
+    if (tid < 48) sQm[tid] = a.qm[tid / 16] ? a.qm[tid / 16][tid % 16] : 1;
+    dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
+    long long count = s_pref[a.nplanes];
+    if (count > max_items) count = max_items;
+    const long long wstride = q.work_stride[a.k];
+    float D[4][4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) D[i >> 2][i & 3] = sD[i];
+    for (long long item = (long long)blockIdx.x * 256 + tid; item < count; item += (long long)gridDim.x * 256) {
+        const int4 cur = fetch_item(a, wstride, lt, s_pref, item);
+        const int b = cur.x / 3, layer = cur.x - b * 3;
+        const int w = lt.w[layer], h = lt.h[layer];
+        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+        const int hc = min(4, h - cur.z), wc = min(4, w - cur.y);
+        float x[4][4];
+        if (hc == 4 && wc == 4 && (w & 3) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + (long long)(cur.z + r) * w + cur.y);
+                x[r][0] = v.x; x[r][1] = v.y; x[r][2] = v.z; x[r][3] = v.w;
+            }
+        } else {                              // clipped at the plane border (np.pad reflect) or unaligned rows
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    x[r][c] = src[(long long)(cur.z + reflect_pad_idx(r, hc)) * w + cur.y + reflect_pad_idx(c, wc)];
+        }
+        float T[4][4];                        // T[i][j] = sum_k D[i][k] X[k][j]
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc = __builtin_fmaf(D[i][k], x[k][j], acc);
+                T[i][j] = acc;
+            }
+        const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
+        int out[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {   // Y[i][jj] = sum_k T[i][k] D[jj][k]
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc = __builtin_fmaf(T[i][k], D[jj][k], acc);
+                if (WANT_DCT) a.dct_f32[out_base + i * 4 + jj] = acc;
+                out[zigzag_pos<4>(i, jj)] = quantise(acc, sQm[layer * 16 + i * 4 + jj]);
+            }
+        int4 *dst = reinterpret_cast<int4 *>(a.coeffs + out_base);     // offsets are sums of squares of sizes >= 2: multiples of 4
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[r] = make_int4(out[4 * r], out[4 * r + 1], out[4 * r + 2], out[4 * r + 3]);
+    }
+}
+
 // LDS-DMA (global_load_lds): per-lane global source, LDS destination = wave-uniform base + lane * size.
 __device__ __forceinline__ void glds16(const float *g, float *lds_wave_base)
 {
@@ -412,7 +483,10 @@ void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const 
     else launch_mfma_t<S, false>(st, g, q, a, max_items, cap(1, HI))
     switch (size) {
     case 2: AEJ_SMALL(2, 128, 2048); break;
-    case 4: AEJ_SMALL(4, 64, 4096); break;
+    case 4:
+        if (wd) hipLaunchKernelGGL((k_dct4<true>), dim3(cap(256, 8192)), dim3(256), pref, st, g, q, a, max_items);
+        else hipLaunchKernelGGL((k_dct4<false>), dim3(cap(256, 8192)), dim3(256), pref, st, g, q, a, max_items);
+        break;
     case 8: AEJ_SMALL(8, 32, 4096); break;
     case 16: AEJ_SMALL(16, 16, 4096); break;
     case 32: AEJ_MFMA(32, 4096); break;
