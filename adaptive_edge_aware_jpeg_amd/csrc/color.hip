@@ -13,16 +13,17 @@
 
 namespace aej {
 
-__device__ __forceinline__ void to_xyz(float r, float g, float b, float &X, float &Y, float &Z)   // xyz.py:27-32, 63-64
+__device__ __forceinline__ void to_xyz(float lr, float lg, float lb, float &X, float &Y, float &Z)   // xyz.py:27-32, 63-64 after linearisation
 {
-    float lr = srgb_to_linear(r), lg = srgb_to_linear(g), lb = srgb_to_linear(b);
     X = dot3(F(0.4124564), F(0.3575761), F(0.1804375), lr, lg, lb);
     Y = dot3(F(0.2126729), F(0.7151522), F(0.0721750), lr, lg, lb);
     Z = dot3(F(0.0193339), F(0.1191920), F(0.9503041), lr, lg, lb);
 }
 
+// colour transform from LINEAR rgb (spaces >= 3: everything after common.py:34-60's sRGB linearisation) or from sRGB
+// itself (the three matrix spaces)
 template <int SPACE>
-__device__ __forceinline__ void color_px(float r, float g, float b, float &o0, float &o1, float &o2)
+__device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o0, float &o1, float &o2)
 {
     if constexpr (SPACE == 0) {          // YCbCr, ycbcr.py:25-30, 61
         o0 = dot3(F(0.299000), F(0.587000), F(0.114000), r, g, b);
@@ -90,6 +91,13 @@ __device__ __forceinline__ void color_px(float r, float g, float b, float &o0, f
     }
 }
 
+template <int SPACE>
+__device__ __forceinline__ void color_px(float r, float g, float b, float &o0, float &o1, float &o2)
+{
+    if constexpr (SPACE >= 3) color_px_lin<SPACE>(srgb_to_linear(r), srgb_to_linear(g), srgb_to_linear(b), o0, o1, o2);
+    else color_px_lin<SPACE>(r, g, b, o0, o1, o2);
+}
+
 // a-3: (v*255).astype(uint8): float32 multiply, truncate toward zero, keep the low byte
 __device__ __forceinline__ unsigned char scale_u8(float v)
 {
@@ -143,12 +151,18 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
     const int py = (blockIdx.y * 8 + (tid >> 5)) * 2;
     const bool do_hist = tile_hist != nullptr;
     constexpr bool kU8 = sizeof(IN) == 1;
-    __shared__ float s_u8f[kU8 ? 256 : 1];
-    if (kU8) s_u8f[tid] = (float)tid / 255.0f;
+    // Spaces with an sRGB linearisation (a float64 pow per channel): images that came from 8-bit files hold only the 256
+    // values k / 255.0f, so the block tabulates srgb_to_linear of exactly those -- computed by the same device function -- and a
+    // pixel row whose 12 inputs all are such values (checked by comparing with the table of inputs) skips its 12 pows.
+    constexpr bool kLin = SPACE >= 3;
+    __shared__ float s_u8f[(kU8 || kLin) ? 256 : 1];
+    __shared__ float s_lin[kLin ? 256 : 1];
+    if (kU8 || kLin) s_u8f[tid] = (float)tid / 255.0f;
+    if (kLin) s_lin[tid] = srgb_to_linear((float)tid / 255.0f);
     if (do_hist) {
         for (int i = tid; i < 3 * 4 * 256; i += 256) s_hist[i] = 0;
     }
-    if (do_hist || kU8) __syncthreads();
+    if (do_hist || kU8 || kLin) __syncthreads();
     // first CLAHE tile touched by this block, per layer
     const int bx0 = blockIdx.x * 128, by0 = blockIdx.y * 16;
     const int tx0_l = bx0 / g.ctw[0], ty0_l = by0 / g.cth[0];
@@ -174,15 +188,34 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
                 const unsigned int *p = reinterpret_cast<const unsigned int *>(rgb + (((long long)b * g.H + (py + r)) * g.W + px) * 3);
                 const unsigned int d[3] = { p[0], p[1], p[2] };
 #pragma unroll
-                for (int k = 0; k < 12; k++) in[k] = s_u8f[(d[k >> 2] >> (8 * (k & 3))) & 0xffu];
+                for (int k = 0; k < 12; k++) in[k] = (kLin ? s_lin : s_u8f)[(d[k >> 2] >> (8 * (k & 3))) & 0xffu];
             } else {
                 const float4 *p = reinterpret_cast<const float4 *>(rgb + (((long long)b * g.H + (py + r)) * g.W + px) * 3);
                 float4 a = p[0], bq = p[1], c = p[2];
                 in[0] = a.x; in[1] = a.y; in[2] = a.z; in[3] = a.w; in[4] = bq.x; in[5] = bq.y; in[6] = bq.z; in[7] = bq.w;
                 in[8] = c.x; in[9] = c.y; in[10] = c.z; in[11] = c.w;
             }
+            if constexpr (kLin && !kU8) {
+                float lin[12];
+                bool hit = true;
 #pragma unroll
-            for (int k = 0; k < 4; k++) color_px<SPACE>(in[3 * k], in[3 * k + 1], in[3 * k + 2], c0[r][k], c1[r][k], c2[r][k]);
+                for (int k = 0; k < 12; k++) {
+                    int idx = __float2int_rn(in[k] * 255.0f);
+                    idx = idx < 0 ? 0 : idx > 255 ? 255 : idx;
+                    hit = hit && (s_u8f[idx] == in[k]);
+                    lin[k] = s_lin[idx];
+                }
+                if (!__all(hit)) {        // some value of this wave's rows is not k / 255.0f: those lanes take the float64 pow
+                    if (!hit) {
+#pragma unroll
+                        for (int k = 0; k < 12; k++) lin[k] = srgb_to_linear(in[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 12; k++) in[k] = lin[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) color_px_lin<SPACE>(in[3 * k], in[3 * k + 1], in[3 * k + 2], c0[r][k], c1[r][k], c2[r][k]);
         }
         const long long ibase = (long long)b * g.pstride;
         // ---- layer 0 (luma): ratio 1x1 => copy

@@ -64,7 +64,11 @@ def synth_batch(torch, B, H, W, seed, device):
         g.manual_seed(seed + b)
         img += torch.randn(img.shape, generator=g, device=device) * 1.5
         img.round_().clamp_(0, 255)
-        img /= 255.0
+    # uint8 levels -> float32 exactly as image.py:80 does (`astype(np.float32) / 255.0`, a true IEEE division): torch divides
+    # by a scalar through a reciprocal multiply, which is 1 ulp off for some levels, so the quotients come from a NumPy table
+    lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(device)
+    for b in range(B):
+        out[b] = lut[out[b].to(torch.int64)]
     return out
 
 

@@ -64,10 +64,21 @@ def test_colour_round_trip_closure_property(A, oracle):
 
 
 # ------------------------------------------------------------------ a-2/a-3/a-11 fused plane kernel
-@pytest.mark.parametrize("space,H,W", [("YCbCr", 64, 128), ("YCoCg", 130, 260), ("ICtCp", 34, 72), ("OKLAB", 18, 36), ("JzAzBz", 16, 20)])
-def test_colour_planes_kernel(A, ctx, oracle, space, H, W):
+@pytest.mark.parametrize("space,H,W,levels", [("YCbCr", 64, 128, "u8"), ("YCoCg", 130, 260, "u8"), ("ICtCp", 34, 72, "u8"), ("OKLAB", 18, 36, "u8"),
+                                                ("JzAzBz", 16, 20, "u8"), ("OKLAB", 64, 256, "float"), ("ICaCb", 32, 128, "mixed"),
+                                                ("JzAzBz", 48, 132, "mixed")])
+def test_colour_planes_kernel(A, ctx, oracle, space, H, W, levels):
+    """levels: 'u8' = every channel is k / 255 (the tabulated sRGB linearisation serves the whole image), 'float' = arbitrary
+    float32 values in [0, 1) (every lane takes the float64 pow), 'mixed' = both within the same waves."""
     import torch
     img = synth(oracle, H, W, 5)
+    if levels != "u8":
+        rnd = np.random.default_rng(3).random((H, W, 3), dtype=np.float32)
+        if levels == "float":
+            img = rnd
+        else:
+            pick = np.random.default_rng(4).random((H, W, 1)) < 0.3
+            img = np.where(pick, rnd, img).astype(np.float32)
     j = A.Jpeg(A.JpegCompressionSettings(space))
     c = j._bind()
     plan = c.plan(1, H, W)
