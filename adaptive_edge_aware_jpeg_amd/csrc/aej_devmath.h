@@ -6,55 +6,53 @@
 namespace aej {
 
 // ------------------------------------------------------------------------------------------------
-// deterministic pow (same recipe as the contract in DESIGN.md: atanh-series log2, Taylor exp2)
+// deterministic pow: exp2(y * log2(x)) from table look-ups and fma chains only (no division), the same recipe and the same
+// generated tables (tools/gen_pow_tables.py) as the CPU side of the contract in DESIGN.md:
+//   log2(x): x = 2^e m, i = top 6 mantissa bits, r = fma(m, INVC[i], -1), |r| <= 2^-7; (e + LOGC[i]) + r P(r)
+//   exp2(t): k = rint(64 t), r = t - k / 64 (exact), j = k & 63, n = k >> 6; 2^n (T[j] + T[j] (r Q(r)))
 // ------------------------------------------------------------------------------------------------
+}  // namespace aej
+#include "pow_tables.h"
+namespace aej {
+
 __device__ __forceinline__ double dev_log2(double x)
 {
     long long b = __double_as_longlong(x);
     int e = (int)(b >> 52) - 1023;
+    int i = (int)((b >> 46) & 63ll);
     double m = __longlong_as_double((b & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll);
-    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
-    double z = (m - 1.0) / (m + 1.0);
-    double z2 = z * z;
-    double p = 2.0 / 25.0;
-    p = fma(p, z2, 2.0 / 23.0);
-    p = fma(p, z2, 2.0 / 21.0);
-    p = fma(p, z2, 2.0 / 19.0);
-    p = fma(p, z2, 2.0 / 17.0);
-    p = fma(p, z2, 2.0 / 15.0);
-    p = fma(p, z2, 2.0 / 13.0);
-    p = fma(p, z2, 2.0 / 11.0);
-    p = fma(p, z2, 2.0 / 9.0);
-    p = fma(p, z2, 2.0 / 7.0);
-    p = fma(p, z2, 2.0 / 5.0);
-    p = fma(p, z2, 2.0 / 3.0);
-    p = fma(p, z2, 2.0);
-    double lnm = z * p;
-    return fma(lnm, 1.4426950408889634, (double)e);
+    double r = fma(m, POW_INVC[i], -1.0);
+    double p = POW_L[7];
+    p = fma(p, r, POW_L[6]);
+    p = fma(p, r, POW_L[5]);
+    p = fma(p, r, POW_L[4]);
+    p = fma(p, r, POW_L[3]);
+    p = fma(p, r, POW_L[2]);
+    p = fma(p, r, POW_L[1]);
+    p = fma(p, r, POW_L[0]);
+    double lo = r * p;
+    double hi = (double)e + POW_LOGC[i];
+    return hi + lo;
 }
 
 __device__ __forceinline__ double dev_exp2(double t)
 {
-    double n = rint(t);
-    double r = (t - n) * 0.6931471805599453;
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    long long ni = (long long)n;
+    double kd = rint(t * 64.0);
+    double r = fma(kd, -0.015625, t);
+    long long k = (long long)kd;
+    int j = (int)(k & 63ll);
+    long long ni = k >> 6;
+    double q = POW_E[5];
+    q = fma(q, r, POW_E[4]);
+    q = fma(q, r, POW_E[3]);
+    q = fma(q, r, POW_E[2]);
+    q = fma(q, r, POW_E[1]);
+    q = fma(q, r, POW_E[0]);
+    double s = r * q;
+    double v = fma(POW_EXP2T[j], s, POW_EXP2T[j]);
     if (ni < -1022) return 0.0;
     if (ni > 1023) return __longlong_as_double(0x7FF0000000000000ll);
-    return p * __longlong_as_double((ni + 1023) << 52);
+    return v * __longlong_as_double((ni + 1023) << 52);
 }
 
 __device__ __forceinline__ double dev_pow(double x, double y)

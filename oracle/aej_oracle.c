@@ -33,9 +33,17 @@
 #endif
 
 /* ------------------------------------------------------------------------------------------
- * Deterministic pow(): only IEEE-754 +,-,*,/,fma,rint on doubles, in a fixed order, so that the
- * HIP kernels (which restate the same recipe) produce the same bits.  |rel err| ~ 1e-15.
+ * Deterministic pow(): only IEEE-754 +,-,*,fma,rint on doubles, integer bit operations and table
+ * look-ups, in a fixed order, so that the HIP kernels (which restate the same recipe with the same
+ * generated tables, tools/gen_pow_tables.py) produce the same bits.  |rel err| ~ 2e-16 for the
+ * arguments of the colour code.
+ *   log2(x): x = 2^e m, i = top 6 mantissa bits, r = fma(m, INVC[i], -1), |r| <= 2^-7;
+ *            log2(x) = (e + LOGC[i]) + r P(r), P = degree-7 Taylor polynomial of log2(1 + r) / r
+ *   exp2(t): k = rint(64 t), r = t - k / 64 (exact), j = k & 63, n = k >> 6;
+ *            exp2(t) = 2^n (T[j] + T[j] (r Q(r))), Q = degree-5 Taylor polynomial of (2^r - 1) / r
  * ---------------------------------------------------------------------------------------- */
+#include "aej_pow_tables.h"
+
 static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 static inline double u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 
@@ -43,50 +51,40 @@ static double orc_log2(double x) /* x > 0, normal */
 {
     uint64_t b = d2u(x);
     int e = (int)(b >> 52) - 1023;
+    int i = (int)((b >> 46) & 63u);
     double m = u2d((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull); /* [1,2) */
-    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
-    double z = (m - 1.0) / (m + 1.0);
-    double z2 = z * z;
-    /* ln(m) = 2 z (1 + z2/3 + z2^2/5 + ... ), Horner with fma, 12 terms */
-    double p = 2.0 / 25.0;
-    p = fma(p, z2, 2.0 / 23.0);
-    p = fma(p, z2, 2.0 / 21.0);
-    p = fma(p, z2, 2.0 / 19.0);
-    p = fma(p, z2, 2.0 / 17.0);
-    p = fma(p, z2, 2.0 / 15.0);
-    p = fma(p, z2, 2.0 / 13.0);
-    p = fma(p, z2, 2.0 / 11.0);
-    p = fma(p, z2, 2.0 / 9.0);
-    p = fma(p, z2, 2.0 / 7.0);
-    p = fma(p, z2, 2.0 / 5.0);
-    p = fma(p, z2, 2.0 / 3.0);
-    p = fma(p, z2, 2.0);
-    double lnm = z * p;
-    return fma(lnm, 1.4426950408889634, (double)e);
+    double r = fma(m, POW_INVC[i], -1.0);
+    double p = POW_L[7];
+    p = fma(p, r, POW_L[6]);
+    p = fma(p, r, POW_L[5]);
+    p = fma(p, r, POW_L[4]);
+    p = fma(p, r, POW_L[3]);
+    p = fma(p, r, POW_L[2]);
+    p = fma(p, r, POW_L[1]);
+    p = fma(p, r, POW_L[0]);
+    double lo = r * p;
+    double hi = (double)e + POW_LOGC[i];
+    return hi + lo;
 }
 
 static double orc_exp2(double t)
 {
-    double n = rint(t);
-    double r = (t - n) * 0.6931471805599453;
-    double p = 1.0 / 6227020800.0;          /* 1/13! */
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    int64_t ni = (int64_t)n;
+    double kd = rint(t * 64.0);
+    double r = fma(kd, -0.015625, t);
+    int64_t k = (int64_t)kd;
+    int j = (int)(k & 63);
+    int64_t ni = k >> 6;                     /* arithmetic shift: floor(k / 64) */
+    double q = POW_E[5];
+    q = fma(q, r, POW_E[4]);
+    q = fma(q, r, POW_E[3]);
+    q = fma(q, r, POW_E[2]);
+    q = fma(q, r, POW_E[1]);
+    q = fma(q, r, POW_E[0]);
+    double s = r * q;
+    double v = fma(POW_EXP2T[j], s, POW_EXP2T[j]);
     if (ni < -1022) return 0.0;
     if (ni > 1023) return INFINITY;
-    return p * u2d((uint64_t)(ni + 1023) << 52);
+    return v * u2d((uint64_t)(ni + 1023) << 52);
 }
 
 /* pow for the arguments the colour code feeds it: x >= 0 (0 -> 0), x < 0 or NaN -> NaN. */

@@ -51,8 +51,8 @@ CHR = np.array([[17, 18, 24, 47, 99, 99, 99, 99], [18, 21, 26, 66, 99, 99, 99, 9
 
 def build(force=False):
     """Compile aej_oracle.c -> liboracle.so (gcc, no contraction, no fast-math)."""
-    hdr = os.path.join(_HERE, "aej_inv_constants.h")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(_SRC), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(_HERE, h) for h in ("aej_inv_constants.h", "aej_pow_tables.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in [_SRC] + hdrs):
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
                                "-fvisibility=hidden", "-mfma", "-mavx2", "-I", _HERE, "-o", _SO, _SRC, "-lm"])
     return _SO
