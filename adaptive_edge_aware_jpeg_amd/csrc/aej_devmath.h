@@ -15,13 +15,18 @@ namespace aej {
 #include "pow_tables.h"
 namespace aej {
 
-__device__ __forceinline__ double dev_log2(double x)
+// where the three 64-entry tables are read from: the __device__ arrays (default) or a workgroup's LDS copy (k_color_planes
+// evaluates 3 to 9 pows per pixel; LDS look-ups are cheaper than per-lane global loads)
+struct PowTabs { const double *invc, *logc, *exp2t; };
+__device__ __forceinline__ PowTabs pow_tabs_global() { return PowTabs{ POW_INVC, POW_LOGC, POW_EXP2T }; }
+
+__device__ __forceinline__ double dev_log2(double x, const PowTabs &pt)
 {
     long long b = __double_as_longlong(x);
     int e = (int)(b >> 52) - 1023;
     int i = (int)((b >> 46) & 63ll);
     double m = __longlong_as_double((b & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll);
-    double r = fma(m, POW_INVC[i], -1.0);
+    double r = fma(m, pt.invc[i], -1.0);
     double p = POW_L[7];
     p = fma(p, r, POW_L[6]);
     p = fma(p, r, POW_L[5]);
@@ -31,11 +36,11 @@ __device__ __forceinline__ double dev_log2(double x)
     p = fma(p, r, POW_L[1]);
     p = fma(p, r, POW_L[0]);
     double lo = r * p;
-    double hi = (double)e + POW_LOGC[i];
+    double hi = (double)e + pt.logc[i];
     return hi + lo;
 }
 
-__device__ __forceinline__ double dev_exp2(double t)
+__device__ __forceinline__ double dev_exp2(double t, const PowTabs &pt)
 {
     double kd = rint(t * 64.0);
     double r = fma(kd, -0.015625, t);
@@ -49,19 +54,21 @@ __device__ __forceinline__ double dev_exp2(double t)
     q = fma(q, r, POW_E[1]);
     q = fma(q, r, POW_E[0]);
     double s = r * q;
-    double v = fma(POW_EXP2T[j], s, POW_EXP2T[j]);
+    const double tj = pt.exp2t[j];
+    double v = fma(tj, s, tj);
     if (ni < -1022) return 0.0;
     if (ni > 1023) return __longlong_as_double(0x7FF0000000000000ll);
     return v * __longlong_as_double((ni + 1023) << 52);
 }
 
-__device__ __forceinline__ double dev_pow(double x, double y)
+__device__ __forceinline__ double dev_pow(double x, double y, const PowTabs &pt)
 {
     if (x == 0.0) return 0.0;
     if (!(x > 0.0)) return __longlong_as_double(0x7FF8000000000000ll);
     if (x < 2.2250738585072014e-308) return 0.0;
-    return dev_exp2(y * dev_log2(x));
+    return dev_exp2(y * dev_log2(x, pt), pt);
 }
+__device__ __forceinline__ double dev_pow(double x, double y) { return dev_pow(x, y, pow_tabs_global()); }
 
 // ------------------------------------------------------------------------------------------------
 // matrices: float32(value) of the Python literals (numpy: np.array([...], dtype=np.float32))
@@ -89,19 +96,20 @@ __device__ __forceinline__ double lin3d(float m0, float m1, float m2, double a, 
     u = (double)m2 * c;
     return t + u;
 }
-__device__ __forceinline__ float srgb_to_linear(float v)   // common.py:34-60 (float64 under numba typing)
+__device__ __forceinline__ float srgb_to_linear(float v, const PowTabs &pt)   // common.py:34-60 (float64 under numba typing)
 {
     double d = (double)v;
     if (d <= 0.04045) return (float)(d / 12.92);
-    return (float)dev_pow((d + 0.055) / 1.055, 2.4);
+    return (float)dev_pow((d + 0.055) / 1.055, 2.4, pt);
 }
-__device__ __forceinline__ double pq_inverse_eotf(double v, double m2)   // common.py:131-159
+__device__ __forceinline__ float srgb_to_linear(float v) { return srgb_to_linear(v, pow_tabs_global()); }
+__device__ __forceinline__ double pq_inverse_eotf(double v, double m2, const PowTabs &pt)   // common.py:131-159
 {
     const double c1 = 3424.0 / 4096.0, c2 = 2413.0 / 128.0, c3 = 2392.0 / 128.0, m1 = 2610.0 / 16384.0;
-    double tmp = dev_pow(v / 10000.0, m1);
+    double tmp = dev_pow(v / 10000.0, m1, pt);
     double num = c1 + c2 * tmp;
     double den = 1.0 + c3 * tmp;
-    return dev_pow(num / den, m2);
+    return dev_pow(num / den, m2, pt);
 }
 
 }  // namespace aej

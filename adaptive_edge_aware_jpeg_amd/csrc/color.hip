@@ -23,7 +23,7 @@ __device__ __forceinline__ void to_xyz(float lr, float lg, float lb, float &X, f
 // colour transform from LINEAR rgb (spaces >= 3: everything after common.py:34-60's sRGB linearisation) or from sRGB
 // itself (the three matrix spaces)
 template <int SPACE>
-__device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o0, float &o1, float &o2)
+__device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o0, float &o1, float &o2, const PowTabs &pt)
 {
     if constexpr (SPACE == 0) {          // YCbCr, ycbcr.py:25-30, 61
         o0 = dot3(F(0.299000), F(0.587000), F(0.114000), r, g, b);
@@ -44,7 +44,7 @@ __device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o
         float m = dot3(F(0.0329845436), F(0.9293118715), F(0.0361456387), X, Y, Z);
         float s = dot3(F(0.0482003018), F(0.2643662691), F(0.6338517070), X, Y, Z);
         const double third = (double)(float)(1.0 / 3.0);
-        float lp = (float)dev_pow((double)l, third), mp = (float)dev_pow((double)m, third), sp = (float)dev_pow((double)s, third);
+        float lp = (float)dev_pow((double)l, third, pt), mp = (float)dev_pow((double)m, third, pt), sp = (float)dev_pow((double)s, third, pt);
         o0 = dot3(F(0.2104542553), F(0.7936177850), F(-0.0040720468), lp, mp, sp);
         o1 = dot3(F(1.9779984951), F(-2.4285922050), F(0.4505937099), lp, mp, sp);
         o2 = dot3(F(0.0259040371), F(0.7827717662), F(-0.8086757660), lp, mp, sp);
@@ -62,7 +62,7 @@ __device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o
             S = lin3(F(0.02567), F(0.16713), F(0.74235), X, Y, Z);
         }
         const double pm2 = 2523.0 / 32.0;
-        double Lp = pq_inverse_eotf((double)L, pm2), Mp = pq_inverse_eotf((double)M, pm2), Sp = pq_inverse_eotf((double)S, pm2);
+        double Lp = pq_inverse_eotf((double)L, pm2, pt), Mp = pq_inverse_eotf((double)M, pm2, pt), Sp = pq_inverse_eotf((double)S, pm2, pt);
         if constexpr (SPACE == 4) {
             o0 = (float)lin3d(F(0.5000), F(0.5000), F(0.0000), Lp, Mp, Sp);
             o1 = (float)lin3d(F(1.6137), F(-3.3234), F(1.7097), Lp, Mp, Sp);
@@ -82,7 +82,7 @@ __device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o
         double L = ((double)F(0.41478972) * Xp + (double)F(0.579999) * Yp) + (double)(F(0.0146480) * Z);
         double M = ((double)F(-0.2015100) * Xp + (double)F(1.120649) * Yp) + (double)(F(0.0531008) * Z);
         double S = ((double)F(-0.0166008) * Xp + (double)F(0.264800) * Yp) + (double)(F(0.6684799) * Z);
-        double Lp = pq_inverse_eotf(L, p), Mp = pq_inverse_eotf(M, p), Sp = pq_inverse_eotf(S, p);
+        double Lp = pq_inverse_eotf(L, p, pt), Mp = pq_inverse_eotf(M, p, pt), Sp = pq_inverse_eotf(S, p, pt);
         double Iz = lin3d(F(0.500000), F(0.500000), F(0.000000), Lp, Mp, Sp);
         double Az = lin3d(F(3.524000), F(-4.066708), F(0.542708), Lp, Mp, Sp);
         double Bz = lin3d(F(0.199076), F(1.096799), F(-1.295875), Lp, Mp, Sp);
@@ -94,8 +94,9 @@ __device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o
 template <int SPACE>
 __device__ __forceinline__ void color_px(float r, float g, float b, float &o0, float &o1, float &o2)
 {
-    if constexpr (SPACE >= 3) color_px_lin<SPACE>(srgb_to_linear(r), srgb_to_linear(g), srgb_to_linear(b), o0, o1, o2);
-    else color_px_lin<SPACE>(r, g, b, o0, o1, o2);
+    const PowTabs pt = pow_tabs_global();
+    if constexpr (SPACE >= 3) color_px_lin<SPACE>(srgb_to_linear(r, pt), srgb_to_linear(g, pt), srgb_to_linear(b, pt), o0, o1, o2, pt);
+    else color_px_lin<SPACE>(r, g, b, o0, o1, o2, pt);
 }
 
 // a-3: (v*255).astype(uint8): float32 multiply, truncate toward zero, keep the low byte
@@ -157,8 +158,15 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
     constexpr bool kLin = SPACE >= 3;
     __shared__ float s_u8f[(kU8 || kLin) ? 256 : 1];
     __shared__ float s_lin[kLin ? 256 : 1];
+    __shared__ double s_pow[kLin ? 192 : 1];       // LDS copy of the pow tables
+    PowTabs pt = pow_tabs_global();
+    if constexpr (kLin) {
+        if (tid < 192) s_pow[tid] = tid < 64 ? POW_INVC[tid] : tid < 128 ? POW_LOGC[tid - 64] : POW_EXP2T[tid - 128];
+        __syncthreads();
+        pt = PowTabs{ s_pow, s_pow + 64, s_pow + 128 };
+    }
     if (kU8 || kLin) s_u8f[tid] = (float)tid / 255.0f;
-    if (kLin) s_lin[tid] = srgb_to_linear((float)tid / 255.0f);
+    if (kLin) s_lin[tid] = srgb_to_linear((float)tid / 255.0f, pt);
     if (do_hist) {
         for (int i = tid; i < 3 * 4 * 256; i += 256) s_hist[i] = 0;
     }
@@ -208,14 +216,14 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
                 if (!__all(hit)) {        // some value of this wave's rows is not k / 255.0f: those lanes take the float64 pow
                     if (!hit) {
 #pragma unroll
-                        for (int k = 0; k < 12; k++) lin[k] = srgb_to_linear(in[k]);
+                        for (int k = 0; k < 12; k++) lin[k] = srgb_to_linear(in[k], pt);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < 12; k++) in[k] = lin[k];
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) color_px_lin<SPACE>(in[3 * k], in[3 * k + 1], in[3 * k + 2], c0[r][k], c1[r][k], c2[r][k]);
+            for (int k = 0; k < 4; k++) color_px_lin<SPACE>(in[3 * k], in[3 * k + 1], in[3 * k + 2], c0[r][k], c1[r][k], c2[r][k], pt);
         }
         const long long ibase = (long long)b * g.pstride;
         // ---- layer 0 (luma): ratio 1x1 => copy
