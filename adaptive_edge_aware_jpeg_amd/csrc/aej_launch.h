@@ -69,11 +69,13 @@ void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuff
 void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb);
 
 // dct.hip
+constexpr int kBigBlocks = 128;      // workgroups (and scratch slots of 256 KiB) of the 256 x 256 kernels
 struct DctArgs {
     const float *norm;        // [B][pstride] normalised planes
     int *coeffs;              // out [B][coeff_stride]
     float *dct_f32;           // optional
     const LeafWork *work;     // work lists for this size (per-plane segments, see QtGeom)
+    float *scratch;           // [kBigBlocks][256 * 256] intermediate product of the 256 x 256 kernel, else null
     const int *work_count;    // [nplanes][kMaxSizes]
     int k;                    // size index
     int nplanes;
@@ -91,6 +93,7 @@ struct IdctArgs {
     const int *coeffs;        // [B][coeff_stride] zigzag-ordered quantised coefficients
     float *planes;            // out [B][pstride] de-normalised layers
     const LeafWork *work;
+    float *scratch;           // [kBigBlocks][256 * 256] for the 256 x 256 kernel, else null
     const int *work_count;    // [nplanes][kMaxSizes]
     int k, nplanes;
     const float *D;           // [s][s]

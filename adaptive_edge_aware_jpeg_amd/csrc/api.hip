@@ -339,8 +339,8 @@ extern "C" int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, con
 {
     if (!ctx) return AEJ_ERR_ARG;
     if (space < 0 || space > 6) return fail(ctx, AEJ_ERR_ARG, "Unsupported color space id: %d", space);
-    if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 2 || bmax > 128)
-        return fail(ctx, bmax > 128 ? AEJ_ERR_UNSUPPORTED : AEJ_ERR_ARG, "block size range (%d, %d): powers of two in [2, 128] required", bmin, bmax);
+    if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 2 || bmax > 256)
+        return fail(ctx, bmax > 256 ? AEJ_ERR_UNSUPPORTED : AEJ_ERR_ARG, "block size range (%d, %d): powers of two in [2, 256] required", bmin, bmax);
     if (!qmats_host) return fail(ctx, AEJ_ERR_ARG, "qmats_host is NULL");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
     int nsizes = 0;
@@ -572,7 +572,10 @@ static int run_color_planes(aej_ctx *ctx, const void *rgb, bool in_u8, const Geo
 }
 
 // ---- whole path ---------------------------------------------------------------------------------------------
+static long long big_scratch_floats(int bmax) { return bmax >= 256 ? (long long)kBigBlocks * 256 * 256 : 0; }
+
 struct EncodeWs {
+    float *big;              // scratch of the 256 x 256 DCT kernel (null unless the settings allow that size)
     float *norm;
     int *area_tabs;
     CannyWs canny;
@@ -587,6 +590,7 @@ static void carve_encode(void *base, const Geom &g, const QtGeom &q, EncodeWs &w
     w.area_tabs = c.take<int>(area_tab_ints(g));
     carve_canny(c, g, w.canny);
     carve_qt(c, g, q, true, w.qt);
+    w.big = big_scratch_floats(q.bmax) ? c.take<float>(big_scratch_floats(q.bmax)) : nullptr;
     w.bytes = (c.off + 255) & ~255ull;
 }
 
@@ -658,6 +662,7 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
             DctArgs a;
             a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
             a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
+            a.scratch = w.big;
             a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
             for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
             launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k]);
@@ -864,6 +869,8 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
     char *scratch = nullptr;
     size_t list_bytes = (size_t)n_leaves * sizeof(LeafWork);
     size_t total = 256 + (size_t)ctx->nsizes * ((list_bytes + 255) & ~(size_t)255);   // 256 B = [3 planes][kMaxSizes] counters
+    const size_t big_off = total;
+    total += (size_t)big_scratch_floats(ctx->bmax) * sizeof(float);
     AEJ_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&scratch), total));
     int *work_count = reinterpret_cast<int *>(scratch);
     LeafWork *work[kMaxSizes] = {};
@@ -876,6 +883,7 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
             DctArgs a;
             a.norm = norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
             a.work = work[k]; a.work_count = work_count; a.k = k; a.nplanes = 3;
+            a.scratch = big_scratch_floats(ctx->bmax) ? reinterpret_cast<float *>(scratch + big_off) : nullptr;
             a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
             for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
             launch_dct(st, s, g, q, a, n_leaves);
@@ -925,6 +933,7 @@ extern "C" int aej_color_convert_inverse(aej_ctx *ctx, int space, const float *i
 }
 
 struct DecodeWs {
+    float *big;
     float *planes;
     int *work_count;
     LeafWork *work[kMaxSizes];
@@ -942,6 +951,7 @@ static void carve_decode(void *base, const Geom &g, const QtGeom &q, DecodeWs &w
         w.work_cap[k] = q.work_stride[k] * g.B;
         w.work[k] = c.take<LeafWork>(w.work_cap[k] > 0 ? w.work_cap[k] : 1);
     }
+    w.big = big_scratch_floats(q.bmax) ? c.take<float>(big_scratch_floats(q.bmax)) : nullptr;
     w.bytes = (c.off + 255) & ~255ull;
 }
 
@@ -977,6 +987,7 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
     for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
         IdctArgs a;
         a.coeffs = coeffs; a.planes = w.planes; a.work = w.work[k]; a.work_count = w.work_count; a.k = k; a.nplanes = batch * 3;
+        a.scratch = w.big;
         a.D = ctx->d_D[k]; a.zz = ctx->d_zz[k]; a.zzinv = ctx->d_zzinv[k];
         for (int l = 0; l < 3; l++) { a.qm[l] = ctx->d_qm[l][k]; a.mid[l] = (float)kMid[ctx->space][l]; a.scale[l] = (float)kScale[ctx->space][l]; }
         launch_idct(st, s, g, q, a, w.work_cap[k]);
@@ -1104,6 +1115,6 @@ extern "C" int aej_get_stage_ms(aej_ctx *ctx, float *ms_host)
 extern "C" const char *aej_stage_name(int i)
 {
     static const char *names[AEJ_N_STAGES] = { "clear", "color_planes", "clahe_lut", "clahe_blur", "thresholds", "sobel_nms",
-                                               "hysteresis", "quadtree", "dct2", "dct4", "dct8", "dct16", "dct32", "dct64", "dct128" };
+                                               "hysteresis", "quadtree", "dct2", "dct4", "dct8", "dct16", "dct32", "dct64", "dct128", "dct256" };
     return i >= 0 && i < AEJ_N_STAGES ? names[i] : "";
 }

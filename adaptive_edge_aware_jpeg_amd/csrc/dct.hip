@@ -10,6 +10,7 @@
 // exactly that k-ordered fma chain.
 #include "aej_common.h"
 #include "aej_launch.h"
+#include "aej_bigblock.h"
 
 namespace aej {
 
@@ -262,6 +263,46 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S = 256 (aej_bigblock.h): T = D.X into this workgroup's scratch, then Y = T.D^T, quantise, zigzag scatter
+// ------------------------------------------------------------------------------------------------
+template <int S, bool WANT_DCT>
+__global__ __launch_bounds__(256) void k_dct_big(Geom g, QtGeom q, DctArgs a, long long max_items)
+{
+    __shared__ BigTileLds L;
+    __shared__ LayerTab lt;
+    extern __shared__ int s_pref[];
+    dct_prologue(g, q, a, s_pref, lt);
+    long long count = s_pref[a.nplanes];
+    if (count > max_items) count = max_items;
+    const long long wstride = q.work_stride[a.k];
+    float *T = a.scratch + (long long)blockIdx.x * S * S;
+    for (long long item = blockIdx.x; item < count; item += gridDim.x) {
+        const int4 cur = fetch_item(a, wstride, lt, s_pref, item);
+        const int b = cur.x / 3, layer = cur.x - b * 3;
+        const int w = lt.w[layer], h = lt.h[layer];
+        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+        const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
+        const float *D = a.D;
+        big_product<S>(L,
+            [&](int i, int k) { return D[i * S + k]; },
+            [&](int k, int j) { return src[(long long)(cur.z + reflect_pad_idx(k, hc)) * w + cur.y + reflect_pad_idx(j, wc)]; },
+            [&](int i, int j, float v) { T[i * S + j] = v; });
+        big_scratch_sync();
+        const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
+        const int *qm = a.qm[layer];
+        big_product<S>(L,
+            [&](int i, int k) { return T[i * S + k]; },
+            [&](int k, int j) { return D[j * S + k]; },
+            [&](int i, int j, float v) {
+                const int ridx = i * S + j;
+                if (WANT_DCT) a.dct_f32[out_base + ridx] = v;
+                a.coeffs[out_base + a.zzinv[ridx]] = quantise(v, qm ? qm[ridx] : 1);
+            });
+        big_scratch_sync();      // the next leaf overwrites T
+    }
+}
+
 // LDS-DMA (global_load_lds): per-lane global source, LDS destination = wave-uniform base + lane * size.
 __device__ __forceinline__ void glds16(const float *g, float *lds_wave_base)
 {
@@ -492,6 +533,11 @@ void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const 
     case 32: AEJ_MFMA(32, 4096); break;
     case 64: AEJ_MFMA(64, 768); break;
     case 128: AEJ_MFMA(128, 256); break;
+    case 256:
+        if (!a.scratch) break;       // callers reserve it whenever the settings allow this size
+        if (wd) hipLaunchKernelGGL((k_dct_big<256, true>), dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a, max_items);
+        else hipLaunchKernelGGL((k_dct_big<256, false>), dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a, max_items);
+        break;
     default: break;
     }
 #undef AEJ_SMALL

@@ -8,6 +8,7 @@
 // then plane[y+n][x+m] = X[n][m] / scale + mid for the in-bounds part of the leaf.
 #include "aej_common.h"
 #include "aej_launch.h"
+#include "aej_bigblock.h"
 #include "aej_devmath.h"
 #include "inv_constants.h"
 
@@ -244,6 +245,44 @@ __global__ __launch_bounds__(IdctCfg<S>::NTHREADS) void k_idct_mfma(Geom g, QtGe
 }
 
 // ------------------------------------------------------------------------------------------------
+// S = 256 (aej_bigblock.h): T = D^T.Y into this workgroup's scratch, then X = T.D, de-normalise, merge
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void k_idct_big(Geom g, QtGeom q, IdctArgs a)
+{
+    __shared__ BigTileLds L;
+    __shared__ LayerTabD lt;
+    extern __shared__ int s_pref[];
+    idct_prologue(g, q, a, s_pref, lt);
+    const long long count = s_pref[a.nplanes];
+    const long long wstride = q.work_stride[a.k];
+    float *T = a.scratch + (long long)blockIdx.x * S * S;
+    for (long long item = blockIdx.x; item < count; item += gridDim.x) {
+        const int4 wk = fetch_item_d(a, wstride, lt, s_pref, item);
+        const int b = wk.x / 3, layer = wk.x - 3 * b;
+        const int w = lt.w[layer], h = lt.h[layer];
+        const int *cf = a.coeffs + (long long)b * q.coeff_stride + lt.coff[layer] + wk.w;
+        const int *qm = a.qm[layer];
+        const float *D = a.D;
+        big_product<S>(L,
+            [&](int i, int k) { return D[k * S + i]; },
+            [&](int k, int j) { const int r = k * S + j; return (float)(cf[a.zzinv[r]] * qm[r]); },      // _dequantize, jpeg.py:508-529
+            [&](int i, int j, float v) { T[i * S + j] = v; });
+        big_scratch_sync();
+        float *dst = a.planes + (long long)b * g.pstride + lt.poff[layer];
+        const float mid = lt.mid[layer], scale = lt.scale[layer];
+        big_product<S>(L,
+            [&](int i, int k) { return T[i * S + k]; },
+            [&](int k, int j) { return D[k * S + j]; },
+            [&](int i, int j, float v) {
+                const int yy = wk.z + i, xx = wk.y + j;
+                if (yy < h && xx < w) { float t = v / scale; dst[(long long)yy * w + xx] = t + mid; }
+            });
+        big_scratch_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // inverse colour transforms (conversion.py:122-124 and the per-space x_to_srgb functions)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bits2f(unsigned u) { return __uint_as_float(u); }
@@ -425,6 +464,9 @@ void launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const
     case 32: launch_idct_mfma_t<32>(st, g, q, a, cap(1, 4096)); break;
     case 64: launch_idct_mfma_t<64>(st, g, q, a, cap(1, 768)); break;
     case 128: launch_idct_mfma_t<128>(st, g, q, a, cap(1, 256)); break;
+    case 256:
+        if (a.scratch) hipLaunchKernelGGL(k_idct_big<256>, dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a);
+        break;
     default: break;
     }
 }

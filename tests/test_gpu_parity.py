@@ -440,9 +440,31 @@ def test_device_round_trip_matches_oracle(A, oracle, space, H, W, br):
     assert np.array_equal(A.Jpeg(A.JpegCompressionSettings()).decompress(data).data, dec[0])
 
 
+@pytest.mark.parametrize("space,H,W,br", [("YCbCr", 600, 800, (8, 256)), ("YCoCg", 530, 520, (4, 256)), ("OKLAB", 300, 700, (256, 256))])
+def test_block_size_256(A, oracle, space, H, W, br):
+    """The GUI's largest block (main_frame.py block-size slider): 256 x 256 leaves, whole and clipped at the plane border
+    (np.pad reflect), through the tiled big-block kernels -- encode and decode against the oracle."""
+    img = oracle.synth_image(H, W, 3, "flat").astype(np.float32) / np.float32(255.0)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = img + (0.05 * np.sin(xx / 90.0) * np.cos(yy / 70.0))[..., None].astype(np.float32)      # smooth, no edges
+    img[100:140, 200:260] = 0.9                                                                    # one patch with edges
+    img = np.clip(np.round(img * 255), 0, 255).astype(np.float32) / np.float32(255.0)
+    codec = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), br))
+    enc = codec.compress_batch(img[None], want_dct=True)
+    ref = oracle.encode_image(img, space, (40, 80), br)
+    assert any(256 in set(ref[l]["leaves"][:, 2].tolist()) for l in range(3))
+    for l in range(3):
+        got = enc.layer(0, l)
+        assert np.array_equal(got["states"], ref[l]["states"]) and np.array_equal(got["leaves"], ref[l]["leaves"])
+        assert np.array_equal(got["coeffs"], ref[l]["coeffs"]), f"L{l} coeffs"
+    dec = codec.decompress_batch(enc).cpu().numpy()[0]
+    want = oracle.decode_image(oracle.write_ajpg(ref, H, W, space, (40, 80), br, ".png"))
+    assert np.array_equal(dec, want)
+
+
 def test_unsupported_inputs_fail_loudly(A):
     codec = A.Jpeg(A.JpegCompressionSettings("YCbCr"))
     with pytest.raises(NotImplementedError):
-        A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 256))).compress_batch(np.zeros((1, 64, 64, 3), np.float32))
+        A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 512))).compress_batch(np.zeros((1, 64, 64, 3), np.float32))
     with pytest.raises(ValueError):
         codec.compress_batch(np.zeros((64, 64, 3), np.float32))
