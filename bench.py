@@ -210,6 +210,19 @@ def main():
         "leaf_histogram": {"per_image": {str(k): round(v / B, 1) for k, v in leaf_hist.items()},
                            "area_share": {str(k): round(k * k * v / leaf_area, 4) for k, v in leaf_hist.items()}},
     }
+    # DCT per block size: time, bytes moved per second (8 B per coefficient) and, for the MFMA sizes, the
+    # fraction of the 157.3 TFLOP/s float32 MFMA peak (4 s^3 FLOP per leaf: two s x s x s products)
+    dct_sizes = {}
+    for sz, n_leaves in leaf_hist.items():
+        ms = stage_ms.get(f"dct{sz}", 0.0)
+        if ms <= 0 or n_leaves == 0:
+            continue
+        e = {"ms": round(ms, 4), "GBps": round(8.0 * sz * sz * n_leaves / (ms * 1e-3) / 1e9, 1)}
+        if sz >= 32:
+            tf = 4.0 * sz ** 3 * n_leaves / (ms * 1e-3) / 1e12
+            e.update({"TFLOPs": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / 157.3, 3)})
+        dct_sizes[str(sz)] = e
+    out["dct_by_block_size"] = dct_sizes
 
     # ---- CPU baseline: the C oracle (a scalar port of the reference algorithm) on the host cores, bounded sample:
     # one image per thread (ctypes releases the GIL inside the C call), the fan-out the reference's own sweep uses
