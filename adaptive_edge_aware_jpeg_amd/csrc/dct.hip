@@ -112,6 +112,16 @@ __device__ __forceinline__ int4 fetch_item(const DctArgs &a, long long work_stri
     return reinterpret_cast<const int4 *>(a.work)[idx];
 }
 
+// Same mapping for a caller whose item indices only grow: scan forward from the plane of the previous item (`p`, updated)
+// instead of bisecting -- usually one or two LDS reads on the critical path instead of eight dependent ones.
+__device__ __forceinline__ int4 fetch_item_fwd(const DctArgs &a, long long work_stride, const LayerTab &lt, const int *s_pref, long long item, int &p)
+{
+    while (p + 1 < a.nplanes && (long long)s_pref[p + 1] <= item) p++;
+    const int b = p / 3, l = p - 3 * b;
+    const long long idx = (long long)b * work_stride + lt.woff[l] + (item - s_pref[p]);
+    return reinterpret_cast<const int4 *>(a.work)[idx];
+}
+
 // ------------------------------------------------------------------------------------------------
 // small blocks: S in {2, 4, 8, 16}; 256 threads = 256/S leaves, S threads per leaf.
 // The descriptor of the next leaf is fetched while the current one is transformed.
@@ -388,8 +398,9 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
     const long long step = gridDim.x;
     long long item = blockIdx.x;
     int4 cur = make_int4(0, 0, 0, 0), nxt = make_int4(0, 0, 0, 0);
-    if (item < count) cur = fetch_item(a, wstride, lt, s_pref, item);
-    if (item + step < count) nxt = fetch_item(a, wstride, lt, s_pref, item + step);
+    int plane_hint = 0;
+    if (item < count) cur = fetch_item_fwd(a, wstride, lt, s_pref, item, plane_hint);
+    if (item + step < count) nxt = fetch_item_fwd(a, wstride, lt, s_pref, item + step, plane_hint);
     int pb = 0;
     if (NXB == 2 && item < count) {
         const int b0 = cur.x / 3, l0 = cur.x - b0 * 3;
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
             dct_load_x<S, NWAVES>(a.norm + (long long)bn * g.pstride + lt.poff[ln], lt.w[ln], lt.h[ln], nxt, sXb + (pb ^ 1) * SS, wave, lane);
         }
         int4 nn = make_int4(0, 0, 0, 0);
-        if (item + 2 * step < count) nn = fetch_item(a, wstride, lt, s_pref, item + 2 * step);
+        if (item + 2 * step < count) nn = fetch_item_fwd(a, wstride, lt, s_pref, item + 2 * step, plane_hint);
 
         floatx16 acc[TPW];
 #pragma unroll
