@@ -8,6 +8,7 @@ a device-resident float32 [B, H, W, 3] batch in, device-resident coefficient / l
 """
 import ctypes
 import json
+import os
 import zlib
 from io import BytesIO
 from typing import List, Optional, Tuple
@@ -203,31 +204,46 @@ class Jpeg:
         return meta, layers
 
     # ------------------------------------------------------------------ .ajpg container (jpeg.py:531-597)
-    def _entropy_encode(self, layers) -> bytes:
-        out = BytesIO()
+    def _header_bytes(self, num_layers: int) -> bytes:
         metadata = {
-            "height": int(self.layer_shape[0]), "width": int(self.layer_shape[1]), "num_layers": len(layers),
+            "height": int(self.layer_shape[0]), "width": int(self.layer_shape[1]), "num_layers": num_layers,
             "color_space": self.settings.color_space,
             "quality_min": self.settings.quality_range[0], "quality_max": self.settings.quality_range[1],
             "block_size_min": self.settings.block_size_range[0], "block_size_max": self.settings.block_size_range[1],
             "extension": self.extension,
         }
         mb = json.dumps(metadata).encode("utf-8")
-        out.write(len(mb).to_bytes(4, byteorder="big"))
-        out.write(mb)
-        for L in layers:
-            st = L["states"]
-            bits_len = 2 * len(st)
-            pad = (-len(st)) % 4
-            quad = np.concatenate([st, np.zeros(pad, np.uint8)]).reshape(-1, 4)
-            packed = ((quad[:, 0] << 6) | (quad[:, 1] << 4) | (quad[:, 2] << 2) | quad[:, 3]).astype(np.uint8)
-            out.write(bits_len.to_bytes(4, byteorder="big"))
-            out.write(int(L["root_size"]).to_bytes(4, byteorder="big"))
-            out.write(packed.tobytes())
-            comp = zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=9)
-            out.write(len(comp).to_bytes(4, byteorder="big"))
-            out.write(comp)
-        return out.getvalue()
+        return len(mb).to_bytes(4, byteorder="big") + mb
+
+    @staticmethod
+    def _layer_bytes(L) -> bytes:
+        """One layer record of the container (jpeg.py:561-595): state bits, root size, zlib-9 of the int32 coefficients."""
+        st = L["states"]
+        bits_len = 2 * len(st)
+        pad = (-len(st)) % 4
+        quad = np.concatenate([st, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+        packed = ((quad[:, 0] << 6) | (quad[:, 1] << 4) | (quad[:, 2] << 2) | quad[:, 3]).astype(np.uint8)
+        comp = zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=9)
+        return b"".join((bits_len.to_bytes(4, byteorder="big"), int(L["root_size"]).to_bytes(4, byteorder="big"), packed.tobytes(),
+                         len(comp).to_bytes(4, byteorder="big"), comp))
+
+    def _entropy_encode(self, layers) -> bytes:
+        return self._header_bytes(len(layers)) + b"".join(self._layer_bytes(L) for L in layers)
+
+    def compress_many(self, batch, extension: Optional[str] = None, workers: Optional[int] = None) -> List[bytes]:
+        """``compress`` for a batch: one GPU pass (``compress_batch``), then the container of every image with the
+        per-layer zlib-9 streams -- the part of ``compress`` that dominates end to end -- deflated on a thread pool (zlib
+        releases the GIL).  Each element equals ``compress(Image(batch[i]))`` byte for byte."""
+        from concurrent.futures import ThreadPoolExecutor
+        enc = self.compress_batch(batch)
+        p = enc.plan
+        self.update_layer_shapes((p.H, p.W))
+        self.extension = extension
+        header = self._header_bytes(3)
+        jobs = [(b, l) for b in range(p.batch) for l in range(3)]
+        with ThreadPoolExecutor(max_workers=workers or min(32, os.cpu_count() or 1)) as ex:
+            recs = list(ex.map(lambda bl: self._layer_bytes(enc.layer(bl[0], bl[1])), jobs))
+        return [header + b"".join(recs[3 * b:3 * b + 3]) for b in range(p.batch)]
 
     # ------------------------------------------------------------------ small helpers, reference names kept
     def _compute_downsampled_shapes(self, layer_shapes) -> np.ndarray:

@@ -343,6 +343,16 @@ def test_batch_equals_single_and_is_deterministic(A, oracle):
     assert (noise["leaves"][:, 2] == 4).mean() > 0.5 and 64 not in set(noise["leaves"][:, 2].tolist())   # white noise: small leaves
 
 
+def test_compress_many_equals_compress(A, oracle):
+    """batch -> list of .ajpg byte strings (GPU pass + thread-pooled zlib-9) == Jpeg.compress image by image"""
+    imgs = np.stack([synth(oracle, 200, 264, s, k) for s, k in ((1, "mixed"), (2, "noise"), (3, "flat"))])
+    codec = A.Jpeg(A.JpegCompressionSettings("YCoCg", (40, 80), (4, 64)))
+    many = codec.compress_many(imgs, extension=".png", workers=4)
+    for i in range(len(imgs)):
+        assert many[i] == codec.compress(A.Image(imgs[i], imgs[i].shape, ".png"))
+    assert np.array_equal(A.Jpeg(A.JpegCompressionSettings()).decompress(many[0]).data, codec.decompress_batch(codec.compress_batch(imgs[:1])).cpu().numpy()[0])
+
+
 @pytest.mark.parametrize("space,H,W", [("YCbCr", 256, 384), ("ICtCp", 128, 256), ("OKLAB", 67, 101), ("YCoCg", 50, 33)])
 def test_uint8_ingest_equals_float_ingest(A, oracle, space, H, W):
     """aej_encode_batch_u8 forms float32(v) / 255 itself (image.py:80): identical to the float path and to the oracle,
