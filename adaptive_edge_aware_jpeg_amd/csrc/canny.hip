@@ -659,9 +659,10 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
 // a-8 part 2: hysteresis on the bit-planes.  One WAVE owns a 64x64 tile: lane r holds row r of the
 // strong and weak planes as 64-bit words, the 8-neighbourhood dilation is shifts + two lane shuffles, and
 // horizontal runs are filled in one step with a Kogge-Stone occluded fill; the loop runs in registers until
-// the tile is at its fix-point for the current halo.  A tile whose border ring changed queues its 8
-// neighbours for the next pass (device work list, de-duplicated with per-parity flags).  Strong bits only
-// ever get set, so the global fix-point is unique = OpenCV's stack flood fill.
+// the tile is at its fix-point for the current halo.  A tile whose border changed dirties exactly the
+// neighbours that see a new pixel (device work list for the next pass, de-duplicated with per-parity flags; from
+// pass 1 on the wave follows one of them itself, see CHASE below).  Strong bits only ever get set, so the global
+// fix-point is unique = OpenCV's stack flood fill.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed, unsigned long long open)
 {
