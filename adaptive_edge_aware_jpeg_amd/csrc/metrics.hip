@@ -9,6 +9,8 @@
 // separable passes through LDS ('valid' convolution: no padding).
 #include "aej_common.h"
 #include "aej_launch.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace aej {
 
@@ -199,6 +201,93 @@ __global__ __launch_bounds__(256) void k_ssim_level(SsimArgs A)
     }
 }
 
+// ---- the same scale as a sliding window (used for every scale; the tiled kernel above is kept as the small-image fallback) ----
+// One WAVE owns a strip of 64 output columns x kStripRows output rows and walks down the input rows: a row's 74 values of x and y
+// go through a wave-private LDS row (no workgroup barrier anywhere), every lane forms the five horizontal sums of its column and
+// keeps the last 11 rows of them in registers (a ring addressed at compile time: the row loop is unrolled 11-fold), and the
+// vertical sums complete one output row per input row.  Same tap order as the tiled kernel, so the same float32 values.
+constexpr int kStripRows = 64;
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(256) void k_ssim_strip(SsimArgs A)
+{
+    __shared__ float rx[4][kSsimK + 64], ry[4][kSsimK + 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int img = blockIdx.z;
+    const int oh = A.h - (kSsimK - 1), ow = A.w - (kSsimK - 1);
+    const int nsx = (ow + 63) / 64, nsy = (oh + kStripRows - 1) / kStripRows;
+    const int sidx = blockIdx.x * 4 + wave;
+    if (sidx >= nsx * nsy) return;                       // no workgroup-level synchronisation below
+    const int sy_ = sidx / nsx, sx_ = sidx - sy_ * nsx;
+    const int x0 = sx_ * 64, y0 = sy_ * kStripRows;
+    const int rows_out = min(kStripRows, oh - y0), R = rows_out + kSsimK - 1;
+    const bool col_ok = x0 + lane < ow;
+    float *wx = rx[wave], *wy = ry[wave];
+    float g[kSsimK];
+#pragma unroll
+    for (int t = 0; t < kSsimK; t++) g[t] = A.g[t];
+    const int c_begin = INTERLEAVED ? 0 : blockIdx.y, c_end = INTERLEAVED ? A.C : c_begin + 1;
+    for (int c = c_begin; c < c_end; c++) {
+        float h[kSsimK][5];
+        float ss_acc = 0.f, cs_acc = 0.f;
+        auto step = [&](auto ph, int r) {
+            constexpr int PH = decltype(ph)::value;
+            if (r >= R) return;
+            const int gy = y0 + r;
+            const int cA = x0 + lane, cB = x0 + 64 + lane;
+            auto at = [&](int col) -> long long {
+                return INTERLEAVED ? (((long long)img * A.h + gy) * A.w + col) * A.C + c : (((long long)img * A.C + c) * A.h + gy) * A.w + col;
+            };
+            float xa = 0.f, ya = 0.f, xb = 0.f, yb = 0.f;
+            if (cA < A.w) { xa = A.xa[at(cA)]; ya = A.xb[at(cA)]; }
+            if (lane < kSsimK - 1 && cB < A.w) { xb = A.xa[at(cB)]; yb = A.xb[at(cB)]; }
+            wx[lane] = xa; wy[lane] = ya;
+            if (lane < kSsimK - 1) { wx[64 + lane] = xb; wy[64 + lane] = yb; }
+            __builtin_amdgcn_wave_barrier();
+            float mx = 0.f, my = 0.f, mxx = 0.f, myy = 0.f, mxy = 0.f;
+#pragma unroll
+            for (int t = 0; t < kSsimK; t++) {
+                const float x = wx[lane + t], y = wy[lane + t];
+                mx += g[t] * x; my += g[t] * y; mxx += g[t] * (x * x); myy += g[t] * (y * y); mxy += g[t] * (x * y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            h[PH][0] = mx; h[PH][1] = my; h[PH][2] = mxx; h[PH][3] = myy; h[PH][4] = mxy;
+            if (r >= kSsimK - 1) {                  // rows r - 10 .. r are in the ring: the oldest sits right after PH
+                float v[5];
+#pragma unroll
+                for (int m = 0; m < 5; m++) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int t = 0; t < kSsimK; t++) sacc += g[t] * h[(PH + 1 + t) % kSsimK][m];
+                    v[m] = sacc;
+                }
+                if (col_ok) {
+                    const float mu_xx = v[0] * v[0], mu_yy = v[1] * v[1], mu_xy = v[0] * v[1];
+                    const float s_xx = v[2] - mu_xx, s_yy = v[3] - mu_yy, s_xy = v[4] - mu_xy;
+                    const float cs = (2.f * s_xy + A.c2) / (s_xx + s_yy + A.c2);
+                    const float ss = (2.f * mu_xy + A.c1) / (mu_xx + mu_yy + A.c1) * cs;
+                    ss_acc += ss; cs_acc += cs;
+                }
+            }
+        };
+        for (int r0 = 0; r0 < R; r0 += kSsimK) {
+            step(std::integral_constant<int, 0>{}, r0);      step(std::integral_constant<int, 1>{}, r0 + 1);
+            step(std::integral_constant<int, 2>{}, r0 + 2);  step(std::integral_constant<int, 3>{}, r0 + 3);
+            step(std::integral_constant<int, 4>{}, r0 + 4);  step(std::integral_constant<int, 5>{}, r0 + 5);
+            step(std::integral_constant<int, 6>{}, r0 + 6);  step(std::integral_constant<int, 7>{}, r0 + 7);
+            step(std::integral_constant<int, 8>{}, r0 + 8);  step(std::integral_constant<int, 9>{}, r0 + 9);
+            step(std::integral_constant<int, 10>{}, r0 + 10);
+        }
+        double ss_d = (double)ss_acc, cs_d = (double)cs_acc;
+        for (int o = 32; o > 0; o >>= 1) { ss_d += __shfl_down(ss_d, o); cs_d += __shfl_down(cs_d, o); }
+        if (lane == 0) {
+            double *acc = A.acc + (long long)img * kMetricSlots + A.slot + 2 * c;
+            atomicAdd(&acc[0], ss_d);
+            atomicAdd(&acc[1], cs_d);
+        }
+    }
+}
+
 // ---- next MS-SSIM scale: F.pad(replicate, left / top by p = max(h % 2, w % 2)) then F.avg_pool2d(2) -> planar ----
 template <bool INTERLEAVED>
 __global__ __launch_bounds__(256) void k_pool2(const float *__restrict__ in, int h, int w, int C, int p, int h2, int w2, float *__restrict__ out)
@@ -280,9 +369,16 @@ void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const 
     const int oh = h - (kSsimK - 1), ow = w - (kSsimK - 1);
     A.ntx = (ow + kSsimT - 1) / kSsimT;
     const int nty = (oh + kSsimT - 1) / kSsimT;
-    dim3 grid(A.ntx * nty, interleaved ? 1 : C, B);
-    if (interleaved) hipLaunchKernelGGL(k_ssim_level<true>, grid, dim3(256), 0, st, A);
-    else hipLaunchKernelGGL(k_ssim_level<false>, grid, dim3(256), 0, st, A);
+    if (getenv("AEJ_SSIM_TILED")) {              // diagnostic: the tiled kernel
+        dim3 grid(A.ntx * nty, interleaved ? 1 : C, B);
+        if (interleaved) hipLaunchKernelGGL(k_ssim_level<true>, grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(k_ssim_level<false>, grid, dim3(256), 0, st, A);
+        return;
+    }
+    const int strips = ((ow + 63) / 64) * ((oh + kStripRows - 1) / kStripRows);
+    dim3 grid((strips + 3) / 4, interleaved ? 1 : C, B);
+    if (interleaved) hipLaunchKernelGGL(k_ssim_strip<true>, grid, dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(k_ssim_strip<false>, grid, dim3(256), 0, st, A);
 }
 
 void launch_pool2(hipStream_t st, bool interleaved, const float *in, int B, int C, int h, int w, int p, int h2, int w2, float *out)
