@@ -113,6 +113,7 @@ void launch_metric_pool_grey(hipStream_t st, const unsigned char *ga, const unsi
                              float *xb);
 void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const float *xb, int B, int C, int h, int w, const float *g11, double *acc,
                        int slot);
+void launch_pool2_rgb(hipStream_t st, const float *ia, const float *ib, int B, int h, int w, int p, int h2, int w2, float *oa, float *ob);
 void launch_pool2(hipStream_t st, bool interleaved, const float *in, int B, int C, int h, int w, int p, int h2, int w2, float *out);
 void launch_metric_final(hipStream_t st, const double *acc, int B, long long npx, long long n_ssim, const long long *n_level, double *out);
 

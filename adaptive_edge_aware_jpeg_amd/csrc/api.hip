@@ -1076,8 +1076,12 @@ extern "C" int aej_metrics_batch(aej_ctx *ctx, const float *img_a, const float *
             const float *xa = l == 0 ? img_a : w.pyr[0][l - 1], *xb = l == 0 ? img_b : w.pyr[1][l - 1];
             if (l > 0) {
                 const float *pa = l == 1 ? img_a : w.pyr[0][l - 2], *pb = l == 1 ? img_b : w.pyr[1][l - 2];
-                launch_pool2(st, l == 1, pa, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[0][l - 1]);
-                launch_pool2(st, l == 1, pb, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[1][l - 1]);
+                if (l == 1) {
+                    launch_pool2_rgb(st, pa, pb, batch, w.lh[0], w.lw[0], w.lp[1], w.lh[1], w.lw[1], w.pyr[0][0], w.pyr[1][0]);
+                } else {
+                    launch_pool2(st, false, pa, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[0][l - 1]);
+                    launch_pool2(st, false, pb, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[1][l - 1]);
+                }
             }
             launch_ssim_level(st, l == 0, xa, xb, batch, 3, w.lh[l], w.lw[l], g11, w.acc, kMetricSlotScales + l * 6);
             n_level[l] = (long long)(w.lh[l] - 10) * (w.lw[l] - 10);

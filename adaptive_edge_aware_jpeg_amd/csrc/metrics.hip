@@ -310,6 +310,34 @@ __global__ __launch_bounds__(256) void k_pool2(const float *__restrict__ in, int
     }
 }
 
+// first MS-SSIM down-scale, from the caller's interleaved RGB: one thread per output pixel handles the three channels of BOTH
+// images (2 x 2 x 3 contiguous floats per source row instead of a 12-byte-strided read per channel)
+__global__ __launch_bounds__(256) void k_pool2_rgb(const float *__restrict__ ia, const float *__restrict__ ib, int h, int w, int p, int h2, int w2,
+                                                   float *__restrict__ oa, float *__restrict__ ob)
+{
+    const int img = blockIdx.y;
+    const long long n = (long long)h2 * w2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / w2), x = (int)(i - (long long)y * w2);
+        float sa[3] = { 0.f, 0.f, 0.f }, sb[3] = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                int sy = 2 * y + dy - p, sx = 2 * x + dx - p;
+                sy = sy < 0 ? 0 : sy; sx = sx < 0 ? 0 : sx;
+                const long long o = (((long long)img * h + sy) * w + sx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { sa[c] += ia[o + c]; sb[c] += ib[o + c]; }
+            }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            oa[((long long)img * 3 + c) * n + i] = sa[c] * 0.25f;
+            ob[((long long)img * 3 + c) * n + i] = sb[c] * 0.25f;
+        }
+    }
+}
+
 // ---- final: sums -> the three scores per image pair ----
 struct FinalArgs {
     double npx3;              // H * W * 3
@@ -386,6 +414,11 @@ void launch_pool2(hipStream_t st, bool interleaved, const float *in, int B, int 
     dim3 grid(grid_for((long long)h2 * w2), C, B);
     if (interleaved) hipLaunchKernelGGL(k_pool2<true>, grid, dim3(256), 0, st, in, h, w, C, p, h2, w2, out);
     else hipLaunchKernelGGL(k_pool2<false>, grid, dim3(256), 0, st, in, h, w, C, p, h2, w2, out);
+}
+
+void launch_pool2_rgb(hipStream_t st, const float *ia, const float *ib, int B, int h, int w, int p, int h2, int w2, float *oa, float *ob)
+{
+    hipLaunchKernelGGL(k_pool2_rgb, dim3(grid_for((long long)h2 * w2), B), dim3(256), 0, st, ia, ib, h, w, p, h2, w2, oa, ob);
 }
 
 void launch_metric_final(hipStream_t st, const double *acc, int B, long long npx, long long n_ssim, const long long *n_level, double *out)
