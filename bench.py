@@ -223,6 +223,12 @@ def main():
             e.update({"TFLOPs": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / 157.3, 3)})
         dct_sizes[str(sz)] = e
     out["dct_by_block_size"] = dct_sizes
+    # Canny chain a-3 .. a-8 (5 B per plane pixel = float32 plane in, uint8 edge map out -> 7.5 B per image pixel)
+    canny_ms = sum(stage_ms.get(k, 0.0) for k in ("clahe_lut", "clahe_blur", "thresholds", "sobel_nms", "hysteresis"))
+    if canny_ms > 0:
+        gbs = 7.5 * local_px / (canny_ms * 1e-3) / 1e9
+        out["canny_chain"] = {"ms": round(canny_ms, 4), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                              "note": "VALU-bound stencils (DESIGN.md section 4), not HBM-bound"}
 
     # ---- CPU baseline: the C oracle (a scalar port of the reference algorithm) on the host cores, bounded sample:
     # one image per thread (ctypes releases the GIL inside the C call), the fan-out the reference's own sweep uses
