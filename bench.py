@@ -95,12 +95,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    # rehearsal switches (not used by the driver): AEJ_BENCH_BACKEND=gloo + AEJ_BENCH_ONE_DEVICE=1 run the multi-rank control flow
+    # (rendezvous, barriers, reduction, rank-0 print) with every rank on GPU 0 of a one-GPU box; RCCL needs one GPU per rank
+    backend = os.environ.get("AEJ_BENCH_BACKEND", "nccl")
+    if os.environ.get("AEJ_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import adaptive_edge_aware_jpeg_amd as A
     from adaptive_edge_aware_jpeg_amd._lib import get_context
@@ -143,7 +151,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput
-    px_total, dt = aggregate_throughput(dist, B * H * W * args.steps, dt, dev)   # SUM of pixels, MAX of seconds
+    px_total, dt = aggregate_throughput(dist, B * H * W * args.steps, dt, dev if backend == "nccl" else None)   # SUM of pixels, MAX of seconds
 
     value = px_total / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
