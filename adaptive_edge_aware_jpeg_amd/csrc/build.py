@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "color.hip", "canny.hip", "quadtree.hip", "dct.hip", "decode.hip", "metrics.hip"]
-HEADERS = ["aej_common.h", "aej_launch.h", "aej_devmath.h", "inv_constants.h", "pow_tables.h", os.path.join("..", "..", "include", "aej.h")]
+HEADERS = ["aej_common.h", "aej_launch.h", "aej_devmath.h", "inv_constants.h", "pow_tables.h", "aej_mfma.h", "aej_bigblock.h", os.path.join("..", "..", "include", "aej.h")]
 LIB = os.path.join(HERE, "..", "libaejpeg_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

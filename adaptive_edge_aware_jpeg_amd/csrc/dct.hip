@@ -11,10 +11,10 @@
 #include "aej_common.h"
 #include "aej_launch.h"
 #include "aej_bigblock.h"
+#include "aej_mfma.h"
 
 namespace aej {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 // np.pad(mode='reflect') index map for a block clipped to n valid samples (jpeg.py:399-402)
 __device__ __forceinline__ int reflect_pad_idx(int i, int n)
@@ -333,10 +333,6 @@ __device__ __forceinline__ void glds4(const float *g, float *lds_wave_base)
 // half-wave: conflict-free.  The quantisers of the lane's 16 outputs and the next leaf's descriptor are
 // loaded before the MFMA chains so that their latency hides under them.
 // ------------------------------------------------------------------------------------------------
-#ifndef AEJ_MFMA_PF
-#define AEJ_MFMA_PF 4
-#endif
-constexpr int kMfmaPF = AEJ_MFMA_PF;      // A operands requested this many MFMAs ahead
 template <int S>
 struct MfmaCfg {
     static constexpr int NT = S / 32;                       // 32x32 output tiles per side
@@ -369,39 +365,6 @@ __device__ __forceinline__ void dct_load_x(const float *src, int w, int h, const
             const int r = idx / S, c = idx - r * S;
             glds4(src + (long long)(d.z + reflect_pad_idx(r, hc)) * w + d.y + reflect_pad_idx(c, wc), sX + chunk * 64);
         }
-    }
-}
-
-// One chain of S / 2 dependent MFMAs per tile: acc += A(:, 2s .. 2s+1) * B(2s .. 2s+1, :).  The A operands come from LDS; the
-// compiler's own schedule is "read, wait, two MFMAs, read, wait, ..." on one register pair, which exposes the LDS latency
-// once per pair.  Here the operands of the next PF steps are requested before the current PF MFMAs are issued (a scheduling
-// barrier keeps that order), so each wait finds data that was requested PF x 64 cycles earlier.
-template <int S, int TPW, int PF>
-__device__ __forceinline__ void mfma_chain(const float *sA, int tile_stride, int col0, int lh, const float (&dreg)[S / 2], floatx16 (&acc)[TPW])
-{
-    float cur[TPW][PF], nxt[TPW][PF];
-#pragma unroll
-    for (int t = 0; t < TPW; t++)
-#pragma unroll
-        for (int i = 0; i < PF; i++) cur[t][i] = sA[(2 * i + lh) * S + col0 + t * tile_stride];
-#pragma unroll
-    for (int s0 = 0; s0 < S / 2; s0 += PF) {
-        if (s0 + PF < S / 2) {
-#pragma unroll
-            for (int t = 0; t < TPW; t++)
-#pragma unroll
-                for (int i = 0; i < PF; i++) nxt[t][i] = sA[(2 * (s0 + PF + i) + lh) * S + col0 + t * tile_stride];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < PF; i++)
-#pragma unroll
-            for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][i], dreg[s0 + i], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TPW; t++)
-#pragma unroll
-            for (int i = 0; i < PF; i++) cur[t][i] = nxt[t][i];
     }
 }
 

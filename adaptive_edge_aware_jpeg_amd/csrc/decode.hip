@@ -9,12 +9,12 @@
 #include "aej_common.h"
 #include "aej_launch.h"
 #include "aej_bigblock.h"
+#include "aej_mfma.h"
 #include "aej_devmath.h"
 #include "inv_constants.h"
 
 namespace aej {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
 // leaf tables -> per-size work lists (per plane segment; order inside a segment is irrelevant for the result)
@@ -207,15 +207,11 @@ __global__ __launch_bounds__(IdctCfg<S>::NTHREADS) void k_idct_mfma(Geom g, QtGe
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
             const int I0 = (wi0 + t * (NT / TPW)) * 32;
-            floatx16 acc;
+            floatx16 acc1[1];
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < S / 2; s++) {
-                if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                float av = sY[(2 * s + lh) * S + I0 + li];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dreg[s], acc, 0, 0, 0);
-            }
+            for (int r = 0; r < 16; r++) acc1[0][r] = 0.f;
+            mfma_chain<S, 1, kMfmaPF>(sY, 0, I0 + li, lh, dreg, acc1);
+            const floatx16 acc = acc1[0];
 #pragma unroll
             for (int r = 0; r < 16; r++) sP[(I0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * S + J0 + li] = acc[r];
         }
@@ -225,15 +221,11 @@ __global__ __launch_bounds__(IdctCfg<S>::NTHREADS) void k_idct_mfma(Geom g, QtGe
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
             const int I0 = (wi0 + t * (NT / TPW)) * 32;
-            floatx16 acc;
+            floatx16 acc1[1];
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < S / 2; s++) {
-                if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                float av = sP[(2 * s + lh) * S + I0 + li];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dreg[s], acc, 0, 0, 0);
-            }
+            for (int r = 0; r < 16; r++) acc1[0][r] = 0.f;
+            mfma_chain<S, 1, kMfmaPF>(sP, 0, I0 + li, lh, dreg, acc1);
+            const floatx16 acc = acc1[0];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int yy = wk.z + I0 + (r & 3) + 8 * (r >> 2) + 4 * lh, xx = wk.y + J0 + li;
