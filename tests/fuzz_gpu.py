@@ -18,7 +18,7 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     space = spaces[rng.integers(len(spaces))]
-    H, W = int(rng.integers(5, 700)), int(rng.integers(5, 900))
+    H, W = int(rng.integers(5, int(os.environ.get("AEJ_FUZZ_MAXH", "700")))), int(rng.integers(5, int(os.environ.get("AEJ_FUZZ_MAXW", "900"))))
     if rng.random() < 0.3:
         H, W = (H // 4 + 1) * 4, (W // 4 + 1) * 4
     lo = int(2 ** rng.integers(1, 5))
