@@ -230,19 +230,25 @@ __global__ __launch_bounds__(256) void k_ssim_strip(SsimArgs A)
     for (int c = c_begin; c < c_end; c++) {
         float h[kSsimK][5];
         float ss_acc = 0.f, cs_acc = 0.f;
-        auto step = [&](auto ph, int r) {
-            constexpr int PH = decltype(ph)::value;
+        const int cA = x0 + lane, cB = x0 + 64 + lane;
+        float pxa = 0.f, pya = 0.f, pxb = 0.f, pyb = 0.f;      // the NEXT input row, fetched one row ahead (its HBM / L2 latency hides under a row of arithmetic)
+        auto fetch = [&](int r) {
+            pxa = pya = pxb = pyb = 0.f;
             if (r >= R) return;
             const int gy = y0 + r;
-            const int cA = x0 + lane, cB = x0 + 64 + lane;
             auto at = [&](int col) -> long long {
                 return INTERLEAVED ? (((long long)img * A.h + gy) * A.w + col) * A.C + c : (((long long)img * A.C + c) * A.h + gy) * A.w + col;
             };
-            float xa = 0.f, ya = 0.f, xb = 0.f, yb = 0.f;
-            if (cA < A.w) { xa = A.xa[at(cA)]; ya = A.xb[at(cA)]; }
-            if (lane < kSsimK - 1 && cB < A.w) { xb = A.xa[at(cB)]; yb = A.xb[at(cB)]; }
-            wx[lane] = xa; wy[lane] = ya;
-            if (lane < kSsimK - 1) { wx[64 + lane] = xb; wy[64 + lane] = yb; }
+            if (cA < A.w) { pxa = A.xa[at(cA)]; pya = A.xb[at(cA)]; }
+            if (lane < kSsimK - 1 && cB < A.w) { pxb = A.xa[at(cB)]; pyb = A.xb[at(cB)]; }
+        };
+        fetch(0);
+        auto step = [&](auto ph, int r) {
+            constexpr int PH = decltype(ph)::value;
+            if (r >= R) return;
+            wx[lane] = pxa; wy[lane] = pya;
+            if (lane < kSsimK - 1) { wx[64 + lane] = pxb; wy[64 + lane] = pyb; }
+            fetch(r + 1);
             __builtin_amdgcn_wave_barrier();
             float mx = 0.f, my = 0.f, mxx = 0.f, myy = 0.f, mxy = 0.f;
 #pragma unroll
