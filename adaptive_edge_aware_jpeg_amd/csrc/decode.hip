@@ -367,49 +367,82 @@ __global__ __launch_bounds__(256) void k_color_inverse(const float *__restrict__
     }
 }
 
-// cv.resize(layer, (W, H), INTER_LINEAR) sample at (dx, dy) (OpenCV resizeGeneric_, HResizeLinear + VResizeLinear, float32)
-__device__ __forceinline__ float bilinear_at(const float *__restrict__ src, int h, int w, int H, int W, int dx, int dy)
+// cv.resize(layer, (W, H), INTER_LINEAR) sample at (dx, dy) (OpenCV resizeGeneric_, HResizeLinear + VResizeLinear, float32).
+// scale_x / scale_y = 1.0 / ((double)W / w), 1.0 / ((double)H / h): formed once on the host (the same IEEE double operations).
+struct UpScale { double sx[3], sy[3]; };
+
+struct RowTaps { const float *s0, *s1; float b0, b1; };
+
+__device__ __forceinline__ RowTaps row_taps(const float *__restrict__ src, int h, int w, double scale_y, int dy)
 {
-    if (h == H && w == W) return src[(long long)dy * w + dx];
-    const double scale_x = 1.0 / ((double)W / (double)w), scale_y = 1.0 / ((double)H / (double)h);
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    RowTaps t;
+    t.b0 = 1.f - fy; t.b1 = fy;
+    const int y0 = sy < 0 ? 0 : sy > h - 1 ? h - 1 : sy, y1 = sy + 1 < 0 ? 0 : sy + 1 > h - 1 ? h - 1 : sy + 1;
+    t.s0 = src + (long long)y0 * w; t.s1 = src + (long long)y1 * w;
+    return t;
+}
+
+struct ColTaps { int sx; float a0, a1; bool two; };
+
+__device__ __forceinline__ ColTaps col_taps(int w, double scale_x, int dx)
+{
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
     int sx = (int)floorf(fx);
     fx -= (float)sx;
     if (sx < 0) { fx = 0.f; sx = 0; }
     if (sx >= w - 1) { fx = 0.f; sx = w - 1; }
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
-    int sy = (int)floorf(fy);
-    fy -= (float)sy;
-    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-    const int y0 = sy < 0 ? 0 : sy > h - 1 ? h - 1 : sy, y1 = sy + 1 < 0 ? 0 : sy + 1 > h - 1 ? h - 1 : sy + 1;
-    const float *s0 = src + (long long)y0 * w, *s1 = src + (long long)y1 * w;
+    ColTaps c;
+    c.sx = sx; c.a0 = 1.f - fx; c.a1 = fx; c.two = sx + 1 < w;
+    return c;
+}
+
+__device__ __forceinline__ float bilinear_at(const RowTaps &t, const ColTaps &c)
+{
     float r0, r1;
-    if (sx + 1 < w) {
-        float p = s0[sx] * a0, q = s0[sx + 1] * a1; r0 = p + q;
-        p = s1[sx] * a0; q = s1[sx + 1] * a1; r1 = p + q;
+    if (c.two) {
+        float p = t.s0[c.sx] * c.a0, q = t.s0[c.sx + 1] * c.a1; r0 = p + q;
+        p = t.s1[c.sx] * c.a0; q = t.s1[c.sx + 1] * c.a1; r1 = p + q;
     } else {
-        r0 = s0[sx] * 1.0f; r1 = s1[sx] * 1.0f;
+        r0 = t.s0[c.sx] * 1.0f; r1 = t.s1[c.sx] * 1.0f;
     }
-    float p = r0 * b0, q = r1 * b1;
+    float p = r0 * t.b0, q = r1 * t.b1;
     return p + q;
 }
 
-// up-sample the three layers to full resolution and apply the inverse colour transform: planes -> rgb [B][H][W][3]
+// up-sample the three layers to full resolution and apply the inverse colour transform: planes -> rgb [B][H][W][3].
+// Thread = one column, walking kUpRows rows (the column taps are computed once); lanes along x so plane reads are coalesced;
+// grid = (x groups, row groups, images): no index divisions.
+constexpr int kUpRows = 16;
+
 template <int SPACE>
-__global__ __launch_bounds__(256) void k_upsample_color(Geom g, const float *__restrict__ planes, float *__restrict__ rgb)
+__global__ __launch_bounds__(256) void k_upsample_color(Geom g, UpScale us, const float *__restrict__ planes, float *__restrict__ rgb)
 {
-    const int b = blockIdx.y;
-    const long long n = (long long)g.H * g.W;
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
     const float *pl = planes + (long long)b * g.pstride;
-    float *out = rgb + (long long)b * n * 3;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int y = (int)(i / g.W), x = (int)(i - (long long)y * g.W);
-        float c0 = bilinear_at(pl + g.poff[0], g.h[0], g.w[0], g.H, g.W, x, y);
-        float c1 = bilinear_at(pl + g.poff[1], g.h[1], g.w[1], g.H, g.W, x, y);
-        float c2 = bilinear_at(pl + g.poff[2], g.h[2], g.w[2], g.H, g.W, x, y);
+    bool same[3];
+    ColTaps ct[3];
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        same[l] = g.h[l] == g.H && g.w[l] == g.W;
+        if (!same[l]) ct[l] = col_taps(g.w[l], us.sx[l], x);
+    }
+    const int y_end = min(g.H, (int)(blockIdx.y + 1) * kUpRows);
+    for (int y = blockIdx.y * kUpRows; y < y_end; y++) {
+        float c[3];
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            if (same[l]) c[l] = pl[g.poff[l] + (long long)y * g.w[l] + x];
+            else c[l] = bilinear_at(row_taps(pl + g.poff[l], g.h[l], g.w[l], us.sy[l], y), ct[l]);
+        }
         float r, gg, bb;
-        color_inv_px<SPACE>(c0, c1, c2, r, gg, bb);
-        out[3 * i] = r; out[3 * i + 1] = gg; out[3 * i + 2] = bb;
+        color_inv_px<SPACE>(c[0], c[1], c[2], r, gg, bb);
+        float *out = rgb + (((long long)b * g.H + y) * g.W + x) * 3;
+        out[0] = r; out[1] = gg; out[2] = bb;
     }
 }
 
@@ -490,10 +523,12 @@ int launch_color_inverse(hipStream_t st, int space, const float *in, float *out,
 template <int SPACE>
 static void launch_up_t(hipStream_t st, const Geom &g, const float *planes, float *rgb)
 {
-    long long n = (long long)g.H * g.W;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_upsample_color<SPACE>, dim3(blocks, g.B), dim3(256), 0, st, g, planes, rgb);
+    UpScale us;
+    for (int l = 0; l < 3; l++) {
+        us.sx[l] = 1.0 / ((double)g.W / (double)g.w[l]);
+        us.sy[l] = 1.0 / ((double)g.H / (double)g.h[l]);
+    }
+    hipLaunchKernelGGL(k_upsample_color<SPACE>, dim3((g.W + 255) / 256, (g.H + kUpRows - 1) / kUpRows, g.B), dim3(256), 0, st, g, us, planes, rgb);
 }
 
 int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float *planes, float *rgb)
