@@ -30,7 +30,8 @@ struct aej_ctx {
     int *h_flag = nullptr;             // pinned host word for counter read-backs
     int last_hyst_passes = 0;
     int hyst_hint = 0;                 // passes the previous encode needed (speculative enqueue, verified at the end of the call)
-    int hyst_margin = 4;               // extra passes enqueued on top of the hint
+    int hyst_margin = 4;               // extra passes enqueued on top of the hint: shrinks to 2 while calls keep converging early, grows after a miss
+    int hyst_streak = 0;               // consecutive calls that converged with at least 2 spare passes
     int hyst_enqueued = 0;             // passes enqueued speculatively by the current call (0 = verified path)
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;
@@ -688,8 +689,15 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
             while (used > 1 && pc[used - 1] == 0) used--;
             ctx->hyst_hint = used;
             ctx->last_hyst_passes = used;
+            if (n - used >= 2) {
+                if (++ctx->hyst_streak >= 8 && ctx->hyst_margin > 2) { ctx->hyst_margin--; ctx->hyst_streak = 0; }
+            } else {
+                ctx->hyst_streak = 0;
+            }
             break;
         }
+        ctx->hyst_streak = 0;
+        if (ctx->hyst_margin < 8) ctx->hyst_margin += 2;
         // rare: the edge map was not at its fix-point when the quadtree ran -- finish the hysteresis, redo what follows
         if (attempt > 0) return fail(ctx, AEJ_ERR_STATE, "hysteresis verification failed twice");
         if ((rc = run_hysteresis(ctx, g, w.canny, false, n))) return rc;
@@ -1099,6 +1107,7 @@ extern "C" int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin)
     if (!ctx || passes < 0 || margin < 0) return AEJ_ERR_ARG;
     ctx->hyst_hint = passes;       // 0 = next whole-path call runs in verified mode
     ctx->hyst_margin = margin;
+    ctx->hyst_streak = 0;
     return 0;
 }
 
