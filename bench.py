@@ -179,7 +179,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX[dom] * local_px, "avg_launch_ms": round(kernels[dom], 4),
-                "note": "priced against HBM as the contract asks; PMC (profiles/r01_d_pmc_valu_lds.txt) shows the stencil / quadtree kernels "
+                "note": "priced against HBM as the contract asks; PMC (profiles/r01_f_pmc_valu_lds.txt) shows the stencil / quadtree kernels "
                         "of this path are VALU-issue-bound (blur ~100 % VALU-busy), DESIGN.md section 4"}
     whole_bpp = WHOLE_PATH_BYTES_PER_PX - (9.0 if args.ingest == "u8" else 0.0)
     whole = whole_bpp * local_px / (ms_per_step * 1e-3) / 1e9
