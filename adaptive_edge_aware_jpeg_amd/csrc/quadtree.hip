@@ -279,6 +279,26 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
     if ((long long)chunk >= q.nchunk[l]) return;
     const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
     const unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
+    {
+        // A chunk that lies wholly outside the plane (about half of the root square) can originate one thing only: the
+        // absent-child symbol '10' of a node whose origin is the chunk's first cell.  Only lane 0 has anything to evaluate.
+        int ccx, ccy;
+        morton_decode(chunk, ccx, ccy);
+        if (ccx * 16 * q.cell >= g.w[l] || ccy * 16 * q.cell >= g.h[l]) {
+            ChunkEdges Z;
+            Z.e0 = 0; Z.e1 = Z.e2 = Z.e3 = Z.e4 = false;
+            int ns = 0;
+            if (lane == 0 && (long long)chunk * 256 < ncell2) ns = eval_cell(q, l, g.w[l], g.h[l], Z, pyr, chunk * 256u, ccx * 16, ccy * 16).nsym;
+            lane_code[((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * 64 + lane] = (unsigned short)(ns ? 3u : 0u);
+            if (lane == 0) {
+                int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
+                o[0] = ns; o[1] = 0; o[2] = 0; o[3] = 0;
+#pragma unroll
+                for (int k = 0; k < kMaxSizes; k++) o[4 + k] = 0;
+            }
+            return;
+        }
+    }
     const ChunkEdges E = chunk_edges(g, q, l, b, edge_bits, chunk, lane);
     int nsym = 0, nleaf = 0, ncoef = 0;
     int nsz[kMaxSizes];
@@ -383,7 +403,9 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
     if ((long long)chunk >= q.nchunk[l]) return;
     const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
     CellNodes c[4];
-    unpack_lane(qb.lane_code[((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * 64 + lane], chunk * 256u + (unsigned)lane * 4u, q.ltot[l], c);
+    const unsigned code = qb.lane_code[((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * 64 + lane];
+    if (!__any(code != 0)) return;        // nothing originates in this chunk (about half of the root square lies outside the plane)
+    unpack_lane(code, chunk * 256u + (unsigned)lane * 4u, q.ltot[l], c);
     int ccx, ccy, lx, ly;
     morton_decode(chunk, ccx, ccy);
     morton_decode((unsigned)lane, lx, ly);
