@@ -729,6 +729,7 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
             unsigned long long Bl = (hasB && hasL) ? Blw >> 63 : 0ull, Br = (hasB && hasR) ? Brw & 1ull : 0ull;
             if (!hasT) Tm = 0;
             if (!hasB) Bm = 0;
+            if (!__any(W != 0ull)) break;        // no candidate pixel in the tile: nothing can change here
             const unsigned long long S0 = S;
             for (;;) {
                 unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
