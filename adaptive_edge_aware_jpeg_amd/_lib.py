@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaejpeg_hip.so")
 
 SPACE_IDS = {"YCbCr": 0, "YCoCg": 1, "YCoCg-R": 2, "OKLAB": 3, "ICtCp": 4, "ICaCb": 5, "JzAzBz": 6}
+CONVERT_IDS = dict(SPACE_IDS, XYZ=7)     # color.convert also serves the helper space XYZ (conversion.py:63-68); not a codec space
 
 AEJ_ERR_ARG, AEJ_ERR_HIP, AEJ_ERR_STATE, AEJ_ERR_CAPACITY, AEJ_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 
@@ -44,6 +45,9 @@ SIGNATURES = {
     "aej_destroy": (None, [_P]),
     "aej_last_error": (ctypes.c_char_p, [_P]),
     "aej_synchronize": (_I, [_P]),
+    "aej_set_stream": (_I, [_P, _P]),
+    "aej_set_hysteresis_speculation": (_I, [_P, _I]),
+    "aej_get_hysteresis_stats": (_I, [_P, _P]),
     "aej_last_hysteresis_passes": (_I, [_P]),
     "aej_set_hysteresis_hint": (_I, [_P, _I, _I]),
     "aej_set_profiling": (_I, [_P, _I]),
@@ -100,19 +104,27 @@ def _torch():
 
 
 class Context:
-    """One aej_ctx bound to a device and to that device's current torch stream."""
+    """One aej_ctx bound to a device and to ONE torch stream of it (the stream that was current when get_context()
+    created it).  Everything torch does for a call -- input copies, output and workspace allocation -- happens on the stream
+    current at call time, so the library must enqueue on that same stream; get_context() therefore hands out one context per
+    (device, stream), each with its own workspace, and `check_stream()` refuses a context used under another stream."""
 
     def __init__(self, device=0):
         self.torch = _torch()
         self.lib = load_library()
         self.device = self.torch.device("cuda", device if isinstance(device, int) else device.index or 0)
-        with self.torch.cuda.device(self.device):
-            stream = self.torch.cuda.current_stream().cuda_stream
-        self.handle = self.lib.aej_create(self.device.index, ctypes.c_void_p(stream))
+        self.stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.handle = self.lib.aej_create(self.device.index, ctypes.c_void_p(self.stream))
         if not self.handle:
             raise AejError(self.lib.aej_last_error(None).decode())
         self.settings_key = None
         self._ws = None
+
+    def check_stream(self):
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self.stream:
+            raise AejError(f"context bound to stream {self.stream:#x} used while torch's current stream is {cur:#x}: "
+                           "obtain the context with get_context() inside the `torch.cuda.stream(...)` block")
 
     def __del__(self):
         try:
@@ -137,10 +149,23 @@ class Context:
         return self.torch.empty(shape, dtype=dtype, device=self.device)
 
     def workspace(self, nbytes):
+        """Scratch of at least `nbytes`, reused across calls.  It is allocated on, and only ever used by kernels of, this
+        context's stream, so dropping the old tensor when a larger one is needed is safe: torch's caching allocator hands a
+        freed block only to later work of the same stream."""
+        self.check_stream()
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
         return self._ws
+
+    def hysteresis_stats(self):
+        """-> dict(calls, speculative, misses, enqueued) of aej_encode_batch on this context (include/aej.h)."""
+        buf = (ctypes.c_int64 * 4)()
+        self.check(self.lib.aej_get_hysteresis_stats(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
+        return {"calls": int(buf[0]), "speculative": int(buf[1]), "misses": int(buf[2]), "enqueued": int(buf[3])}
+
+    def set_speculation(self, on):
+        self.check(self.lib.aej_set_hysteresis_speculation(self.handle, 1 if on else 0))
 
     def to_device(self, arr, dtype):
         t = self.torch
@@ -178,8 +203,11 @@ _contexts = {}
 
 
 def get_context(device=0):
+    """The context of (device, torch's current stream on it); created on first use."""
     idx = device if isinstance(device, int) else (device.index or 0)
-    ctx = _contexts.get(idx)
+    torch = _torch()
+    key = (idx, torch.cuda.current_stream(torch.device("cuda", idx)).cuda_stream)
+    ctx = _contexts.get(key)
     if ctx is None:
-        ctx = _contexts[idx] = Context(idx)
+        ctx = _contexts[key] = Context(idx)
     return ctx

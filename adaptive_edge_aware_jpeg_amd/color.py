@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import SPACE_IDS, get_context
+from ._lib import CONVERT_IDS, get_context
 
 # MIDPOINTS / SCALE_FACTORS exactly as the reference declares them (float32 of these literals):
 # ycbcr.py:41-42, ycocg.py:41-42,62-63, oklab.py:51-52, ictcp.py:162-163, icacb.py:162-163, jzazbz.py:211-212,
@@ -41,7 +41,9 @@ def _check(data):
 
 
 def convert(from_space: str, to_space: str, data: np.ndarray) -> np.ndarray:
-    """conversion.py:95-124.  Computes in float32 on the GPU (the codec always feeds float32)."""
+    """conversion.py:95-124.  Computes in float32 on the GPU: the codec always feeds float32 (image.py:80); float64 input
+    (the reference's own colour unit test feeds a float64 grid, test_color_conversions.py:31-33) is rounded to float32 first
+    and the result is float32, as the reference's transforms return."""
     _check(data)
     if from_space not in _ALL_SPACES or to_space not in _ALL_SPACES:
         raise ValueError("Invalid color space. Please check the available color spaces.")
@@ -50,22 +52,18 @@ def convert(from_space: str, to_space: str, data: np.ndarray) -> np.ndarray:
     if from_space == "sRGB":
         if to_space == "sRGB":
             return None     # the reference's table holds None callables for sRGB and would raise; keep it inert
-        if to_space == "XYZ":
-            raise NotImplementedError("sRGB -> XYZ is not on the codec path and is not built")
         ctx = get_context()
         t = ctx.torch
         x = ctx.to_device(data, t.float32)
         out = t.empty_like(x)
-        ctx.check(ctx.lib.aej_color_convert(ctx.handle, SPACE_IDS[to_space], x.data_ptr(), out.data_ptr(),
+        ctx.check(ctx.lib.aej_color_convert(ctx.handle, CONVERT_IDS[to_space], x.data_ptr(), out.data_ptr(),
                                             ctypes.c_int64(x.shape[0])))
         return out.cpu().numpy()
-    if from_space == "XYZ":
-        raise NotImplementedError("XYZ -> sRGB is not on the codec path and is not built")
     ctx = get_context()
     t = ctx.torch
     x = ctx.to_device(data, t.float32)
     out = t.empty_like(x)
-    ctx.check(ctx.lib.aej_color_convert_inverse(ctx.handle, SPACE_IDS[from_space], x.data_ptr(), out.data_ptr(),
+    ctx.check(ctx.lib.aej_color_convert_inverse(ctx.handle, CONVERT_IDS[from_space], x.data_ptr(), out.data_ptr(),
                                                 ctypes.c_int64(x.shape[0])))
     return out.cpu().numpy()
 

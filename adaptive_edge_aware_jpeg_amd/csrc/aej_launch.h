@@ -83,7 +83,7 @@ struct DctArgs {
     const int *zzinv;         // [s*s]
     const int *qm[3];         // [s*s] per layer
 };
-void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items);
+int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items);   // 0, or -1 when no kernel serves the request
 // builds a work list from a leaf table (stand-alone aej_dct_quant_zigzag)
 void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int bmin, int plane, LeafWork *const *work, int *work_count);
 
@@ -102,7 +102,7 @@ struct IdctArgs {
     float mid[3], scale[3];
 };
 void launch_work_from_tables(hipStream_t st, const Geom &g, const QtGeom &q, const int *leaves, const long long *counts, LeafWork *const *work,
-                             int *work_count);
+                             int *work_count, int *bad /* [1], zeroed by the caller: set when the tables do not fit the plan */);
 void launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const IdctArgs &a, long long max_items);
 int launch_color_inverse(hipStream_t st, int space, const float *in, float *out, long long n);
 int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float *planes, float *rgb);

@@ -33,6 +33,8 @@ struct aej_ctx {
     int hyst_margin = 4;               // extra passes enqueued on top of the hint: shrinks to 2 while calls keep converging early, grows after a miss
     int hyst_streak = 0;               // consecutive calls that converged with at least 2 spare passes
     int hyst_enqueued = 0;             // passes enqueued speculatively by the current call (0 = verified path)
+    bool hyst_speculate = true;        // aej_set_hysteresis_speculation: false = every whole-path call runs the verified loop
+    long long n_encode_calls = 0, n_spec_calls = 0, n_spec_misses = 0;   // aej_get_hysteresis_stats
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;
     hipEvent_t ev[24] = {};
@@ -440,7 +442,7 @@ static int run_hysteresis(aej_ctx *ctx, const Geom &g, CannyWs &w, bool speculat
     const int group = 8;
     int pass = first_pass;
     ctx->hyst_enqueued = 0;
-    if (speculate && ctx->hyst_hint > 0 && first_pass == 0) {
+    if (speculate && ctx->hyst_speculate && ctx->hyst_hint > 0 && first_pass == 0) {
         int n = ctx->hyst_hint + ctx->hyst_margin;
         if (n > kMaxHystPasses - group) n = kMaxHystPasses - group;
         for (int i = 0; i < n; i++) launch_hyst_pass(st, g, w.cb, pass++);
@@ -644,6 +646,7 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     w.canny.cb.space_w = ctx->d_space_w;
     w.canny.cb.color_w = ctx->d_color_w;
     ctx->n_ev = 0;
+    ctx->n_encode_calls++;
     mark(ctx, -1);
     if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
     mark(ctx, AEJ_STAGE_CLEAR);
@@ -666,7 +669,7 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
             a.scratch = w.big;
             a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
             for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
-            launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k]);
+            if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k])) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
             mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
         }
         AEJ_HIP_CHECK(hipGetLastError());
@@ -679,11 +682,7 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
         if (n == 0) break;
         const int *pc = ctx->h_flag + 1;
-        if (getenv("AEJ_DEBUG_HYST")) {       // diagnostic: tiles queued per pass
-            fprintf(stderr, "[aej] hysteresis work lists:");
-            for (int i = 0; i <= n; i++) fprintf(stderr, " %d", pc[i]);
-            fprintf(stderr, "\n");
-        }
+        if (attempt == 0) ctx->n_spec_calls++;
         if (pc[n] == 0) {                       // converged within the speculative passes: remember how many were needed
             int used = n;
             while (used > 1 && pc[used - 1] == 0) used--;
@@ -697,6 +696,7 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
             break;
         }
         ctx->hyst_streak = 0;
+        ctx->n_spec_misses++;
         if (ctx->hyst_margin < 8) ctx->hyst_margin += 2;
         // rare: the edge map was not at its fix-point when the quadtree ran -- finish the hysteresis, redo what follows
         if (attempt > 0) return fail(ctx, AEJ_ERR_STATE, "hysteresis verification failed twice");
@@ -894,9 +894,9 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
             a.scratch = big_scratch_floats(ctx->bmax) ? reinterpret_cast<float *>(scratch + big_off) : nullptr;
             a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
             for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
-            launch_dct(st, s, g, q, a, n_leaves);
+            if (launch_dct(st, s, g, q, a, n_leaves)) { e = hipErrorInvalidValue; break; }
         }
-        e = hipGetLastError();
+        if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     (void)hipFree(scratch);
@@ -913,10 +913,11 @@ extern "C" int64_t aej_leaf_positions_host(const int32_t *sizes_host, int64_t n,
     std::vector<It> stack;
     stack.push_back({ 0, 0, root });
     int64_t li = 0;
-    while (!stack.empty() && li < n) {
+    while (!stack.empty()) {
         It it = stack.back();
         stack.pop_back();
         if (it.x >= W || it.y >= H || it.s == 0) continue;
+        if (li >= n) return -2;      // a node inside the layer is left without a leaf: the sizes do not tile it
         if (it.s == sizes_host[li]) { xy_host[2 * li] = it.x; xy_host[2 * li + 1] = it.y; li++; }
         else {
             int h = it.s / 2;
@@ -953,7 +954,7 @@ static void carve_decode(void *base, const Geom &g, const QtGeom &q, DecodeWs &w
 {
     Carver c(base);
     w.planes = c.take<float>((long long)g.B * g.pstride);
-    w.work_count = c.take<int>((long long)g.B * 3 * kMaxSizes);
+    w.work_count = c.take<int>((long long)g.B * 3 * kMaxSizes + 1);       // + 1: the "tables do not fit the plan" flag
     for (int k = 0; k < kMaxSizes; k++) { w.work[k] = nullptr; w.work_cap[k] = 0; }
     for (int k = 0; k < q.nsizes; k++) {
         w.work_cap[k] = q.work_stride[k] * g.B;
@@ -989,8 +990,9 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
     carve_decode(workspace, g, q, w);
     if (w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes", w.bytes);
     hipStream_t st = ctx->stream;
-    AEJ_HIP_CHECK(hipMemsetAsync(w.work_count, 0, (size_t)batch * 3 * kMaxSizes * sizeof(int), st));
-    launch_work_from_tables(st, g, q, leaves, reinterpret_cast<const long long *>(counts), w.work, w.work_count);
+    int *bad = w.work_count + (size_t)batch * 3 * kMaxSizes;
+    AEJ_HIP_CHECK(hipMemsetAsync(w.work_count, 0, ((size_t)batch * 3 * kMaxSizes + 1) * sizeof(int), st));
+    launch_work_from_tables(st, g, q, leaves, reinterpret_cast<const long long *>(counts), w.work, w.work_count, bad);
     int k = 0;
     for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
         IdctArgs a;
@@ -1002,7 +1004,9 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
     }
     if (launch_upsample_color(st, ctx->space, g, w.planes, rgb_out)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
     AEJ_HIP_CHECK(hipGetLastError());
+    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, bad, sizeof(int), hipMemcpyDeviceToHost, st));
     AEJ_HIP_CHECK(hipStreamSynchronize(st));
+    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_ARG, "corrupt stream: the leaf tables do not fit the plan (leaf count, block size outside %d-%d, or too many leaves of one size)", q.bmin, q.bmax);
     return 0;
 }
 
@@ -1108,6 +1112,34 @@ extern "C" int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin)
     ctx->hyst_hint = passes;       // 0 = next whole-path call runs in verified mode
     ctx->hyst_margin = margin;
     ctx->hyst_streak = 0;
+    return 0;
+}
+
+extern "C" int aej_set_hysteresis_speculation(aej_ctx *ctx, int enable)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    ctx->hyst_speculate = enable != 0;
+    return 0;
+}
+
+extern "C" int aej_get_hysteresis_stats(aej_ctx *ctx, int64_t *out_host)
+{
+    if (!ctx || !out_host) return AEJ_ERR_ARG;
+    out_host[0] = ctx->n_encode_calls;
+    out_host[1] = ctx->n_spec_calls;
+    out_host[2] = ctx->n_spec_misses;
+    out_host[3] = ctx->hyst_enqueued;
+    return 0;
+}
+
+extern "C" int aej_set_stream(aej_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (s == ctx->stream) return 0;
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // nothing of ours is left running on the stream we leave
+    ctx->stream = s;
     return 0;
 }
 

@@ -680,7 +680,8 @@ __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed,
 // next pass but processes one of them itself straight away (up to kChaseDepth tiles in a row), so a long thin contour advances
 // many tiles per pass instead of one and the number of (launch-latency-bound) passes drops.  Two waves may then work on the same
 // tile at the same time, so CHASE writes words with atomicOr and reads them with agent-scope (cache-bypassing) loads; a missed
-// update is always repaired because whoever changes a border re-queues or re-processes the neighbour behind it.
+// update is always repaired because whoever changes a border re-queues or re-processes the neighbour behind it (after its own
+// writes have been acknowledged, see the s_waitcnt below).
 constexpr int kChaseDepth = 32;
 
 template <bool CHASE>
@@ -751,6 +752,10 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
                 if constexpr (CHASE) atomicOr(&sg[o], S);
                 else sg[o] = S;
             }
+            // CHASE: this wave may now process a neighbour itself and read, as that tile's halo, the very words it has just
+            // OR-ed -- without queueing the neighbour for anyone else.  Drain the atomics first (they execute at the L2 /
+            // memory side, which also serves the agent-scope loads), so that those loads cannot overtake them.
+            if constexpr (CHASE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // which of the 8 neighbours see a changed pixel next to them: new bits in the first / last valid row (and their end
             // columns for the diagonal neighbours), in the first / last column
             const int last_row = min(63, h - 1 - ty * 64);

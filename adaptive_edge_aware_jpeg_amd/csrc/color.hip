@@ -72,6 +72,8 @@ __device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o
             o1 = (float)lin3d(F(4.2854), F(-4.5462), F(0.2609), Lp, Mp, Sp);
             o2 = (float)lin3d(F(0.3605), F(1.1499), F(-1.5105), Lp, Mp, Sp);
         }
+    } else if constexpr (SPACE == 7) {    // XYZ itself, xyz.py:63-64 (helper space of color.convert; not a codec space)
+        to_xyz(r, g, b, o0, o1, o2);
     } else {                              // JzAzBz, jzazbz.py:54-99, 178-206
         float X, Y, Z;
         to_xyz(r, g, b, X, Y, Z);
@@ -395,6 +397,7 @@ int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out
     case 4: launch_convert_t<4>(st, rgb, out, n); break;
     case 5: launch_convert_t<5>(st, rgb, out, n); break;
     case 6: launch_convert_t<6>(st, rgb, out, n); break;
+    case 7: launch_convert_t<7>(st, rgb, out, n); break;
     default: return -1;
     }
     return 0;

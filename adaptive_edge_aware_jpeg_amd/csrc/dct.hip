@@ -502,9 +502,10 @@ static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const 
     hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(MfmaCfg<S>::NTHREADS), lds, st, g, q, a, max_items);
 }
 
-void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
+int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
 {
-    if (max_items <= 0 || a.nplanes > kMaxPlanes) return;
+    if (max_items <= 0) return 0;                  // an empty work list is not an error
+    if (a.nplanes > kMaxPlanes) return -1;         // the per-plane prefix table would not fit the launch's LDS
     const size_t pref = (size_t)(a.nplanes + 1) * sizeof(int);
     auto cap = [&](long long per_block, int hi) {
         long long b = (max_items + per_block - 1) / per_block;
@@ -529,14 +530,15 @@ void launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const 
     case 64: AEJ_MFMA(64, 768); break;
     case 128: AEJ_MFMA(128, 256); break;
     case 256:
-        if (!a.scratch) break;       // callers reserve it whenever the settings allow this size
+        if (!a.scratch) return -1;   // callers reserve it whenever the settings allow this size
         if (wd) hipLaunchKernelGGL((k_dct_big<256, true>), dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a, max_items);
         else hipLaunchKernelGGL((k_dct_big<256, false>), dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a, max_items);
         break;
-    default: break;
+    default: return -1;
     }
 #undef AEJ_SMALL
 #undef AEJ_MFMA
+    return 0;
 }
 
 }  // namespace aej

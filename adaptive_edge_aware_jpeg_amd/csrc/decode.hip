@@ -21,16 +21,22 @@ namespace aej {
 // ------------------------------------------------------------------------------------------------
 struct WorkPtrsD { LeafWork *w[kMaxSizes]; };
 
+// A leaf table that does not fit the plan (more leaves than the layer can hold, a size outside the settings' block range, more
+// leaves of one size than its work list holds) sets *bad instead of writing out of bounds; aej_decode_batch reports it.
 __global__ __launch_bounds__(256) void k_work_from_tables(Geom g, QtGeom q, const int *__restrict__ leaves, const long long *__restrict__ counts,
-                                                          WorkPtrsD wp, int *__restrict__ work_count, int bmin_log2)
+                                                          WorkPtrsD wp, int *__restrict__ work_count, int bmin_log2, int *__restrict__ bad)
 {
     const int l = blockIdx.y, b = blockIdx.z, plane = b * 3 + l;
-    const long long n = counts[(long long)plane * 4 + 1];
+    long long n = counts[(long long)plane * 4 + 1];
+    if (n < 0 || n > q.leaf_cap[l]) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *bad = 1;
+        n = 0;
+    }
     const int4 *tab = reinterpret_cast<const int4 *>(leaves) + (long long)b * q.leaf_stride + q.leaf_off[l];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         int4 lf = tab[i];
         int k = (31 - __clz(lf.z)) - bmin_log2;
-        if (k < 0 || k >= q.nsizes || !wp.w[k]) k = -1;
+        if (k < 0 || k >= q.nsizes || !wp.w[k] || lf.z != (q.bmin << k)) { k = -1; *bad = 1; }
         // one atomic per wave and block size instead of one per leaf (all lanes of a wave work on the same plane): a few
         // counters shared by 10^5 leaves per image serialise otherwise.  List order is irrelevant to the decode.
         const int lane = threadIdx.x & 63;
@@ -44,8 +50,11 @@ __global__ __launch_bounds__(256) void k_work_from_tables(Geom g, QtGeom q, cons
             base = __shfl(base, leader);
             if (k == kk) pos = base + __popcll(m & ((1ull << lane) - 1ull));
         }
-        if (k >= 0)
-            reinterpret_cast<int4 *>(wp.w[k])[(long long)b * q.work_stride[k] + q.work_off[l][k] + pos] = make_int4(plane, lf.x, lf.y, lf.w);
+        if (k >= 0) {
+            const long long cap = (l < 2 ? q.work_off[l + 1][k] : q.work_stride[k]) - q.work_off[l][k];      // this plane's segment of the list
+            if (pos < cap) reinterpret_cast<int4 *>(wp.w[k])[(long long)b * q.work_stride[k] + q.work_off[l][k] + pos] = make_int4(plane, lf.x, lf.y, lf.w);
+            else *bad = 1;
+        }
     }
 }
 
@@ -342,6 +351,8 @@ __device__ __forceinline__ void color_inv_px(float a, float b, float c, float &r
         const double pm2 = 2523.0 / 32.0;
         double L = pq_eotf((double)Lp, pm2), M = pq_eotf((double)Mp, pm2), S = pq_eotf((double)Sp, pm2);
         xyz_to_srgb((float)ilin3d(m1 + 0, L, M, S), (float)ilin3d(m1 + 3, L, M, S), (float)ilin3d(m1 + 6, L, M, S), r, g, bl);
+    } else if constexpr (SPACE == 7) {    // XYZ -> sRGB, xyz.py:83-84 (helper space of color.convert)
+        xyz_to_srgb(a, b, c, r, g, bl);
     } else {
         const double bb = 1.15, gg = 0.66, d = -0.56, d0 = 1.6295499532821566e-11, p = 1.7 * 2523.0 / 32.0;
         const unsigned *m2 = INV_JZ_LMSP_BITS, *m1 = INV_JZ_LMS_XYZ_BITS;
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256) void k_upsample_color(Geom g, UpScale us, cons
 // launchers
 // ------------------------------------------------------------------------------------------------
 void launch_work_from_tables(hipStream_t st, const Geom &g, const QtGeom &q, const int *leaves, const long long *counts, LeafWork *const *work,
-                             int *work_count)
+                             int *work_count, int *bad)
 {
     WorkPtrsD wp;
     for (int k = 0; k < kMaxSizes; k++) wp.w[k] = work[k];
@@ -458,7 +469,7 @@ void launch_work_from_tables(hipStream_t st, const Geom &g, const QtGeom &q, con
     for (int l = 0; l < 3; l++) if (q.leaf_cap[l] > mx) mx = q.leaf_cap[l];
     int bx = (int)((mx + 255) / 256);
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_work_from_tables, dim3(bx, 3, g.B), dim3(256), 0, st, g, q, leaves, counts, wp, work_count, ilog2(q.bmin));
+    hipLaunchKernelGGL(k_work_from_tables, dim3(bx, 3, g.B), dim3(256), 0, st, g, q, leaves, counts, wp, work_count, ilog2(q.bmin), bad);
 }
 
 template <int S>
@@ -515,6 +526,7 @@ int launch_color_inverse(hipStream_t st, int space, const float *in, float *out,
     case 4: launch_inv_t<4>(st, in, out, n); break;
     case 5: launch_inv_t<5>(st, in, out, n); break;
     case 6: launch_inv_t<6>(st, in, out, n); break;
+    case 7: launch_inv_t<7>(st, in, out, n); break;
     default: return -1;
     }
     return 0;

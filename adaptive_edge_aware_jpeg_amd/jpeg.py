@@ -163,6 +163,10 @@ class Jpeg:
             h, w = (int(v) for v in self.layer_shapes[l])
             sizes = np.asarray(Jpeg._decode_leaf_sizes(L["states"], L["root_size"]), dtype=np.int32)
             root = tables.largest_power_of_2(max(h, w)) * 2                     # jpeg.py:425
+            # a stream whose header does not describe a tiling with the settings' block sizes must not reach the GPU tables
+            leaf_cap = (plan.leaf_off[l + 1] if l < 2 else plan.leaf_stride) - plan.leaf_off[l]
+            if len(sizes) > leaf_cap or (len(sizes) and (sizes.min() < self._block_sizes[0] or sizes.max() > self._block_sizes[-1])):
+                raise ValueError("corrupt stream: leaf sizes outside the block-size range of the header, or more leaves than the layer holds")
             xy = np.zeros((len(sizes), 2), np.int32)
             placed = ctx.lib.aej_leaf_positions_host(sizes.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(sizes)), root, h, w,
                                                      xy.ctypes.data_as(ctypes.c_void_p))

@@ -6,17 +6,29 @@ quadtree -> DCT -> quantise -> zigzag) over
 64 synthetic 3840x2160 float32 RGB images per GPU (BASELINE config 4: 512 4K images over 8 GPUs = 64 per GPU;
 weak scaling).  Inputs are in HBM before the timed region; outputs stay in HBM.
 
-    python bench.py                      # 1 GPU, 64 x 4K, 5 steps
+    python bench.py                      # 1 GPU, 64 x 4K, 10 steps
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, HIP-event
-timed on the launch stream inside the library) and `cpu_baseline` (the C oracle, one image per host core, bounded sample).
+What the timed region does and does not contain:
+* TWO different device-resident batches (different seeds) alternate across the steps, so the data-dependent speculation of the
+  hysteresis stage (pass count learnt from the previous call) is exercised on changing inputs; `hysteresis` in the JSON line
+  reports how many timed calls were speculative and how many missed, and `verified_mode_ms_per_step` is the same loop with the
+  speculation switched off (one counter read-back per 8 passes).
+* no profiling events: stage times come from separate, untimed steps afterwards.
+* after the timed region the outputs of the LAST timed step are compared with the CPU oracle for the first and the last image
+  of the batch (`"verified"`), so the number is tied to correct output.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, HIP-event timed on the
+launch stream inside the library), `valu` (the same kernel against the vector-issue limit, which is what actually bounds it)
+and `cpu_baseline` (the C oracle, one image per host core, bounded sample, plus the reference-structured NumPy restatement on
+one core).
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -26,23 +38,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3       # same guide: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 H4K, W4K = 2160, 3840
 
-# algorithmic HBM bytes per INPUT pixel of each stage for 4:2:0-type spaces (1.5 plane-pixels per pixel); DESIGN.md
+# algorithmic HBM bytes per INPUT pixel of each stage for 4:2:0-type spaces (1.5 plane-pixels per pixel); DESIGN.md section 4
 ALGO_BYTES_PER_PX = {
     "color_planes": 12.0 + 1.5 * 4 + 1.5 * 1,   # f32 RGB in (3 B with --ingest u8); normalised f32 planes + u8 planes out
     "clahe_blur": 1.5 * (1 + 1),                 # u8 in, u8 out
     "sobel_nms": 1.5 * (1 + 1),                  # u8 in, u8 map out
     "hysteresis": 1.5 * (1 + 1),                 # map in, map out (one sweep is the algorithmic minimum)
     "quadtree": 1.5 * 1,                         # map in (leaf/state tables are < 0.1 B/px)
-    "dct": 1.5 * (4 + 4),                        # f32 plane in, int32 coefficients out (all block sizes together)
 }
 WHOLE_PATH_BYTES_PER_PX = 18.0                   # 12 B f32 RGB in + 4 B x 1.5 coefficients out
+KERNEL_OF_STAGE = {"color_planes": "k_color_planes", "clahe_blur": "k_clahe_blur", "sobel_nms": "k_sobel_nms", "hysteresis": "k_hyst_pass",
+                   "quadtree": "k_qt_", "dct4": "k_dct4", "dct8": "k_dct_small<8", "dct16": "k_dct_small<16", "dct32": "k_dct_mfma<32",
+                   "dct64": "k_dct_mfma<64", "dct128": "k_dct_mfma<128", "dct2": "k_dct_small<2", "dct256": "k_dct_big"}
 
 
 def synth_batch(torch, B, H, W, seed, device):
     """'mixed' synthetic images of SURVEY.md 8d, generated on the GPU: smooth sinusoidal background, K = ceil(N/32768)
-    opaque rectangles, N(0, 1.5^2) noise, rounded to uint8 levels, /255 -> float32 [B, H, W, 3]."""
+    opaque rectangles, N(0, 1.5^2) noise, rounded to uint8 levels, /255 -> float32 [B, H, W, 3].  Image i uses seed + i."""
     out = torch.empty((B, H, W, 3), dtype=torch.float32, device=device)
     yy = (torch.arange(H, device=device, dtype=torch.float32) / H)[:, None]
     xx = (torch.arange(W, device=device, dtype=torch.float32) / W)[None, :]
@@ -72,12 +88,14 @@ def synth_batch(torch, B, H, W, seed, device):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("AEJ_BENCH_BATCH", "64")), help="images per GPU")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("AEJ_BENCH_BATCH", "64")), help="images per GPU (weak scaling)")
+    ap.add_argument("--total-images", type=int, default=0,
+                    help="strong-scaling variant: this many images in total, cut into contiguous shards by image index (sharding.shard_bounds)")
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--space", default="YCbCr")
@@ -86,40 +104,125 @@ def main():
     ap.add_argument("--ingest", choices=["f32", "u8"], default="f32",
                     help="f32 = the BASELINE metric's float32 RGB input; u8 = 8-bit ingest (aej_encode_batch_u8, 3 B/px in), reported as a variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle comparison")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for cpu_baseline; 0 = min(available cores, 16)")
-    args = ap.parse_args()
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiler runs (tools/profiling/*.sh): only the W warm-up and K timed steps, so every kernel is launched a known "
+                         "number of times; prints value / ms_per_step only")
+    ap.add_argument("--rehearse-control-flow", action="store_true",
+                    help="NO GPU work: run only the multi-rank control flow (rendezvous, per-rank seeds, barriers, reduction, rank-0 "
+                         "JSON) with a sleep in place of the encode; used by the CPU gloo test, never a measurement")
+    return ap.parse_args(argv)
+
+
+def rank_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(torch, backend, rank, local_rank, world):
+    """One process per GPU; rendezvous on 127.0.0.1 (the container hostname may not resolve).  Returns torch.distributed or None."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist
+
+
+def local_batch_and_seed(args, rank, world):
+    """-> (images on this rank, seed of its first image of batch A, seed of batch B, scaling label).  Seeds are distinct per
+    rank and per image: weak scaling gives rank r the images [r*B, (r+1)*B) of an endless seeded sequence; the strong-scaling
+    variant cuts --total-images into contiguous shards (sharding.shard_bounds)."""
+    from adaptive_edge_aware_jpeg_amd.sharding import shard_bounds
+    if args.total_images > 0:
+        lo, hi = shard_bounds(args.total_images, rank, world)
+        return hi - lo, 20250718 + lo, 20250718 + 1_000_000 + lo, "strong"
+    return args.batch, 20250718 + rank * args.batch, 20250718 + 1_000_000 + rank * args.batch, "weak"
+
+
+def timed_loop(torch, dist, step, steps, sync):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> local seconds."""
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def load_profile_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
+
+
+def rehearse(args):
+    """Control flow only (see --rehearse-control-flow)."""
+    import torch
+    rank, local_rank, world = rank_env()
+    dist = init_distributed(torch, os.environ.get("AEJ_BENCH_BACKEND", "gloo"), rank, local_rank, world)
+    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput
+    B, seed_a, seed_b, scaling = local_batch_and_seed(args, rank, world)
+    dt = timed_loop(torch, dist, lambda i: time.sleep(0.002 * (1 + rank)), args.steps, lambda: None)
+    px, dt = aggregate_throughput(dist, B * args.height * args.width * args.steps, dt, None)
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of bench.py's multi-rank control flow (no GPU work, not a measurement)", "value": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "pixels_total": px,
+                          "seconds_max": round(dt, 4), "rank0_images": B, "rank0_seeds": [seed_a, seed_b]}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.rehearse_control_flow:
+        return rehearse(args)
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    rank, local_rank, world = rank_env()
     # rehearsal switches (not used by the driver): AEJ_BENCH_BACKEND=gloo + AEJ_BENCH_ONE_DEVICE=1 run the multi-rank control flow
-    # (rendezvous, barriers, reduction, rank-0 print) with every rank on GPU 0 of a one-GPU box; RCCL needs one GPU per rank
+    # with every rank on GPU 0 of a one-GPU box; RCCL needs one GPU per rank
     backend = os.environ.get("AEJ_BENCH_BACKEND", "nccl")
     if os.environ.get("AEJ_BENCH_ONE_DEVICE"):
         local_rank = 0
+    # device_count() does not initialise the GPU; everything that does comes after the rendezvous below
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py needs an MI355X: no HIP device for local rank {local_rank}")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    dist = init_distributed(torch, backend, rank, local_rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
 
     import adaptive_edge_aware_jpeg_amd as A
-    from adaptive_edge_aware_jpeg_amd._lib import get_context
+    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput
 
-    B, H, W = args.batch, args.height, args.width
+    H, W = args.height, args.width
+    B, seed_a, seed_b, scaling = local_batch_and_seed(args, rank, world)
+    if B < 1:
+        raise SystemExit("no images for this rank")
     space, qrange, brange = args.space, tuple(args.quality), tuple(args.blocks)
     dev = torch.device("cuda", local_rank)
-    x = synth_batch(torch, B, H, W, 20250718 + rank * B, dev)
-    x_f32 = x
-    if args.ingest == "u8":
-        x = (x * 255.0).round().to(torch.uint8)
+    batches_f32 = [synth_batch(torch, B, H, W, seed_a, dev), synth_batch(torch, B, H, W, seed_b, dev)]
+    batches = batches_f32 if args.ingest == "f32" else [(x * 255.0).round().to(torch.uint8) for x in batches_f32]
 
     jpeg = A.Jpeg(A.JpegCompressionSettings(space, qrange, brange), device=local_rank)
     ctx = jpeg._bind()
@@ -128,66 +231,72 @@ def main():
     leaves = ctx.empty((B * plan.leaf_stride, 4), torch.int32)
     states = ctx.empty((B * plan.state_stride,), torch.uint8)
     counts = ctx.empty((B, 3, 4), torch.int64)
-    ctx.set_profiling(True)
 
-    def step():
-        jpeg.encode_into(ctx, x, plan, coeffs, leaves, states, counts)
+    def step(i):
+        jpeg.encode_into(ctx, batches[i & 1], plan, coeffs, leaves, states, counts)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def sync():
+        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stage_acc = {}
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k, v in ctx.stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput
-    px_total, dt = aggregate_throughput(dist, B * H * W * args.steps, dt, dev if backend == "nccl" else None)   # SUM of pixels, MAX of seconds
-
+    # ---- the measurement: W warm-up steps, then exactly K timed steps on alternating inputs, profiling off ----
+    ctx.set_profiling(False)
+    for i in range(args.warmup):
+        step(i)
+    h0 = ctx.hysteresis_stats()
+    dt_local = timed_loop(torch, dist, step, args.steps, sync)
+    h1 = ctx.hysteresis_stats()
+    px_total, dt = aggregate_throughput(dist, B * H * W * args.steps, dt_local, dev if backend == "nccl" else None)   # SUM of pixels, MAX of seconds
     value = px_total / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
+    last_batch = (args.steps - 1) & 1
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch", "value": round(value, 1), "unit": "MP/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                              "encode_calls": args.steps + args.warmup, "hysteresis_misses": h1["misses"] - h0["misses"], "timed_only": True}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
-    # ---- per-stage means and the roofline of the dominant kernel (this rank) ----
-    stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
-    dct_ms = sum(v for k, v in stage_ms.items() if k.startswith("dct"))
-    kernels = {k: stage_ms.get(k, 0.0) for k in ("color_planes", "clahe_blur", "sobel_nms", "hysteresis", "quadtree")}
-    kernels["dct"] = dct_ms
-    dom = max(kernels, key=kernels.get)
-    local_px = B * H * W
-    if args.ingest == "u8":
-        ALGO_BYTES_PER_PX["color_planes"] -= 9.0
-    achieved = ALGO_BYTES_PER_PX[dom] * local_px / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
-    # HBM bytes of the dominant kernel from the PMC passes (tests/traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # runs of this same workload; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_color_planes' known read volume)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if (tj.get("batch"), tj.get("height"), tj.get("width")) == (B, H, W) and space == "YCbCr" and brange == (4, 64):
-            names = {"color_planes": ["k_color_planes"], "clahe_blur": ["k_clahe_blur"], "sobel_nms": ["k_sobel_nms"],
-                     "hysteresis": ["k_hyst_pass"], "quadtree": ["k_qt_"], "dct": ["k_dct_"]}[dom]
-            traffic = sum(v["hbm_bytes"] for k, v in tj["kernels"].items() if any(k.startswith(n) for n in names))
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX[dom] * local_px, "avg_launch_ms": round(kernels[dom], 4),
-                "note": "priced against HBM as the contract asks; PMC (profiles/r01_f_pmc_valu_lds.txt) shows the stencil / quadtree kernels "
-                        "of this path are VALU-issue-bound (blur ~100 % VALU-busy), DESIGN.md section 4"}
-    whole_bpp = WHOLE_PATH_BYTES_PER_PX - (9.0 if args.ingest == "u8" else 0.0)
-    whole = whole_bpp * local_px / (ms_per_step * 1e-3) / 1e9
-    per_stage = {k: {"ms": round(v, 4), "GBps": round(ALGO_BYTES_PER_PX[k] * local_px / (v * 1e-3) / 1e9, 1) if v > 0 else None}
-                 for k, v in kernels.items()}
+    # ---- tie the number to correct output: first and last image of the LAST timed step's batch against the CPU oracle ----
+    verified = None
+    if rank == 0 and not args.no_verify:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as O
+        O.build()
+        from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+        enc = EncodedBatch(plan, coeffs, leaves, states, counts)
+        picks = sorted({0, B - 1})
+        with ThreadPoolExecutor(max_workers=len(picks)) as ex:
+            refs = list(ex.map(lambda b: O.encode_image(batches_f32[last_batch][b].cpu().numpy(), space, qrange, brange), picks))
+        ok = True
+        for b, ref in zip(picks, refs):
+            for l in range(3):
+                got = enc.layer(b, l)
+                ok = ok and got["root_size"] == ref[l]["root_size"] and all(np.array_equal(got[k], ref[l][k]) for k in ("states", "leaves", "coeffs"))
+        verified = {"ok": bool(ok), "images": picks, "of_batch": "A" if last_batch == 0 else "B",
+                    "what": "quadtree states, leaf table and quantised zigzag coefficients of all 3 layers, bit-exact vs the CPU oracle"}
 
+    # ---- the same loop with the speculation off (verified hysteresis loop) ----
+    ctx.set_speculation(False)
+    step(0); step(1)
+    dt_v = timed_loop(torch, dist, step, args.steps, sync)
+    _, dt_v = aggregate_throughput(dist, 0, dt_v, dev if backend == "nccl" else None)
+    ctx.set_speculation(True)
+
+    # ---- per-stage times: separate, untimed, profiled steps (HIP events on the launch stream inside the library) ----
+    ctx.set_profiling(True)
+    stage_acc, n_prof = {}, 4
+    step(0); step(1)
+    for i in range(n_prof):
+        step(i)
+        for k, v in ctx.stage_ms().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    ctx.set_profiling(False)
+    stage_ms = {k: v / n_prof for k, v in stage_acc.items()}
+
+    # leaf-size histogram of this rank's last batch ("report the leaf-size histogram with every number")
     cnt = counts.cpu().numpy()
-    # leaf-size histogram of this rank's batch ("report the leaf-size histogram with every number")
     lv = leaves.view(B, plan.leaf_stride, 4)
     leaf_hist = {}
     for l in range(3):
@@ -201,19 +310,75 @@ def main():
             leaf_hist[s] = leaf_hist.get(s, 0) + int(((sz == s) & valid).sum().item())
             s *= 2
     leaf_area = sum(k * k * v for k, v in leaf_hist.items())
+
+    # ---- kernels of the step, their algorithmic bytes, and the roofline of the dominant one ----
+    local_px = B * H * W
+    algo = {k: v * local_px for k, v in ALGO_BYTES_PER_PX.items()}
+    if args.ingest == "u8":
+        algo["color_planes"] -= 9.0 * local_px
+    kernels = {k: stage_ms.get(k, 0.0) for k in ("color_planes", "clahe_blur", "sobel_nms", "hysteresis", "quadtree")}
+    for sz, n_leaves in leaf_hist.items():
+        ms = stage_ms.get(f"dct{sz}", 0.0)
+        if ms > 0 and n_leaves > 0:
+            kernels[f"dct{sz}"] = ms
+            algo[f"dct{sz}"] = 8.0 * sz * sz * n_leaves          # f32 in + int32 out per coefficient
+    dom = max(kernels, key=kernels.get)
+    achieved = algo[dom] / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
+    head = git_head()
+    # HBM bytes and VALU instruction counts come from rocprofv3 PMC passes of this same command (profiles/, tools/pmc_summary.py);
+    # they cannot be collected inside a normal run, so the line says which profile they are from and for which commit
+    traffic, traffic_src = None, None
+    tj = load_profile_json("r02_hbm_traffic.json")
+    if tj and (tj.get("batch"), tj.get("height"), tj.get("width")) == (B, H, W) and tj.get("space", "YCbCr") == space and tuple(tj.get("blocks", (4, 64))) == brange:
+        pre = KERNEL_OF_STAGE[dom]
+        hit = [v["hbm_bytes"] for k, v in tj["kernels"].items() if pre in k]
+        if hit:
+            traffic = sum(hit)
+            traffic_src = {"file": "profiles/r02_hbm_traffic.json", "profiled_commit": tj.get("head"), "this_commit": head,
+                           "stale": tj.get("head") != head}
+    roofline = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom].rstrip("<_") if dom != "quadtree" else "k_qt_upper+count+scan+emit",
+                "stage": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": algo[dom], "avg_launch_ms": round(kernels[dom], 4)}
+    valu = None
+    vj = load_profile_json("r02_pmc_valu.json")
+    if vj and (vj.get("batch"), vj.get("height"), vj.get("width")) == (B, H, W) and vj.get("space", "YCbCr") == space and tuple(vj.get("blocks", (4, 64))) == brange:
+        pre = KERNEL_OF_STAGE[dom]
+        hit = [v for k, v in vj["kernels"].items() if pre in k]
+        if hit:
+            insts = sum(v["valu_insts_per_launch"] for v in hit)       # wave-level VALU instructions of one launch
+            plane_px = 1.5 * local_px
+            # issue limit measured here (profiles/r02_valu_issue_ubench.txt): one plain 32-bit VALU instruction per SIMD every ~1.1 ns
+            # (2 cycles at the clock the chip holds) when >= 2 waves share the SIMD; shifts / conversions / SDWA / 3-operand
+            # integer / packed ops take ~1.75 ns.  frac = time the instructions need at the plain rate / measured time.
+            t_issue = insts / N_SIMD * 1.1e-9
+            valu = {"kernel": roofline["kernel"], "wave_instructions_per_launch": insts, "instructions_per_plane_px": round(insts * 64 / plane_px, 1),
+                    "frac_of_issue_peak": round(t_issue / (kernels[dom] * 1e-3), 3),
+                    "issue_ns_per_simd_instruction": 1.1, "source": {"file": "profiles/r02_pmc_valu.json", "profiled_commit": vj.get("head"),
+                                                                       "this_commit": head, "stale": vj.get("head") != head}}
+    whole_bpp = WHOLE_PATH_BYTES_PER_PX - (9.0 if args.ingest == "u8" else 0.0)
+    whole = whole_bpp * local_px / (ms_per_step * 1e-3) / 1e9
+    per_stage = {k: {"ms": round(v, 4), "GBps": round(algo[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None} for k, v in kernels.items()}
+
     out = {
         "metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic ('mixed' images generated on the GPU, SURVEY.md 8d recipe)",
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic ('mixed' images generated on the GPU, SURVEY.md 8d recipe); two batches of different seeds alternate across steps",
         "config": {"workload": f"{B} x {W}x{H} {'uint8' if args.ingest == 'u8' else 'float32'} RGB per GPU, {space}, blocks {brange[0]}-{brange[1]}, quality {qrange[0]}-{qrange[1]} "
                                f"(BASELINE config 4: 512 4K images / 8 GPUs)",
                    "images_per_gpu": B, "height": H, "width": W, "color_space": space,
                    "block_size_range": list(brange), "quality_range": list(qrange)},
         "roofline": roofline,
+        "valu": valu,
+        "verified": verified,
+        "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "speculative_calls": h1["speculative"] - h0["speculative"],
+                       "misses": h1["misses"] - h0["misses"], "passes_enqueued_last_call": h1["enqueued"],
+                       "passes_needed_last_call": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle))},
+        "verified_mode_ms_per_step": round(dt_v / args.steps * 1e3, 3),
         "whole_path": {"bytes_per_px": whole_bpp, "achieved_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4)},
         "stages": per_stage,
-        "hysteresis_passes": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle)),
+        "stage_ms_source": f"{n_prof} separate profiled steps after the timed region (sum {sum(stage_ms.values()):.3f} ms)",
         "leaves_per_image": {"luma": int(cnt[:, 0, 1].mean()), "chroma": int(cnt[:, 1:, 1].mean())},
         "leaf_histogram": {"per_image": {str(k): round(v / B, 1) for k, v in leaf_hist.items()},
                            "area_share": {str(k): round(k * k * v / leaf_area, 4) for k, v in leaf_hist.items()}},
@@ -226,32 +391,34 @@ def main():
         if ms <= 0 or n_leaves == 0:
             continue
         e = {"ms": round(ms, 4), "GBps": round(8.0 * sz * sz * n_leaves / (ms * 1e-3) / 1e9, 1)}
-        if sz >= 32:
+        if sz >= 16:
             tf = 4.0 * sz ** 3 * n_leaves / (ms * 1e-3) / 1e12
-            e.update({"TFLOPs": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / 157.3, 3)})
+            e.update({"TFLOPs": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 3)})
         dct_sizes[str(sz)] = e
     out["dct_by_block_size"] = dct_sizes
     # Canny chain a-3 .. a-8 (5 B per plane pixel = float32 plane in, uint8 edge map out -> 7.5 B per image pixel)
     canny_ms = sum(stage_ms.get(k, 0.0) for k in ("clahe_lut", "clahe_blur", "thresholds", "sobel_nms", "hysteresis"))
     if canny_ms > 0:
         gbs = 7.5 * local_px / (canny_ms * 1e-3) / 1e9
-        out["canny_chain"] = {"ms": round(canny_ms, 4), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-                              "note": "VALU-bound stencils (DESIGN.md section 4), not HBM-bound"}
+        out["canny_chain"] = {"ms": round(canny_ms, 4), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
-    # ---- CPU baseline: the C oracle (a scalar port of the reference algorithm) on the host cores, bounded sample:
-    # one image per thread (ctypes releases the GIL inside the C call), the fan-out the reference's own sweep uses
-    # (one image per worker process); the single-core rate is reported beside it ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- CPU baselines on this box's host cores (rank 0, bounded sample) ----
+    # "port": the C oracle (a scalar port of the reference algorithm), one image per thread (ctypes releases the GIL inside the
+    #   C call) -- the fan-out the reference's own sweep uses (one image per worker process, metrics_computation.py:253);
+    # "reference_structured": SURVEY 8d's figure -- one Python thread, per-layer stages, per-node quadtree tests and per-leaf
+    #   Python loops exactly as jpeg.py:393-404,471,499-502,581-585, native calls where the reference calls OpenCV / numba.
+    if rank == 0 and not args.no_cpu_baseline:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
+        from oracle import reference_structured as RS
         O.build()
         try:
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
         cores = max(1, min(args.cpu_threads or min(avail, 16), B))      # a 1-GPU box's CPU share is 16 cores
-        n_img = min(B, 2 * cores)                                       # about 20 s of CPU work
-        imgs = x_f32[:n_img].cpu().numpy()
+        n_img = min(B, 2 * cores)                                       # about 10-20 s of CPU work
+        imgs = batches_f32[0][:n_img].cpu().numpy()
         t0 = time.perf_counter()
         O.encode_image(imgs[0], space, qrange, brange)
         t1 = time.perf_counter() - t0
@@ -259,10 +426,17 @@ def main():
         with ThreadPoolExecutor(max_workers=cores) as ex:
             list(ex.map(lambda im: O.encode_image(im, space, qrange, brange), [imgs[i] for i in range(n_img)]))
         cdt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        RS.encode_image(imgs[0], space, qrange, brange)
+        t_rs = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(n_img * H * W / cdt / 1e6, 2), "unit": "MP/s", "cores": cores, "kind": "port",
                                "sample": f"{n_img} of the {B} bench images ({W}x{H}) over {cores} threads (one image per call), whole path a-1..a-15 in the C oracle, "
                                          f"{cdt:.1f} s; single core: 1 image in {t1:.1f} s",
-                               "single_core_value": round(H * W / t1 / 1e6, 2), "host_cpus": os.cpu_count()}
+                               "single_core_value": round(H * W / t1 / 1e6, 2), "host_cpus": os.cpu_count(),
+                               "reference_structured": {"value": round(H * W / t_rs / 1e6, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+                                                        "sample": f"1 bench image ({W}x{H}), {t_rs:.1f} s: the reference's control structure (one Python thread, "
+                                                                  "per-node quadtree tests, per-leaf pad / DCT / quantise / zigzag loops) with the C oracle standing in for "
+                                                                  "its OpenCV / numba calls -- not the reference binary stack (cv2 / numba absent)"}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -49,7 +49,8 @@ typedef enum aej_status {
 
 /* colour spaces: keys of JpegCompressionSettings.COLOR_SPACE_SETTINGS (jpeg.py:62-147) */
 typedef enum aej_space {
-    AEJ_YCBCR = 0, AEJ_YCOCG = 1, AEJ_YCOCG_R = 2, AEJ_OKLAB = 3, AEJ_ICTCP = 4, AEJ_ICACB = 5, AEJ_JZAZBZ = 6
+    AEJ_YCBCR = 0, AEJ_YCOCG = 1, AEJ_YCOCG_R = 2, AEJ_OKLAB = 3, AEJ_ICTCP = 4, AEJ_ICACB = 5, AEJ_JZAZBZ = 6,
+    AEJ_XYZ = 7 /* aej_color_convert / aej_color_convert_inverse only (conversion.py:63-68); not a codec space */
 } aej_space;
 
 #define AEJ_MAX_SIZES 8 /* block sizes 2,4,...,256 (GUI range, src/gui/main_frame.py:41-45) */
@@ -72,6 +73,9 @@ AEJ_API aej_ctx *aej_create(int device, void *hip_stream /* hipStream_t or NULL 
 AEJ_API void aej_destroy(aej_ctx *ctx);
 AEJ_API const char *aej_last_error(aej_ctx *ctx); /* host string owned by ctx (or a static one if ctx==NULL) */
 AEJ_API int aej_synchronize(aej_ctx *ctx);
+/* Re-binds the context to another stream of its device (the Python host follows torch's current stream with it, so
+ * that the library's kernels are ordered behind whatever produced the caller's tensors); drains the stream it leaves. */
+AEJ_API int aej_set_stream(aej_ctx *ctx, void *hip_stream);
 AEJ_API int aej_last_hysteresis_passes(aej_ctx *ctx); /* diagnostic: passes enqueued by the last Canny run */
 
 /* Stage timing of aej_encode_batch: HIP events recorded on the context's stream around every stage of the
@@ -85,6 +89,12 @@ enum {
  * with its final synchronisation (falling back to the verified loop and redoing quadtree + DCT when they were too few).
  * `passes` is normally learnt from the previous call; 0 forces the verified mode for the next call. */
 AEJ_API int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin);
+/* enable = 0: every aej_encode_batch runs the verified loop (one counter read-back per 8 passes, nothing speculative). */
+AEJ_API int aej_set_hysteresis_speculation(aej_ctx *ctx, int enable);
+/* out_host[4] = { aej_encode_batch calls, calls that enqueued their passes speculatively, speculative calls whose pass
+ * count turned out too small (hysteresis finished in the verified loop, quadtree + DCT redone), passes enqueued
+ * speculatively by the last call } since aej_create. */
+AEJ_API int aej_get_hysteresis_stats(aej_ctx *ctx, int64_t *out_host);
 AEJ_API int aej_set_profiling(aej_ctx *ctx, int enable);
 AEJ_API int aej_get_stage_ms(aej_ctx *ctx, float *ms_host /* [AEJ_N_STAGES] */);
 AEJ_API const char *aej_stage_name(int stage);
@@ -159,14 +169,19 @@ AEJ_API int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, 
 /* ---- decode path: Jpeg.decompress after the host-side entropy decode (jpeg.py:285-296) ------
  * coeffs / leaves / counts use the layout of aej_encode_batch's outputs (so an encoded batch can be decoded in
  * place); counts is a DEVICE array [batch][3][4], only n_leaves is read.  rgb_out: [batch][H][W][3] float32 in [0,1]
- * (Jpeg._dequantize, _apply_inverse_dct, _block_merge, _upsample, _convert_color_space_inverse). */
+ * (Jpeg._dequantize, _apply_inverse_dct, _block_merge, _upsample, _convert_color_space_inverse).
+ * The leaf tables must tile every layer (aej_encode_batch's output does; Jpeg.decompress checks a parsed stream on the host
+ * with aej_leaf_positions_host): a table that does not fit the plan -- n_leaves beyond the layer's capacity, a size outside
+ * the settings' block range, more leaves of one size than can exist -- returns AEJ_ERR_ARG instead of touching memory it
+ * does not own; pixels no leaf covers are left undefined (the reference starts from np.zeros, jpeg.py:421). */
 AEJ_API uint64_t aej_decode_workspace_bytes(aej_ctx *ctx, int batch, int H, int W);
 AEJ_API int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32_t *leaves, const int64_t *counts, int batch, int H,
                              int W, float *rgb_out, void *workspace, uint64_t workspace_bytes);
 /* color.convert(space, "sRGB", x) (conversion.py:122-124): in [n][3] -> sRGB [n][3], float32 */
 AEJ_API int aej_color_convert_inverse(aej_ctx *ctx, int space, const float *in, float *out_rgb, int64_t n);
 /* HOST helper (no device): leaf positions from leaf sizes, the walk of Jpeg._block_merge (jpeg.py:424-448).
- * sizes_host [n] -> xy_host [n][2]; returns the number of leaves placed. */
+ * sizes_host [n] -> xy_host [n][2]; returns the number of leaves placed (== n for a well-formed stream), or -2 when the n
+ * leaves leave a part of the layer uncovered. */
 AEJ_API int64_t aej_leaf_positions_host(const int32_t *sizes_host, int64_t n, int root, int H, int W, int32_t *xy_host);
 
 #ifdef __cplusplus

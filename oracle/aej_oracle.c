@@ -104,7 +104,7 @@ ORC_API void orc_pow_array(const double *x, double y, double *out, int64_t n)
 /* ------------------------------------------------------------------------------------------
  * a-1  colour:  color.convert("sRGB", space, x)  (src/color/conversion.py:95-124)
  * ---------------------------------------------------------------------------------------- */
-enum { SP_YCBCR = 0, SP_YCOCG = 1, SP_YCOCG_R = 2, SP_OKLAB = 3, SP_ICTCP = 4, SP_ICACB = 5, SP_JZAZBZ = 6 };
+enum { SP_YCBCR = 0, SP_YCOCG = 1, SP_YCOCG_R = 2, SP_OKLAB = 3, SP_ICTCP = 4, SP_ICACB = 5, SP_JZAZBZ = 6, SP_XYZ = 7 };
 
 /* numpy builds these from Python doubles cast to float32 (np.array(..., dtype=np.float32)) */
 #define F(x) ((float)(x))
@@ -186,6 +186,7 @@ static void color_px(int space, float r, float g, float b, float *o)
     /* xyz.py:63-64 */
     float lr = srgb_to_linear(r), lg = srgb_to_linear(g), lb = srgb_to_linear(b);
     float X = dot3(M_RGB_XYZ + 0, lr, lg, lb), Y = dot3(M_RGB_XYZ + 3, lr, lg, lb), Z = dot3(M_RGB_XYZ + 6, lr, lg, lb);
+    if (space == SP_XYZ) { o[0] = X; o[1] = Y; o[2] = Z; return; } /* XYZ.srgb_to_xyz, xyz.py:63-64 */
     if (space == SP_OKLAB) { /* oklab.py:71-75 */
         float l = dot3(M_OK_LMS + 0, X, Y, Z), m = dot3(M_OK_LMS + 3, X, Y, Z), s = dot3(M_OK_LMS + 6, X, Y, Z);
         const double third = (double)(float)(1.0 / 3.0); /* np.power(f32, python float) -> powf(x, (float)(1/3)) */
@@ -709,6 +710,15 @@ static void dct_block(const float *D, const float *X, float *T, float *Y, int s)
     }
 }
 
+/* bare forward DCT contract on one float block: the per-leaf `cv.dct(block)` call of jpeg.py:471 (used by the
+ * reference-structured CPU baseline, oracle/reference_structured.py) */
+ORC_API void orc_dct_block(const float *D, const float *X, float *Y, int s)
+{
+    float *T = (float *)malloc(sizeof(float) * (size_t)s * s);
+    dct_block(D, X, T, Y, s);
+    free(T);
+}
+
 /* a-11 gather + a-12 DCT + a-13 quantise (np.round(f32 / int32) in float64, half-even, jpeg.py:501)
  * + a-15 zigzag gather (jpeg.py:579-588), per leaf, in leaf order.
  * norm: normalised plane (H,W); leaves (n,3) = x,y,s; qm_by_log2[l] / zz_by_log2[l]: tables for s = 1<<l.
@@ -819,6 +829,7 @@ static void color_inv_px(int space, float a, float b, float c, float *o)
         o[0] = clip01(idot3(m + 0, a, b, c)); o[1] = clip01(idot3(m + 3, a, b, c)); o[2] = clip01(idot3(m + 6, a, b, c));
         return;
     }
+    if (space == SP_XYZ) { xyz_to_srgb(a, b, c, o); return; }   /* XYZ.xyz_to_srgb, xyz.py:83-84 */
     if (space == SP_OKLAB) {   /* oklab.py:92-96 */
         float lp = idot3(INV_OK_LAB_LMSP_BITS + 0, a, b, c), mp = idot3(INV_OK_LAB_LMSP_BITS + 3, a, b, c), sp = idot3(INV_OK_LAB_LMSP_BITS + 6, a, b, c);
         /* np.power(f32, 3): x^3 rounded once from float64 */

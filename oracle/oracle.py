@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 _SRC = os.path.join(_HERE, "aej_oracle.c")
 
-SPACES = {"YCbCr": 0, "YCoCg": 1, "YCoCg-R": 2, "OKLAB": 3, "ICtCp": 4, "ICaCb": 5, "JzAzBz": 6}
+SPACES = {"YCbCr": 0, "YCoCg": 1, "YCoCg-R": 2, "OKLAB": 3, "ICtCp": 4, "ICaCb": 5, "JzAzBz": 6, "XYZ": 7}   # XYZ: colour conversion only
 
 # jpeg.py:62-147 -- (rh, rw) per layer
 RATIOS = {
@@ -49,13 +49,20 @@ CHR = np.array([[17, 18, 24, 47, 99, 99, 99, 99], [18, 21, 26, 66, 99, 99, 99, 9
                 [47, 66, 99, 99, 99, 99, 99, 99]] + [[99] * 8] * 4, dtype=np.float32)                          # jpeg.py:50-59
 
 
-def build(force=False):
-    """Compile aej_oracle.c -> liboracle.so (gcc, no contraction, no fast-math)."""
+_SO_ASAN = os.path.join(_HERE, "liboracle_asan.so")
+
+
+def build(force=False, sanitize=False):
+    """Compile aej_oracle.c -> liboracle.so (gcc, no contraction, no fast-math).  sanitize=True builds the
+    -fsanitize=address,undefined variant liboracle_asan.so (CPU tests only: tests/test_oracle_pins.py runs the whole oracle path
+    under it in a child interpreter with libasan preloaded; select it with AEJ_ORACLE_SANITIZE=1)."""
     hdrs = [os.path.join(_HERE, h) for h in ("aej_inv_constants.h", "aej_pow_tables.h")]
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in [_SRC] + hdrs):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
-                               "-fvisibility=hidden", "-mfma", "-mavx2", "-I", _HERE, "-o", _SO, _SRC, "-lm"])
-    return _SO
+    so = _SO_ASAN if sanitize else _SO
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [_SRC] + hdrs):
+        extra = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"] if sanitize else ["-O2"]
+        subprocess.check_call(["gcc"] + extra + ["-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                               "-fvisibility=hidden", "-mfma", "-mavx2", "-I", _HERE, "-o", so, _SRC, "-lm"])
+    return so
 
 
 _lib = None
@@ -64,8 +71,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_SO)
+        sanitize = os.environ.get("AEJ_ORACLE_SANITIZE") == "1"
+        _lib = ctypes.CDLL(build(sanitize=sanitize))
         _lib.orc_root_size.restype = ctypes.c_int
         _lib.orc_leaf_positions.restype = ctypes.c_int64
         for name in ("orc_downsample", "orc_quadtree", "orc_blocks_encode", "orc_blocks_decode"):

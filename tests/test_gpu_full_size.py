@@ -1,0 +1,165 @@
+"""GPU (-m gpu): BASELINE.json's full-size configurations against the CPU oracle, bit for bit.
+
+* config 4's image class: one 3840x2160 image, YCbCr, blocks 4-64;
+* config 5's image class: one 7680x4320 image, OKLAB, blocks 4-128 (root 8192: 13-bit Morton codes, pyramid levels >= 5);
+* the batched layouts the bench times: B = 8 x 4K and B = 64 x 1080p (int64 plane offsets, per-plane work lists, kMaxPlanes
+  prefix tables), images 0, B/2 and B-1 compared with the oracle;
+* determinism: the same batch encoded twice in one process gives identical bytes (the hysteresis chase passes race by design;
+  the fix-point must not depend on the interleaving);
+* contexts follow torch's current stream.
+
+Images come from bench.synth_batch (the generator the bench times) so that the tested inputs are the benchmarked ones; the
+oracle runs on their host copies (C, about 1.5 s per 4K image and 11 s for the 8K one).
+"""
+import hashlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import adaptive_edge_aware_jpeg_amd as pkg
+    import bench
+    return torch, pkg, bench
+
+
+def check_image(enc, b, ref, tag):
+    for l in range(3):
+        got = enc.layer(b, l)
+        assert got["root_size"] == ref[l]["root_size"], f"{tag} L{l} root"
+        assert np.array_equal(got["states"], ref[l]["states"]), f"{tag} L{l} states"
+        assert np.array_equal(got["leaves"], ref[l]["leaves"]), f"{tag} L{l} leaves"
+        assert np.array_equal(got["coeffs"], ref[l]["coeffs"]), f"{tag} L{l} coeffs"
+
+
+@pytest.mark.parametrize("H,W,space,br", [(2160, 3840, "YCbCr", (4, 64)), (4320, 7680, "OKLAB", (4, 128))],
+                         ids=["4K-YCbCr-4-64", "8K-OKLAB-4-128"])
+def test_single_full_size_image_matches_oracle(env, oracle, H, W, space, br):
+    torch, A, bench = env
+    x = bench.synth_batch(torch, 1, H, W, 20250718, torch.device("cuda", 0))
+    enc = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), br)).compress_batch(x)
+    ref = oracle.encode_image(x[0].cpu().numpy(), space, (40, 80), br)
+    check_image(enc, 0, ref, f"{W}x{H} {space}")
+    sizes = set(int(s) for l in range(3) for s in np.unique(enc.layer(0, l)["leaves"][:, 2]))
+    assert min(sizes) == br[0] and max(sizes) == br[1], sizes          # the whole block range occurs in the image
+
+
+@pytest.mark.parametrize("B,H,W", [(8, 2160, 3840), (64, 1080, 1920)], ids=["8x4K", "64x1080p"])
+def test_batched_layout_matches_oracle(env, oracle, B, H, W):
+    torch, A, bench = env
+    space, qr, br = "YCbCr", (40, 80), (4, 64)
+    x = bench.synth_batch(torch, B, H, W, 20250718, torch.device("cuda", 0))
+    codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
+    enc = codec.compress_batch(x)
+    picks = sorted({0, B // 2, B - 1})
+    with ThreadPoolExecutor(max_workers=len(picks)) as ex:         # ctypes releases the GIL inside the C oracle
+        refs = list(ex.map(lambda b: oracle.encode_image(x[b].cpu().numpy(), space, qr, br), picks))
+    for b, ref in zip(picks, refs):
+        check_image(enc, b, ref, f"image {b} of {B}")
+    # every image of the batch: counts consistent with the per-layer tables
+    cnt = enc.counts_host
+    for b in range(B):
+        for l in range(3):
+            n_coef, n_leaf, n_state, root = (int(v) for v in cnt[b, l])
+            assert root == enc.plan.root_size[l] and n_leaf > 0 and n_state >= n_leaf and n_coef >= enc.plan.layer_h[l] * enc.plan.layer_w[l]
+
+
+def digest(enc, B):
+    h = hashlib.sha256()
+    h.update(enc.counts_host.tobytes())
+    for b in range(B):
+        for l in range(3):
+            d = enc.layer(b, l)
+            for k in ("coeffs", "leaves", "states"):
+                h.update(d[k].tobytes())
+    return h.hexdigest()
+
+
+def test_encode_is_deterministic_in_process(env):
+    """the chase passes of the hysteresis write with atomics while other waves read; the result must not depend on
+    the interleaving.  Same device-resident batch, three encodes (first verified, then speculative), identical digests."""
+    torch, A, bench = env
+    B, H, W = 8, 2160, 3840
+    x = bench.synth_batch(torch, B, H, W, 4242, torch.device("cuda", 0))
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    d = [digest(codec.compress_batch(x), B) for _ in range(3)]
+    assert d[0] == d[1] == d[2]
+
+
+def test_speculation_on_off_and_stats(env, oracle):
+    """The speculative hysteresis enqueue and the verified loop give the same bytes; the miss counter counts."""
+    torch, A, bench = env
+    from adaptive_edge_aware_jpeg_amd._lib import get_context
+    B, H, W = 2, 1080, 1920
+    dev = torch.device("cuda", 0)
+    x1 = bench.synth_batch(torch, B, H, W, 1, dev)
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    ctx = get_context()
+    s0 = ctx.hysteresis_stats()
+    a = digest(codec.compress_batch(x1), B)             # may be verified (first call) or speculative
+    b = digest(codec.compress_batch(x1), B)             # speculative: hint learnt
+    ctx.set_speculation(False)
+    try:
+        c = digest(codec.compress_batch(x1), B)
+        s1 = ctx.hysteresis_stats()
+    finally:
+        ctx.set_speculation(True)
+    assert a == b == c
+    assert s1["calls"] - s0["calls"] == 3 and s1["speculative"] - s0["speculative"] >= 1
+    # force a miss: a 1-pass hint with no margin on an image whose contours cross many tiles
+    ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
+    d = digest(codec.compress_batch(x1), B)
+    s2 = ctx.hysteresis_stats()
+    assert d == a and s2["misses"] - s1["misses"] == 1
+
+
+def test_contexts_follow_the_current_stream(env, oracle):
+    """work issued under `torch.cuda.stream(s)` must run on s -- inputs produced on s are read by our
+    kernels without any cross-stream hazard, and each stream gets its own context / workspace."""
+    torch, A, bench = env
+    from adaptive_edge_aware_jpeg_amd._lib import get_context
+    dev = torch.device("cuda", 0)
+    img = oracle.synth_image(256, 384, 77).astype(np.float32) / np.float32(255.0)
+    ref = oracle.encode_image(img, "YCbCr", (40, 80), (4, 64))
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    c0 = get_context()
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        c1 = get_context()
+        assert c1 is not c0 and c1.stream == s.cuda_stream
+        big = torch.zeros((64, 1024, 1024), device=dev)         # keeps s busy so that the producer really is "in flight"
+        for _ in range(4):
+            big += 1.0
+        x = torch.from_numpy(img[None]).to(dev, non_blocking=True) + (big[0, :1, :1, None] * 0.0)   # produced ON s, after the busy work
+        enc = codec.compress_batch(x)
+        with pytest.raises(Exception):
+            c0.workspace(16)                                     # a context bound to another stream refuses to serve
+    s.synchronize()
+    check_image(enc, 0, ref, "side stream")
+    assert get_context() is c0
+    # aej_set_stream (C ABI) re-binds a context explicitly
+    c1.check(c1.lib.aej_set_stream(c1.handle, None))
+    c1.check(c1.lib.aej_set_stream(c1.handle, s.cuda_stream))
+
+
+def test_xyz_helper_space_and_float64_input(env, oracle):
+    import os
+    from conftest import GOLDEN
+    torch, A, bench = env
+    g = np.load(os.path.join(GOLDEN, "color_xyz.npz"))
+    x = g["rgb_u8"].astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(A.convert("sRGB", "XYZ", x), g["XYZ"])                 # the reference's own output
+    assert np.array_equal(A.convert("XYZ", "sRGB", g["XYZ_in"]), g["sRGB"])
+    assert np.array_equal(A.apply_normalization("XYZ", g["XYZ"], False).astype(np.float32), g["XYZ_norm"])
+    y64 = A.convert("sRGB", "YCbCr", x.astype(np.float64))                       # float64 in: rounded to float32, float32 out
+    assert y64.dtype == np.float32 and np.array_equal(y64, A.convert("sRGB", "YCbCr", x))
+    with pytest.raises(ValueError):
+        A.convert("XYZ", "YCbCr", x)
+    with pytest.raises(ValueError):
+        A.JpegCompressionSettings("XYZ")                                          # not a codec space (jpeg.py:164-165)

@@ -3,6 +3,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -156,3 +157,26 @@ def test_leaf_positions_host_helper(oracle):
                                         xy.ctypes.data_as(ctypes.c_void_p))
         assert n == len(sizes) and np.array_equal(xy, leaves[:, :2])
         assert np.array_equal(oracle.leaf_positions(sizes, root, h, w), leaves[:, :2])
+
+
+def test_compat_alias_packages_expose_the_reference_import_names():
+    """`from jpeg import ...`, `from jpeg.utils import largest_power_of_2`, `from jpeg.quadtree import QuadTree`,
+    `from color import convert`, `from image import Image` (setup.py:26-27; src/jpeg/utils.py:24-41) resolve with compat/ on
+    the path.  Run in a child interpreter so the alias names do not leak into this test process."""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, sys.argv[1])\n"
+        "from jpeg import Jpeg, JpegCompressionSettings\n"
+        "from jpeg.utils import largest_power_of_2\n"
+        "from jpeg.jpeg import Jpeg as J2\n"
+        "from jpeg.quadtree import QuadTree, QuadNode\n"
+        "from jpeg.edge_detection import EdgeDetection\n"
+        "from color import convert, apply_normalization, get_color_spaces\n"
+        "from image import Image, EvaluationMetrics\n"
+        "assert J2 is Jpeg\n"
+        "assert [largest_power_of_2(n) for n in (1, 2, 3, 512, 513, 1920, 3840, 7680)] == [1, 2, 2, 256, 512, 1024, 2048, 4096]\n"
+        "try:\n    largest_power_of_2(0)\nexcept ValueError:\n    pass\nelse:\n    raise SystemExit('no ValueError')\n"
+        "assert sorted(get_color_spaces()) == sorted(['ICaCb', 'ICtCp', 'JzAzBz', 'OKLAB', 'YCbCr', 'YCoCg', 'YCoCg-R'])\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "compat")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr

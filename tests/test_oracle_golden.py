@@ -131,3 +131,12 @@ def test_round_trip_quality(oracle, lena):
         L = oracle.encode_image(x, sp, (40, 80), (4, 64))
         y = oracle.decode_image(oracle.write_ajpg(L, 128, 128, sp, (40, 80), (4, 64), ".png"))
         assert 10 * np.log10(1.0 / np.mean((x - y) ** 2)) > 29.0 and not np.isnan(y).any()
+
+
+def test_xyz_helper_space_matches_reference(oracle):
+    """convert("sRGB", "XYZ", x) / convert("XYZ", "sRGB", y) as the reference's own modules computed them
+    (tests/golden/make_golden_xyz.py; conversion.py:63-68, xyz.py:63-84): bit-exact, both directions."""
+    g = np.load(os.path.join(GOLDEN, "color_xyz.npz"))
+    x = g["rgb_u8"].astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(oracle.color_forward("XYZ", x), g["XYZ"])
+    assert np.array_equal(oracle.color_inverse("XYZ", g["XYZ_in"]), g["sRGB"])

@@ -1,5 +1,7 @@
 """CPU: the oracle against the real third-party libraries that ARE present (NumPy), plus algebraic
 properties of the restated OpenCV stages (cv2 itself is absent: those stay 'parity unpinned')."""
+import os
+
 import numpy as np
 import pytest
 
@@ -166,3 +168,50 @@ def test_general_inter_area_against_float64_integration(oracle):
     assert np.abs(oracle.downsample(flat, 1, 2, 2) - np.float32(0.3)).max() < 1e-7
     same = oracle.downsample(rng.random((6, 6, 3), dtype=np.float32), 0, 1, 1)
     assert same.shape == (6, 6)
+
+
+def test_reference_structured_restatement_equals_the_oracle(oracle):
+    """oracle/reference_structured.py keeps the reference's control structure (explicit-stack quadtree with one region test per
+    node, per-leaf Python loops for pad / DCT / quantise / zigzag: quadtree.py:93-165, jpeg.py:393-404,471,499-502,581-588);
+    it is bench.py's second CPU baseline.  Same bytes as the one-C-call-per-stage oracle, ragged shapes included."""
+    from oracle import reference_structured as R
+    for (H, W, sp, br) in ((150, 211, "YCbCr", (4, 64)), (67, 101, "OKLAB", (4, 32)), (64, 100, "ICtCp", (8, 8)), (5, 9, "YCoCg", (2, 4))):
+        img = oracle.synth_image(H, W, H + W).astype(np.float32) / np.float32(255.0)
+        a, b = oracle.encode_image(img, sp, (40, 80), br), R.encode_image(img, sp, (40, 80), br)
+        for l in range(3):
+            assert a[l]["root_size"] == b[l]["root_size"]
+            for k in ("states", "leaves", "coeffs"):
+                assert np.array_equal(a[l][k], b[l][k]), (sp, l, k)
+
+
+def test_oracle_runs_clean_under_address_and_ub_sanitizers(oracle):
+    """The C oracle is the checker behind every parity claim: run its whole encode + decode path (ragged shapes, every colour
+    space, block sizes 2..128, overhanging leaves) in a child interpreter against the -fsanitize=address,undefined build, with
+    libasan preloaded.  Any out-of-bounds access, use-after-free or undefined shift / overflow aborts the child."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    oracle.build(sanitize=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found next to gcc")
+    code = (
+        "import sys; sys.path.insert(0, sys.argv[1])\n"
+        "import numpy as np\n"
+        "from oracle import oracle as O\n"
+        "cases = [(67, 101, 'YCbCr', (4, 64)), (33, 50, 'OKLAB', (4, 128)), (40, 51, 'ICtCp', (2, 16)), (5, 9, 'YCoCg', (2, 4)),\n"
+        "         (130, 260, 'JzAzBz', (8, 32)), (64, 62, 'ICaCb', (4, 16)), (96, 160, 'YCoCg-R', (16, 16))]\n"
+        "for (H, W, sp, br) in cases:\n"
+        "    img = O.synth_image(H, W, H * W).astype(np.float32) / np.float32(255.0)\n"
+        "    layers = O.encode_image(img, sp, (40, 80), br)\n"
+        "    data = O.write_ajpg(layers, H, W, sp, (40, 80), br, '.png')\n"
+        "    out = O.decode_image(data)\n"
+        "    assert out.shape == (H, W, 3)\n"
+        "e = (np.random.default_rng(1).random((150, 90)) < 0.01).astype(np.uint8)\n"
+        "O.quadtree(e, 2, 256); O.quadtree(e[:1, :1], 4, 64)\n"
+        "print('clean')\n")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               AEJ_ORACLE_SANITIZE="1")
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("clean"), (r.stdout[-500:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]

@@ -53,3 +53,38 @@ def test_two_rank_aggregation_over_gloo():
 
 def test_single_process_passthrough():
     assert aggregate_throughput(None, 10, 2.5) == (10, 2.5)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("extra,scaling,images", [([], "weak", [4, 4]), (["--total-images", "7"], "strong", [4, 3])])
+def test_bench_multi_rank_control_flow_rehearsal(extra, scaling, images):
+    """bench.py's own N > 1 control flow -- env parsing, rendezvous on 127.0.0.1, per-rank shard and seeds, barrier-bracketed
+    timing, SUM / MAX reduction, rank-0-only JSON line -- as two real processes over gloo, with a sleep in place of the GPU step
+    (--rehearse-control-flow: no GPU work, no measurement).  The driver runs the same code path with backend nccl on 8 GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AEJ_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--rehearse-control-flow", "--gpus", "2", "--steps", "3",
+                                       "--warmup", "1", "--batch", "4", "--height", "100", "--width", "200"] + extra,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    json_lines = [[ln for ln in o[0].splitlines() if ln.startswith("{")] for o in outs]      # gloo itself chats on stdout
+    assert len(json_lines[0]) == 1 and json_lines[1] == []           # only rank 0 prints the result line
+    line = json.loads(json_lines[0][0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == scaling
+    assert line["pixels_total"] == sum(images) * 100 * 200 * 3       # SUM over ranks
+    assert line["seconds_max"] >= 3 * 0.004 * 0.9                      # MAX over ranks: rank 1 sleeps twice as long
+    assert line["rank0_images"] == images[0] and line["rank0_seeds"][0] == 20250718

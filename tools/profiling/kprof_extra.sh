@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel timing of tools/bench_extra.py under rocprofv3 (GPU box): bash tests/kprof_extra.sh <tag> [args]
+# per-kernel timing of tools/bench_extra.py under rocprofv3 (GPU box): bash tools/profiling/kprof_extra.sh <tag> [args]
 export TMPDIR=/tmp
 tag=$1; shift
 R=$PWD
@@ -7,4 +7,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/profx_$tag
 f=$(ls gpurun_out/profx_$tag/*/*kernel_stats.csv | head -1)
 cp $f gpurun_out/profx_${tag}_kernel_stats.csv
 rm -rf gpurun_out/profx_$tag
-python3 tests/kstats.py gpurun_out/profx_${tag}_kernel_stats.csv
+python3 tools/profiling/kstats.py gpurun_out/profx_${tag}_kernel_stats.csv

@@ -1,0 +1,191 @@
+// valu_issue2.hip -- second round of issue-rate measurements for the stencil kernels (diagnostic, not product):
+// more VALU kinds, LDS atomics / wide reads, and small-table gathers through the vector L1 (buffer_load_dword with a per-lane
+// offset) alone and beside LDS gathers -- the bilateral filter's 12 weight look-ups per pixel could be split over both pipes.
+//   hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_issue2.hip -o /tmp/valu_issue2 && /tmp/valu_issue2
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <math.h>
+#include <vector>
+
+#define REP4(x) x x x x
+#define REP16(x) REP4(REP4(x))
+#define BODY(INS)                                                                                               \
+    REP16(asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)                                   \
+                       : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
+                       : "v"(b), "v"(c));)
+
+#define I0(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define I1(n) "v_mov_b32 %" #n ", %8\n"
+#define I2(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+#define I3(n) "v_or_b32 %" #n ", %" #n ", %8\n"
+#define I4(n) "v_sub_u32 %" #n ", %" #n ", %8\n"
+#define I5(n) "v_lshl_or_b32 %" #n ", %" #n ", 8, %8\n"
+#define I6(n) "v_or3_b32 %" #n ", %" #n ", %8, %9\n"
+#define I7(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %9\n"
+#define I8(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define I9(n) "v_fract_f32 %" #n ", %" #n "\n"
+#define I10(n) "v_rndne_f32 %" #n ", %" #n "\n"
+#define I11(n) "v_cvt_pk_u8_f32 %" #n ", %8, 1, %" #n "\n"
+#define I12(n) "v_cvt_f32_u32 %" #n ", %" #n "\n"
+#define I13(n) "v_alignbit_b32 %" #n ", %" #n ", %8, 16\n"
+#define I14(n) "v_dot4_u32_u8 %" #n ", %" #n ", %8, %9\n"
+#define I15(n) "v_fmac_f32 %" #n ", %8, %9\n"
+#define I16(n) "v_add_f32_dpp %" #n ", %" #n ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I17(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define I18(n) "v_add_u32_sdwa %" #n ", %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I19(n) "v_lshlrev_b32_sdwa %" #n ", %8, %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"
+#define I20(n) "v_min_u32 %" #n ", %" #n ", %8\n"
+#define I21(n) "v_xor_b32 %" #n ", %" #n ", %8\n"
+#define I22(n) "v_mul_f32 %" #n ", 0.25, %" #n "\n"
+#define I23(n) "v_add_f32 %" #n ", |%" #n "|, %8\n"
+#define I24(n) "v_sad_u8 %" #n ", %" #n ", %8, %9\n"
+#define I25(n) "v_cvt_f32_ubyte0 %" #n ", %" #n "\n"
+#define I26(n) "v_pk_sub_i16 %" #n ", %" #n ", %8\n"
+#define I27(n) "v_mad_u32_u16 %" #n ", %" #n ", %8, %9\n"
+#define I28(n) "v_bfi_b32 %" #n ", %" #n ", %8, %9\n"
+#define I29(n) "v_mov_b32_dpp %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+
+template <int OP>
+__global__ __launch_bounds__(512) void k_scalar(float *out, int iters)
+{
+    float a[8];
+    for (int i = 0; i < 8; i++) a[i] = (float)(threadIdx.x + i) * 1e-3f;
+    float b = __int_as_float(0x01020304 + (threadIdx.x & 3)), c = __int_as_float(0x07060504);
+    if (OP == 2 || OP == 9 || OP == 10 || OP == 11 || OP == 15 || OP == 16 || OP == 17 || OP == 22 || OP == 23) { b = 1.0001f; c = 1e-7f; }
+    for (int it = 0; it < iters; it++) {
+#define CASE(N) if (OP == N) { BODY(I##N) }
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+        CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29)
+    }
+    float s = 0;
+    for (int i = 0; i < 8; i++) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// memory pipes.  MODE bit 0: LDS gather (ds_read_b32 random), bit 1: L1 gather (buffer_load_dword, per-lane offset into a
+// small table), bit 2: ds_add_u32 (no return) random, bit 3: ds_read_b128 stride; loads issued in groups of 8, drained per group
+typedef int int4v __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(512) void k_mem(float *out, const float *table, int table_dwords, int iters)
+{
+    __shared__ unsigned int s[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) s[i] = i * 2654435761u;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63;
+    unsigned int off[8];
+    for (int i = 0; i < 8; i++) off[i] = ((((lane * 2654435761u + i * 40503u + blockIdx.x * 977u) >> 7) % (unsigned)table_dwords)) * 4u;
+    const unsigned lds0 = (unsigned)(size_t)(&s[0]);
+    // buffer resource over the table: base, stride 0, num_records = bytes, flags for raw dword access
+    int4v rsrc;
+    rsrc.x = (int)(unsigned)(size_t)table; rsrc.y = (int)((size_t)table >> 32) & 0xffff; rsrc.z = table_dwords * 4; rsrc.w = 0x00020000;
+    float acc = 0.f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            unsigned v[8]; float f[8]; unsigned q[4];
+            if (MODE & 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) asm volatile("ds_read_b32 %0, %1" : "=v"(v[i]) : "v"(lds0 + off[i]));
+            }
+            if (MODE & 2) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) f[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[(i + r) & 7], 0, 0));
+            }
+            if (MODE & 4) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) asm volatile("ds_add_u32 %0, %1" :: "v"(lds0 + off[i]), "v"(1u) : "memory");
+            }
+            if (MODE & 8) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) asm volatile("ds_read_b128 %0, %1" : "=v"(*(int4v *)q) : "v"(lds0 + lane * 16 + i * 1024));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (MODE & 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) asm volatile("" :: "v"(v[i]));
+            }
+            if (MODE & 2) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc += f[i];
+            }
+            if (MODE & 8) asm volatile("" :: "v"(q[0]));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+__global__ void k_cvt_pk_check(const float *in, unsigned *out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned r = 0;
+    asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(r) : "v"(in[i]));
+    out[i] = r;
+}
+
+template <typename K>
+static void run(const char *name, K kern, int wpsimd, int iters, int ninstr_per_iter)
+{
+    const int threads = 64 * 4 * (wpsimd > 2 ? 2 : wpsimd);
+    const int wg_per_cu = wpsimd > 2 ? wpsimd / 2 : 1;
+    const int blocks = 256 * wg_per_cu;
+    float *out;
+    (void)hipMalloc(&out, (size_t)blocks * threads * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    kern(blocks, threads, out, 8);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    kern(blocks, threads, out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double simd_instr = (double)iters * ninstr_per_iter * wpsimd;
+    printf("%-40s waves/SIMD %d: wall %7.3f ms -> %6.2f ns per SIMD-instr (%6.2f ns per CU-instr)\n", name, wpsimd, ms, ms * 1e6 / simd_instr, ms * 1e6 / simd_instr / 4);
+    (void)hipFree(out);
+}
+
+#define RUN_S(NAME, OP) for (int w : { 2, 4 }) run(NAME, [](int bl, int th, float *o, int it) { hipLaunchKernelGGL((k_scalar<OP>), dim3(bl), dim3(th), 0, 0, o, it); }, w, 1500, 128)
+#define RUN_M(NAME, MODE, TD, N) for (int w : { 2, 4, 8 }) run(NAME, [=](int bl, int th, float *o, int it) { hipLaunchKernelGGL((k_mem<MODE>), dim3(bl), dim3(th), 0, 0, o, table, TD, it); }, w, 300, N)
+
+int main()
+{
+    float *table;
+    (void)hipMalloc(&table, 1 << 20);
+    (void)hipMemset(table, 0, 1 << 20);
+    RUN_S("v_cndmask_b32", 0); RUN_S("v_mov_b32", 1); RUN_S("v_max_f32", 2); RUN_S("v_or_b32", 3); RUN_S("v_sub_u32", 4);
+    RUN_S("v_lshl_or_b32", 5); RUN_S("v_or3_b32", 6); RUN_S("v_mad_u32_u24", 7); RUN_S("v_mul_u32_u24", 8); RUN_S("v_fract_f32", 9);
+    RUN_S("v_rndne_f32", 10); RUN_S("v_cvt_pk_u8_f32", 11); RUN_S("v_cvt_f32_u32", 12); RUN_S("v_alignbit_b32", 13); RUN_S("v_dot4_u32_u8", 14);
+    RUN_S("v_fmac_f32", 15); RUN_S("v_add_f32_dpp row_shr", 16); RUN_S("v_cmp_lt_f32 vcc", 17); RUN_S("v_add_u32_sdwa byte", 18);
+    RUN_S("v_lshlrev_b32_sdwa byte", 19); RUN_S("v_min_u32", 20); RUN_S("v_xor_b32", 21); RUN_S("v_mul_f32 inline const", 22);
+    RUN_S("v_add_f32 |abs| (VOP3)", 23); RUN_S("v_sad_u8", 24); RUN_S("v_cvt_f32_ubyte0", 25); RUN_S("v_pk_sub_i16", 26); RUN_S("v_mad_u32_u16", 27);
+    RUN_S("v_bfi_b32", 28); RUN_S("v_mov_b32_dpp quad_perm", 29);
+    RUN_M("LDS gather b32 (random, 8K dwords)", 1, 1536, 64);
+    RUN_M("L1 gather dword, 6 KB table", 2, 1536, 64);
+    RUN_M("L1 gather dword, 1 KB table", 2, 256, 64);
+    RUN_M("L1 gather dword, 64 KB table", 2, 16384, 64);
+    RUN_M("LDS + L1 gathers together (each counted)", 3, 1536, 128);
+    RUN_M("ds_add_u32 random", 4, 1536, 64);
+    RUN_M("ds_read_b128 stride", 8, 1536, 64);
+    // rounding of v_cvt_pk_u8_f32 against rintf (round-half-even) with saturation to [0, 255]
+    {
+        const int n = 1 << 20;
+        std::vector<float> h(n);
+        for (int i = 0; i < n; i++) h[i] = (i & 1) ? (float)(i % 600) * 0.5f - 20.f : (float)((i * 2654435761u) >> 8) * (300.f / 16777216.f) - 10.f;
+        float *d; unsigned *o;
+        (void)hipMalloc(&d, n * 4); (void)hipMalloc(&o, n * 4);
+        (void)hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_cvt_pk_check, dim3(n / 256), dim3(256), 0, 0, d, o, n);
+        std::vector<unsigned> r(n);
+        (void)hipMemcpy(r.data(), o, n * 4, hipMemcpyDeviceToHost);
+        int bad_rne = 0, bad_trunc = 0;
+        for (int i = 0; i < n; i++) {
+            float x = h[i];
+            int e = (int)rintf(x); e = e < 0 ? 0 : e > 255 ? 255 : e;
+            int t = (int)x; t = t < 0 ? 0 : t > 255 ? 255 : t;
+            if ((int)(r[i] & 0xff) != e) bad_rne++;
+            if ((int)(r[i] & 0xff) != t) bad_trunc++;
+        }
+        printf("v_cvt_pk_u8_f32: %d of %d differ from saturated rintf (RNE), %d differ from saturated truncation\n", bad_rne, n, bad_trunc);
+    }
+    return 0;
+}
