@@ -11,7 +11,9 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaejpeg_hip.so")
+# AEJ_LIBRARY: developer override used by tools/profiling/variants.py to time experimental builds of the same ABI side by side
+# (they live under build/variants/, never in place of the in-tree library)
+LIB_PATH = os.environ.get("AEJ_LIBRARY") or os.path.join(_HERE, "libaejpeg_hip.so")
 
 SPACE_IDS = {"YCbCr": 0, "YCoCg": 1, "YCoCg-R": 2, "OKLAB": 3, "ICtCp": 4, "ICaCb": 5, "JzAzBz": 6}
 CONVERT_IDS = dict(SPACE_IDS, XYZ=7)     # color.convert also serves the helper space XYZ (conversion.py:63-68); not a codec space

@@ -13,6 +13,9 @@ HEADERS = ["aej_common.h", "aej_launch.h", "aej_devmath.h", "inv_constants.h", "
 LIB = os.path.join(HERE, "..", "libaejpeg_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# per-source additions.  canny.hip: the SLP vectoriser pairs the bilateral filter's float adds / fmas into v_pk_* instructions,
+# which issue at half rate on gfx950 (profiles/r02_valu_issue_ubench.txt) and cost register pairs: measured 20 % slower.
+EXTRA_FLAGS = {"canny.hip": ["-fno-slp-vectorize", "-Wno-pass-failed"]}
 
 
 def _hipcc():
@@ -38,7 +41,7 @@ def build(force=False, verbose=True):
         o = os.path.join(HERE, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

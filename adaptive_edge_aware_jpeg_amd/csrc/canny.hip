@@ -118,242 +118,120 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 
 // ------------------------------------------------------------------------------------------------
 // fused CLAHE apply (a-4) + Gaussian 3x3 (a-5) + bilateral d=5 (a-6) + histogram of the result (a-7)
-// Output tile 64 x 32; LDS holds the CLAHE image with a 3-pixel halo and the Gaussian image with a
-// 2-pixel halo, indexed by image coordinate so that REFLECT_101 is a coordinate remap.  Tiles whose
-// halo lies fully inside the image (almost all of them) take the INTERIOR path: no bounds tests, no
-// reflection, dword LDS reads and 4 pixels per thread in the bilateral stage.
+//
+// This kernel is bound by the LDS pipe, not by VALU issue or HBM (PMC: the LDS array is busy > 70 % of the kernel's time,
+// profiles/r02_blur_pmc.txt), so its structure minimises LDS cycles per pixel:
+//   * 512-thread workgroups on 128 x 64 output tiles (2 workgroups per CU): the staged halo is 16 % / 13 % of the tile for the
+//     CLAHE / Gaussian images instead of 34 % / 27 % with 64 x 32 tiles;
+//   * stage A (CLAHE): the four tile LUTs a pixel blends are pre-packed, per workgroup, into one float4 per input value
+//     ("packed LUT": { L[ty1][tx1][v], L[ty1][tx2][v], L[ty2][tx1][v], L[ty2][tx2][v] } as floats), so a pixel costs ONE
+//     16-byte LDS gather and no int -> float conversions instead of four byte gathers + four conversions.  A 136 x 70 window
+//     rarely crosses a tile-centre line, and almost never one per axis: two packed LUTs are kept (windows that would need
+//     more -- tiny planes, the 0.5 % of tiles on a crossing of both axes -- take the general path that reads LUT bytes from
+//     global memory); a thread keeps its column for the whole tile, so the column weights live in registers;
+//   * stage B (Gaussian): a thread slides down 5 output rows of one column dword, re-using the horizontal [1 2 1] sums of the
+//     previous two rows: 3 LDS reads per row instead of 9.  The result is stored one dword per pixel as the float 2^23 + 4 g,
+//     whose BIT PATTERN is 0x4B000000 + 4 g: differences of bit patterns are table byte offsets (plain integer subtraction)
+//     and the float minus 2^23 is the tap value x 4 (one float subtraction, exact) -- no conversions in the bilateral stage;
+//   * stage C (bilateral): a thread owns 4 x 2 pixels.  All window reads are 16- or 8-byte reads of whole 512-byte row
+//     segments (conflict-free), and the weight of a pixel PAIR, which depends only on |difference| and distance, is fetched
+//     once and used for both pixels: 76 instead of 96 table gathers per 8 pixels.
+// Every float operation per pixel is the same single IEEE operation in the same order as before (and as the CPU oracle).
 // ------------------------------------------------------------------------------------------------
-constexpr int kAW = kBlurTW + 8;   // LDS row stride in bytes (72 = 18 dwords); column c <-> gx = x0 - 4 + c
-constexpr int kAW4 = kAW / 4;
-constexpr int kAH = kBlurTH + 6;   // CLAHE rows  [y0-3, y0+TH+3)
-constexpr int kBH = kBlurTH + 4;   // Gauss rows  [y0-2, y0+TH+2)
-
-__constant__ int c_bil_dy[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
-__constant__ int c_bil_dx[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
-
-constexpr int kBW2 = 2 * kAW4;     // Gaussian row stride in dwords: two pixels per dword (see BlurLds::Bm)
+constexpr int kBT = 512;                  // threads per workgroup
+constexpr int kBTW = 128, kBTH = 64;      // output tile
+constexpr int kBAW = kBTW + 8;            // staged columns: c <-> gx = x0 - 4 + c (bytes per CLAHE row, dwords per Gaussian row)
+constexpr int kBAW4 = kBAW / 4;           // 34 dwords per CLAHE row
+constexpr int kBAH = kBTH + 6;            // CLAHE rows  [y0-3, y0+TH+3)
+constexpr int kBGH = kBTH + 4;            // Gauss rows  [y0-2, y0+TH+2)
+constexpr int kBGW = kBAW + 4;            // Gaussian row stride in dwords; staged column c is stored at c + 2, so that the 8-dword window of
+                                          // a bilateral thread (columns 4 c4 + 2 .. 4 c4 + 9) is two ALIGNED 16-byte reads (conflict-free)
+constexpr int kBStrip = 8;                // tiles of one tile-row handled by one workgroup (tables / histogram stay in LDS)
+constexpr int kASlots = kBT / kBAW4;      // 15 row slots: thread t owns column dword t % 34 and rows t / 34 + 15 k
+constexpr int kAIter = (kBAH + kASlots - 1) / kASlots;   // 5
+constexpr int kBRows = 5;                 // Gaussian output rows per thread: rows 5 * (t / 34) .. + 4
+static_assert(kASlots * kBRows >= kBGH && kASlots * kAIter >= kBAH, "thread -> row mapping must cover the tile");
 constexpr int kHistCopies = 12;
+constexpr int kHistStride = 257;          // dwords per histogram copy: odd, so the same bin of different copies sits in different banks
 
+// Member order matters: DS instructions carry a 16-bit immediate offset, so everything addressed with small compile-time offsets
+// (parameter arrays, tables, histogram) sits in the first 64 KB and the big Gaussian image, addressed through computed bases, last.
 struct __attribute__((aligned(16))) BlurLds {
-    unsigned char lut[16 * 256];
-    unsigned int A[kAH * kAW4];      // CLAHE image, one byte per pixel
-    // Gaussian image, 16 bits per pixel holding 4*value: dword (c >> 1) of a row carries column c in its low (c even) or
-    // high (c odd) half.  The pre-scaled value is at once the byte offset into the weight table and (x4, exact in
-    // float32) the tap value of the bilateral sum.
-    unsigned int Bm[kBH * kBW2];
+    int colq[kBAW];                  // byte offset of the column's packed LUT: 0 or sizeof(P[0])
+    float colXa[kBAW], colXa1[kBAW];
+    int colT1[kBAW], colT2[kBAW];    // clamped CLAHE tile indices of the columns / rows (general path, class detection)
+    int rowq[kBAH];                  // byte offset of the row's packed LUT: 0 or sizeof(P[0])
+    float rowYa[kBAH], rowYa1[kBAH];
+    int rowT1[kBAH], rowT2[kBAH];
+    int cls[8];                      // [0..1] (tx1 << 2 | tx2) of column class 0 / 1, [2..3] likewise for rows, [4] / [5] number of class changes
+    int pkey[2];                     // which (tx1, tx2, ty1, ty2) each packed LUT currently holds, -1 = none
     // space weight (radius 1, sqrt 2, 2) x colour weight: the float32 product OpenCV forms per tap, indexed by the SIGNED
     // difference d + 256 so the filter needs no |d|
     float cw[3][512];
-    unsigned int hist16[kHistCopies * 129];   // lane-striped copies of 256 packed 16-bit counters; odd stride => copies sit in different banks
-    int colOff1[kAW], colOff2[kAW];
-    float colXa[kAW], colXa1[kAW];
-    int rowOff1[kAH], rowOff2[kAH];
-    float rowYa[kAH], rowYa1[kAH];
+    unsigned int hist[kHistCopies * kHistStride];   // lane-striped copies of the 256 counters of this strip
+    float4 P[2][256];                // packed LUTs: slot 0 = class 0 of both axes, slot 1 = class 1 of the ONE axis that changes
+    unsigned int A[kBAH * kBAW4];    // CLAHE image, one byte per pixel
+    unsigned int G[kBGH * kBGW];     // Gaussian image, one dword per pixel: bit pattern of the float 2^23 + 4 * value
 };
+static_assert(sizeof(BlurLds) <= 80 * 1024, "two workgroups per CU");
 
-// Per-tile histogram: lane-striped copies keep same-value lanes of a wave off the same LDS word (flat image
-// regions would otherwise serialise 64-way); two 16-bit counters per word (a tile has 2048 pixels).
-__device__ __forceinline__ void hist_add(BlurLds &L, int copy_base, int v)
+// 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2): (dy, dx) =
+// (-2,0) (-1,-1) (-1,0) (-1,1) (0,-2) (0,-1) (0,0) (0,1) (0,2) (1,-1) (1,0) (1,1) (2,0).  The weight of a tap is
+// space_w[k] * color_w[|delta|]; space_w takes 3 values (radius 1, sqrt 2, 2), so the float32 products are tabulated once per
+// workgroup (same multiplication, same rounding) in cw[0 / 1 / 2].  The centre tap has weight 1.
+// pair_w: weight of the pixel pair (a, b) of radius class T from the bit patterns of their Gaussian words.
+template <int T>
+__device__ __forceinline__ float pair_w(const BlurLds &L, unsigned a, unsigned b)
 {
-    atomicAdd(&L.hist16[copy_base + (v >> 1)], 1u << (16 * (v & 1)));
+    const int d = (int)b - (int)a;       // 4 * (difference of the two Gaussian values): |d| <= 1020
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(L.cw[T]) + 1024 + d);
 }
 
-__device__ __forceinline__ unsigned char clahe_px(const BlurLds &L, int v, int r1, int r2, int c1, int c2, float xa, float xa1, float ya, float ya1)
+__device__ __forceinline__ void acc_tap(float &sum, float &wsum, float v, float wgt)
 {
-    float pa = (float)L.lut[r1 + c1 + v] * xa1;
-    float pb = (float)L.lut[r1 + c2 + v] * xa;
-    float pc = (float)L.lut[r2 + c1 + v] * xa1;
-    float pd = (float)L.lut[r2 + c2 + v] * xa;
+    wsum = wsum + wgt;
+    sum = __builtin_fmaf(v, wgt, sum);
+}
+
+// CLAHE_Interpolation_Body for one pixel from the four LUT values (general path: LUT bytes straight from global memory)
+__device__ __forceinline__ float clahe_blend(float l11, float l12, float l21, float l22, float xa, float xa1, float ya, float ya1)
+{
+    float pa = l11 * xa1, pb = l12 * xa, pc = l21 * xa1, pd = l22 * xa;
     float top = pa + pb, bot = pc + pd;
     float t1 = top * ya1, t2 = bot * ya;
-    float res = t1 + t2;
-    int r = __float2int_rn(res);
-    return (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+    return t1 + t2;
 }
 
-// 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2).  The weight of tap k is
-// space_w[k] * color_w[|delta|]; space_w takes 3 values (radius 1, sqrt 2, 2), so the float32 products are tabulated once
-// per workgroup (same multiplication, same rounding).  The centre tap has |delta| = 0 and both factors 1.
-// v4[k] = 4 * tap value.  Scaling every tap by 4 scales each partial sum and the quotient by exactly 4 (powers of two
-// commute with float32 rounding away from the denormal range), so (sum4 / wsum) * 0.25f is bitwise sum / wsum.
-__device__ __forceinline__ unsigned int bilateral_px(const BlurLds &L, const int (&v4)[13])
+// raw bytes of a tile for stage A: thread t fetches the dwords it will map itself (column dword t % 34, rows t / 34 + 15 k),
+// one tile ahead.  `aligned` tiles (staged window inside the image, w % 4 == 0) use dword loads; tiles on the image border
+// gather bytes at REFLECT_101-mapped coordinates, which yields the padded CLAHE image the Gaussian needs (Gaussian of the
+// padded image = padded Gaussian, the kernel being symmetric).
+__device__ __forceinline__ void blur_prefetch(const unsigned char *src, int w, int h, int x0, int y0, bool aligned, unsigned int (&raw)[kAIter])
 {
-    const int c0 = v4[6] - 1024;         // v4[k] - c0 = 4 * (d + 256): byte offset into cw[t]
-    float sum = 0.f, wsum = 0.f;
+    const int t = threadIdx.x;
+    const int col = t % kBAW4, slot = t / kBAW4;
+    if (slot >= kASlots) return;
 #pragma unroll
-    for (int k = 0; k < 13; k++) {
-        float wgt;
-        if (k == 6) {
-            wgt = 1.0f;
-        } else {
-            const int t = (k == 0 || k == 4 || k == 8 || k == 12) ? 2 : (k == 1 || k == 3 || k == 9 || k == 11) ? 1 : 0;
-            wgt = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(L.cw[t]) + (v4[k] - c0));
-        }
-        wsum = wsum + wgt;
-        sum = __builtin_fmaf((float)v4[k], wgt, sum);
-    }
-    int r = __float2int_rn((sum / wsum) * 0.25f);
-    return (unsigned int)(r < 0 ? 0 : r > 255 ? 255 : r);
-}
-
-// The raw bytes of a tile (38 rows x 18 dwords = 684 dwords, <= 3 per thread) are fetched into registers one tile
-// ahead by the strip loop, so their HBM latency hides under the previous tile's Gaussian and bilateral stages; the
-// thread that fetched a dword is the one that CLAHE-maps it.  `aligned` tiles (window inside the image, w % 4 == 0)
-// use dword loads; tiles on the image border gather bytes at REFLECT_101-mapped coordinates, which yields the padded
-// CLAHE image the Gaussian needs.
-constexpr int kRawPerThread = (kAH * kAW4 + 255) / 256;
-
-__device__ __forceinline__ void blur_prefetch(const unsigned char *src, int w, int h, int x0, int y0, bool aligned, unsigned int (&raw)[kRawPerThread])
-{
-#pragma unroll
-    for (int k = 0; k < kRawPerThread; k++) {
-        int idx = threadIdx.x + k * 256;
-        if (idx < kAH * kAW4) {
-            int j = idx / kAW4, i4 = idx - j * kAW4;
+    for (int k = 0; k < kAIter; k++) {
+        const int j = slot + kASlots * k;
+        if (j < kBAH) {
             if (aligned) {
-                raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 3 + j) * w + (x0 - 4) + 4 * i4);
+                raw[k] = *reinterpret_cast<const unsigned int *>(src + (long long)(y0 - 3 + j) * w + (x0 - 4) + 4 * col);
             } else {
                 const unsigned char *row = src + (long long)reflect101(y0 - 3 + j, h) * w;
                 unsigned int v = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) v |= (unsigned int)row[reflect101(x0 - 4 + 4 * i4 + q, w)] << (8 * q);
+                for (int q = 0; q < 4; q++) v |= (unsigned int)row[reflect101(x0 - 4 + 4 * col + q, w)] << (8 * q);
                 raw[k] = v;
             }
         }
     }
 }
 
-// One 64x32 tile from the fetched raw bytes in raw[].  For tiles that touch the image border the fetch (and the
-// CLAHE parameter arrays) already hold REFLECT_101-mapped data, i.e. the padded CLAHE image; because the Gaussian
-// kernel is symmetric, Gaussian(pad(A)) at a mirrored position equals the mirrored Gaussian, so the padded Gaussian
-// image the bilateral filter needs comes out of the same code.  `full` = the 64x32 outputs all lie inside the image.
-template <typename NEXT>
-__device__ __forceinline__ void blur_tile(const Geom &g, const CannyBuffers &cb, BlurLds &L, int l, int b, int x0, int y0, bool full,
-                                          unsigned int (&raw)[kRawPerThread], NEXT &&fetch_next)
-{
-    const int tid = threadIdx.x;
-    const int w = g.w[l], h = g.h[l];
-    const long long pbase = (long long)b * g.pstride + g.poff[l];
-    // ---- stage A: CLAHE interpolation, 4 pixels (one dword) per item
-#pragma unroll
-    for (int kk = 0; kk < (kAH * kAW4 + 255) / 256; kk++) {
-        const int idx = tid + kk * 256;
-        if (idx >= kAH * kAW4) break;
-        int j = idx / kAW4, i4 = idx - j * kAW4;
-        unsigned int rv = raw[kk];
-#if defined(AEJ_ABLATE) && (AEJ_ABLATE == 3 || AEJ_ABLATE == 5)
-        L.A[idx] = rv; continue;
-#endif
-        const int4 c1 = reinterpret_cast<const int4 *>(L.colOff1)[i4], c2 = reinterpret_cast<const int4 *>(L.colOff2)[i4];
-        const float4 xa = reinterpret_cast<const float4 *>(L.colXa)[i4], xa1 = reinterpret_cast<const float4 *>(L.colXa1)[i4];
-        const int r1 = L.rowOff1[j], r2 = L.rowOff2[j];
-        const float ya = L.rowYa[j], ya1 = L.rowYa1[j];
-        unsigned int o0 = clahe_px(L, rv & 0xff, r1, r2, c1.x, c2.x, xa.x, xa1.x, ya, ya1);
-        unsigned int o1 = clahe_px(L, (rv >> 8) & 0xff, r1, r2, c1.y, c2.y, xa.y, xa1.y, ya, ya1);
-        unsigned int o2 = clahe_px(L, (rv >> 16) & 0xff, r1, r2, c1.z, c2.z, xa.z, xa1.z, ya, ya1);
-        unsigned int o3 = clahe_px(L, rv >> 24, r1, r2, c1.w, c2.w, xa.w, xa1.w, ya, ya1);
-        L.A[idx] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
-    }
-    fetch_next();          // raw[] is free again: next tile's bytes fly while this tile runs stages B and C
-    __syncthreads();
-    if (cb.dump_clahe)
-        for (int idx = tid; idx < kBlurTH * kBlurTW; idx += 256) {
-            int j = idx / kBlurTW, i = idx - j * kBlurTW;
-            if (x0 + i < w && y0 + j < h)
-                cb.dump_clahe[pbase + (long long)(y0 + j) * w + x0 + i] = reinterpret_cast<const unsigned char *>(L.A)[(j + 3) * kAW + i + 4];
-        }
-    // ---- stage B: Gaussian [1 2 1]^2, (sum + 8) >> 4, SWAR on even/odd bytes (16-bit fields hold <= 4088)
-#pragma unroll
-    for (int kk = 0; kk < (kBH * kAW4 + 255) / 256; kk++) {
-        const int idx = tid + kk * 256;
-        if (idx >= kBH * kAW4) break;
-        int j = idx / kAW4, i4 = idx - j * kAW4;
-        const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kAW4 - 1 ? i4 + 1 : kAW4 - 1;   // edge dwords feed unused columns only
-#if defined(AEJ_ABLATE) && (AEJ_ABLATE == 4 || AEJ_ABLATE == 5)
-        L.Bm[2 * idx] = L.A[(j + 1) * kAW4 + i4]; continue;
-#endif
-        unsigned int he[3], ho[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            // two 16-bit fields per word by byte permutes (selector 0x0C = zero byte) of the 6 bytes at columns -1 .. 4:
-            // LE = (-1, 1), A = (0, 2), B = (1, 3), RO = (2, 4); outputs 0, 2 = LE + 2A + B, outputs 1, 3 = A + 2B + RO
-            const unsigned int *row = L.A + (j + r) * kAW4;
-            const unsigned int m = row[i4], lf = row[il], rt = row[ir];
-            const unsigned int LE = __builtin_amdgcn_perm(m, lf, 0x0C050C03u);
-            const unsigned int A = m & 0x00FF00FFu;
-            const unsigned int B = __builtin_amdgcn_perm(m, m, 0x0C030C01u);
-            const unsigned int RO = __builtin_amdgcn_perm(rt, m, 0x0C040C02u);
-            he[r] = LE + 2u * A + B;
-            ho[r] = A + 2u * B + RO;
-        }
-        unsigned int ve = he[0] + 2u * he[1] + he[2] + 0x00080008u;
-        unsigned int vo = ho[0] + 2u * ho[1] + ho[2] + 0x00080008u;
-        const unsigned int e4 = (ve >> 2) & 0x03FC03FCu;     // 4 * pixel 0 | 4 * pixel 2 << 16
-        const unsigned int o4 = (vo >> 2) & 0x03FC03FCu;     // 4 * pixel 1 | 4 * pixel 3 << 16
-        *reinterpret_cast<uint2 *>(&L.Bm[2 * idx]) = make_uint2((e4 & 0xffffu) | (o4 << 16), (e4 >> 16) | (o4 & 0xffff0000u));
-    }
-    __syncthreads();
-    if (cb.dump_gauss)
-        for (int idx = tid; idx < kBlurTH * kBlurTW; idx += 256) {
-            int j = idx / kBlurTW, i = idx - j * kBlurTW;
-            if (x0 + i < w && y0 + j < h)
-                cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] =
-                    (unsigned char)(reinterpret_cast<const unsigned short *>(L.Bm)[(j + 2) * kAW + i + 4] >> 2);
-        }
-    // ---- stage C: bilateral, 4 consecutive pixels per thread; the window columns 4*c4 + 2 .. 4*c4 + 9 of 5 Gaussian rows
-    // are 4 dwords per row (rows -2 / +2 are only tapped at dx = 0: the middle 2 dwords)
-    unsigned char *dst = cb.u8b + pbase;
-    const int c4 = tid & 15;           // output pixels x0 + 4*c4 .. +3
-    const int hbase = (tid % kHistCopies) * 129;
-#pragma unroll 1
-    for (int pass = 0; pass < kBlurTH / 16; pass++) {
-        const int j = (tid >> 4) + pass * 16;
-        unsigned int rw[5][4];
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const unsigned int *p = L.Bm + (j + r) * kBW2 + 2 * c4 + 1;
-            if (r == 0 || r == 4) { rw[r][0] = rw[r][3] = 0; rw[r][1] = p[1]; rw[r][2] = p[2]; }
-            else { rw[r][0] = p[0]; rw[r][1] = p[1]; rw[r][2] = p[2]; rw[r][3] = p[3]; }
-        }
-        unsigned int o[4];
-#pragma unroll
-        for (int px = 0; px < 4; px++) {
-#if defined(AEJ_ABLATE) && (AEJ_ABLATE == 2 || AEJ_ABLATE == 5)
-            o[px] = ((rw[2][(px + 2) >> 1] >> (16 * (px & 1))) & 0xffffu) >> 2; continue;
-#endif
-            constexpr int dys[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 };
-            constexpr int dxs[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
-            int v4[13];
-#pragma unroll
-            for (int k = 0; k < 13; k++) {
-                const int rr = 2 + dys[k], c = px + 2 + dxs[k];      // column relative to 4*c4 + 2
-                v4[k] = (c & 1) ? (int)(rw[rr][c >> 1] >> 16) : (int)(rw[rr][c >> 1] & 0xffffu);
-            }
-            o[px] = bilateral_px(L, v4);
-        }
-        if (full) {
-            *reinterpret_cast<unsigned int *>(dst + (long long)(y0 + j) * w + x0 + 4 * c4) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-#if !defined(AEJ_ABLATE) || (AEJ_ABLATE != 1 && AEJ_ABLATE != 5)
-#pragma unroll
-            for (int px = 0; px < 4; px++) hist_add(L, hbase, (int)o[px]);
-#endif
-        } else if (y0 + j < h) {
-#pragma unroll
-            for (int px = 0; px < 4; px++)
-                if (x0 + 4 * c4 + px < w) {
-                    dst[(long long)(y0 + j) * w + x0 + 4 * c4 + px] = (unsigned char)o[px];
-                    hist_add(L, hbase, (int)o[px]);
-                }
-        }
-    }
-}
-
-constexpr int kStrip = 8;    // tiles of one tile-row handled by one workgroup (LUT / tables / histogram stay in LDS)
-
-__device__ __forceinline__ bool locate_strip(const Geom &g, int t, int &layer, int &sx, int &ty)
+__device__ __forceinline__ bool locate_blur_strip(const Geom &g, int t, int &layer, int &sx, int &ty)
 {
     for (int l = 0; l < g.nl; l++) {
-        int ntx = cdiv(g.w[l], kBlurTW), nty = cdiv(g.h[l], kBlurTH), nsx = cdiv(ntx, kStrip);
+        int ntx = cdiv(g.w[l], kBTW), nty = cdiv(g.h[l], kBTH), nsx = cdiv(ntx, kBStrip);
         int n = nsx * nty;
         if (t < n) { layer = l; ty = t / nsx; sx = t - ty * nsx; return true; }
         t -= n;
@@ -361,10 +239,7 @@ __device__ __forceinline__ bool locate_strip(const Geom &g, int t, int &layer, i
     return false;
 }
 
-#ifndef AEJ_BLUR_OCC
-#define AEJ_BLUR_OCC 5
-#endif
-__global__ __launch_bounds__(256, AEJ_BLUR_OCC) void k_clahe_blur(Geom g, CannyBuffers cb)
+__global__ __launch_bounds__(kBT, 4) void k_clahe_blur(Geom g, CannyBuffers cb)
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;
@@ -372,25 +247,35 @@ __global__ __launch_bounds__(256, AEJ_BLUR_OCC) void k_clahe_blur(Geom g, CannyB
     const int strips = gridDim.x / g.B;
     const int b = (int)(wg / strips);
     int l, sx, ty;
-    if (!locate_strip(g, (int)(wg - (long long)b * strips), l, sx, ty)) return;
+    if (!locate_blur_strip(g, (int)(wg - (long long)b * strips), l, sx, ty)) return;
     const int w = g.w[l], h = g.h[l];
-    const int ntx = cdiv(w, kBlurTW);
-    const int y0 = ty * kBlurTH;
-    const int tx_begin = sx * kStrip, tx_end = min(ntx, tx_begin + kStrip);
-    const unsigned char *src = cb.u8a + (long long)b * g.pstride + g.poff[l];
+    const int ntx = cdiv(w, kBTW);
+    const int y0 = ty * kBTH;
+    const int tx_begin = sx * kBStrip, tx_end = min(ntx, tx_begin + kBStrip);
+    const long long pbase = (long long)b * g.pstride + g.poff[l];
+    const unsigned char *src = cb.u8a + pbase;
+    const unsigned char *glut = cb.lut + ((long long)b * 3 + l) * 4096;     // [ty][tx][256]
 
-    reinterpret_cast<uint4 *>(L.lut)[tid] = reinterpret_cast<const uint4 *>(cb.lut + ((long long)b * 3 + l) * 4096)[tid];
-#pragma unroll
-    for (int i = tid; i < 512; i += 256) {
+    // a tile is "aligned" when its staged window [x0-4, x0+TW+4) x [y0-3, y0+TH+3) lies inside the image: dword prefetch
+    auto is_aligned = [&](int tx) {
+        int x0 = tx * kBTW;
+        return x0 >= 4 && y0 >= 3 && x0 + kBTW + 4 <= w && y0 + kBTH + 3 <= h && (w % 4) == 0;
+    };
+    unsigned int raw[kAIter];
+    blur_prefetch(src, w, h, tx_begin * kBTW, y0, is_aligned(tx_begin), raw);      // flies while the per-strip tables are built
+
+    // ---- per-strip set-up
+    for (int i = tid; i < 512; i += kBT) {
         const int d = i - 256;
         const float cwv = i == 0 ? 0.f : cb.color_w[d < 0 ? -d : d];     // slot 0 (d = -256) is never addressed
         L.cw[0][i] = cb.space_w[5] * cwv;       // radius 1
         L.cw[1][i] = cb.space_w[1] * cwv;       // radius sqrt(2)
         L.cw[2][i] = cb.space_w[0] * cwv;       // radius 2
     }
-    for (int i = tid; i < kHistCopies * 129; i += 256) L.hist16[i] = 0;
-    if (tid >= 128 && tid < 128 + kAH) {      // row parameters of CLAHE_Interpolation_Body: fixed for the strip
-        const int j = tid - 128;
+    for (int i = tid; i < kHistCopies * kHistStride; i += kBT) L.hist[i] = 0;
+    if (tid < 2) L.pkey[tid] = -1;
+    if (tid < kBAH) {                          // row parameters of CLAHE_Interpolation_Body: fixed for the strip
+        const int j = tid;
         const int gy = reflect101(y0 - 3 + j, h);
         const float inv_th = 1.0f / (float)g.cth[l];
         float tyf = (float)gy * inv_th - 0.5f;
@@ -399,19 +284,32 @@ __global__ __launch_bounds__(256, AEJ_BLUR_OCC) void k_clahe_blur(Geom g, CannyB
         L.rowYa[j] = ya; L.rowYa1[j] = 1.0f - ya;
         if (ty1 < 0) ty1 = 0;
         if (ty2 > 3) ty2 = 3;
-        L.rowOff1[j] = ty1 * 1024; L.rowOff2[j] = ty2 * 1024;
+        L.rowT1[j] = ty1; L.rowT2[j] = ty2;
     }
-    // a tile is "aligned" when its staged window [x0-4, x0+68) x [y0-3, y0+35) lies inside the image: dword prefetch
-    auto is_aligned = [&](int tx) {
-        int x0 = tx * kBlurTW;
-        return x0 >= 4 && y0 >= 3 && x0 + kBlurTW + 4 <= w && y0 + kBlurTH + 3 <= h && (w % 4) == 0;
-    };
-    unsigned int raw[kRawPerThread];
-    blur_prefetch(src, w, h, tx_begin * kBlurTW, y0, is_aligned(tx_begin), raw);
+    __syncthreads();
+    {                                          // row classes: class 0 = the tile pair of row 0, class 1 = the pair after the (single) change
+        bool rchg = false;
+        if (tid < kBAH) {
+            const int j = tid;
+            const int key = (L.rowT1[j] << 2) | L.rowT2[j], key0 = (L.rowT1[0] << 2) | L.rowT2[0];
+            rchg = j > 0 && key != ((L.rowT1[j - 1] << 2) | L.rowT2[j - 1]);
+            if (rchg) L.cls[3] = key;
+            if (j == 0) L.cls[2] = key;
+            L.rowq[j] = key != key0 ? (int)sizeof(L.P[0]) : 0;
+        }
+        const int n = __syncthreads_count(rchg);
+        if (tid == 0) L.cls[5] = n;            // read by every tile's prologue after its own barrier
+    }
+    unsigned char *dst = cb.u8b + pbase;
 
     for (int tx = tx_begin; tx < tx_end; tx++) {
-        const int x0 = tx * kBlurTW;
-        if (tid < kAW) {                       // column parameters for this tile (reflected at the image border)
+        const int x0 = tx * kBTW;
+        const bool full = x0 + kBTW <= w && y0 + kBTH <= h && (w % 4) == 0;
+        // ---- column parameters for this tile (reflected at the image border) and their classes.  A thread evaluates its own
+        // column, its left neighbour and column 0, so the class test needs no exchange; the barrier that publishes the parameters
+        // also counts the class changes (and separates the previous tile's stage C from this tile's writes to A and G).
+        if (tid == 0) L.cls[4] = 0;
+        if (tid < kBAW) {
             const int gx = reflect101(x0 - 4 + tid, w);
             const float inv_tw = 1.0f / (float)g.ctw[l];
             float txf = (float)gx * inv_tw - 0.5f;
@@ -420,18 +318,284 @@ __global__ __launch_bounds__(256, AEJ_BLUR_OCC) void k_clahe_blur(Geom g, CannyB
             L.colXa[tid] = xa; L.colXa1[tid] = 1.0f - xa;
             if (tx1 < 0) tx1 = 0;
             if (tx2 > 3) tx2 = 3;
-            L.colOff1[tid] = tx1 * 256; L.colOff2[tid] = tx2 * 256;
+            L.colT1[tid] = tx1; L.colT2[tid] = tx2;
+        }
+        __syncthreads();                       // (also: the previous tile's stage C is finished with G, stage B with A)
+        if (tid < kBAW) {
+            const int key = (L.colT1[tid] << 2) | L.colT2[tid], key0 = (L.colT1[0] << 2) | L.colT2[0];
+            const bool chg = tid > 0 && key != ((L.colT1[tid - 1] << 2) | L.colT2[tid - 1]);
+            if (chg) { atomicAdd(&L.cls[4], 1); L.cls[1] = key; }
+            if (tid == 0) { L.cls[0] = key; }
+            L.colq[tid] = key != key0 ? (int)sizeof(L.P[0]) : 0;
         }
         __syncthreads();
-        blur_tile(g, cb, L, l, b, x0, y0, x0 + kBlurTW <= w && y0 + kBlurTH <= h && (w % 4) == 0, raw, [&]() {
-            if (tx + 1 < tx_end) blur_prefetch(src, w, h, (tx + 1) * kBlurTW, y0, is_aligned(tx + 1), raw);
-        });
+        const int nchg_c = L.cls[4], nchg_r = L.cls[5];
+        // the packed-LUT path serves windows with at most one class change in total (two packed LUTs)
+        const bool fast = nchg_c + nchg_r <= 1;
+        if (fast) {
+            // (re)build the packed LUTs this tile needs and does not hold yet: threads 0..255 slot 0, threads 256..511 slot 1
+            const int key_s0 = (L.cls[0] << 4) | L.cls[2];
+            const int key_s1 = (L.cls[nchg_c] << 4) | L.cls[2 + nchg_r];
+            const bool need1 = nchg_c + nchg_r == 1;
+            const bool build0 = L.pkey[0] != key_s0, build1 = need1 && L.pkey[1] != key_s1;
+            if (build0 || build1) {              // uniform: everything above comes from LDS words every thread reads alike
+                const int v = tid & 255, slot = tid >> 8;
+                const int key = slot ? key_s1 : key_s0;
+                if (slot ? build1 : build0) {
+                    const int ckey = key >> 4, rkey = key & 15;
+                    const int tx1 = ckey >> 2, tx2 = ckey & 3, ty1 = rkey >> 2, ty2 = rkey & 3;
+                    L.P[slot][v] = make_float4((float)glut[(ty1 * 4 + tx1) * 256 + v], (float)glut[(ty1 * 4 + tx2) * 256 + v],
+                                               (float)glut[(ty2 * 4 + tx1) * 256 + v], (float)glut[(ty2 * 4 + tx2) * 256 + v]);
+                }
+                __syncthreads();                   // every thread has compared the old keys; the new entries are visible
+                if (v == 0 && (slot ? build1 : build0)) L.pkey[slot] = key;
+            }
+        }
+        // Thread -> work mappings are re-derived per tile from a copy of the thread id the compiler cannot see through: otherwise
+        // it hoists a few dozen per-thread LDS addresses out of the tile loop and, with stage C needing the whole register
+        // budget, parks them in scratch memory.
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int acol = tq % kBAW4, aslot = tq / kBAW4;      // stage A / B: this thread's column dword and row slot / row group
+        // ---- stage A: CLAHE interpolation, 4 pixels (one dword) per item; this thread's column is fixed
+        if (aslot < kASlots) {
+            const float4 xa = reinterpret_cast<const float4 *>(L.colXa)[acol], xa1 = reinterpret_cast<const float4 *>(L.colXa1)[acol];
+            if (fast) {
+                const int4 cq = reinterpret_cast<const int4 *>(L.colq)[acol];
+                const char *Pb = reinterpret_cast<const char *>(&L.P[0][0]);
+#pragma unroll
+                for (int k = 0; k < kAIter; k++) {
+                    const int j = aslot + kASlots * k;
+                    if (j < kBAH) {
+                        const unsigned int rv = raw[k];
+                        const int rq = L.rowq[j];
+                        const float ya = L.rowYa[j], ya1 = L.rowYa1[j];
+                        const float4 f0 = *reinterpret_cast<const float4 *>(Pb + ((rv & 0xffu) * 16u + (unsigned)(cq.x + rq)));
+                        const float4 f1 = *reinterpret_cast<const float4 *>(Pb + (((rv >> 8) & 0xffu) * 16u + (unsigned)(cq.y + rq)));
+                        const float4 f2 = *reinterpret_cast<const float4 *>(Pb + (((rv >> 16) & 0xffu) * 16u + (unsigned)(cq.z + rq)));
+                        const float4 f3 = *reinterpret_cast<const float4 *>(Pb + ((rv >> 24) * 16u + (unsigned)(cq.w + rq)));
+                        // v_cvt_pk_u8_f32 = cvRound + saturate_cast<uchar> + pack (round-half-even, checked on hardware)
+                        unsigned int o = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend(f0.x, f0.y, f0.z, f0.w, xa.x, xa1.x, ya, ya1), 0, 0u);
+                        o = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend(f1.x, f1.y, f1.z, f1.w, xa.y, xa1.y, ya, ya1), 1, o);
+                        o = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend(f2.x, f2.y, f2.z, f2.w, xa.z, xa1.z, ya, ya1), 2, o);
+                        o = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend(f3.x, f3.y, f3.z, f3.w, xa.w, xa1.w, ya, ya1), 3, o);
+                        L.A[j * kBAW4 + acol] = o;
+                    }
+                }
+            } else {
+                const int4 t1 = reinterpret_cast<const int4 *>(L.colT1)[acol], t2 = reinterpret_cast<const int4 *>(L.colT2)[acol];
+                const int ct1[4] = { t1.x, t1.y, t1.z, t1.w }, ct2[4] = { t2.x, t2.y, t2.z, t2.w };
+                const float cxa[4] = { xa.x, xa.y, xa.z, xa.w }, cxa1[4] = { xa1.x, xa1.y, xa1.z, xa1.w };
+                for (int k = 0; k < kAIter; k++) {
+                    const int j = aslot + kASlots * k;
+                    if (j < kBAH) {
+                        const unsigned int rv = raw[k];
+                        const int r1 = L.rowT1[j] * 1024, r2 = L.rowT2[j] * 1024;
+                        const float ya = L.rowYa[j], ya1 = L.rowYa1[j];
+                        unsigned int o = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int v = (rv >> (8 * q)) & 0xff;
+                            const float res = clahe_blend((float)glut[r1 + ct1[q] * 256 + v], (float)glut[r1 + ct2[q] * 256 + v],
+                                                          (float)glut[r2 + ct1[q] * 256 + v], (float)glut[r2 + ct2[q] * 256 + v], cxa[q], cxa1[q], ya, ya1);
+                            o = __builtin_amdgcn_cvt_pk_u8_f32(res, q, o);
+                        }
+                        L.A[j * kBAW4 + acol] = o;
+                    }
+                }
+            }
+        }
+        // raw[] is free again: the next tile's bytes fly while this tile runs stages B and C
+        if (tx + 1 < tx_end) blur_prefetch(src, w, h, (tx + 1) * kBTW, y0, is_aligned(tx + 1), raw);
+        __syncthreads();
+        if (cb.dump_clahe)
+            for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
+                int j = idx / kBTW, i = idx - j * kBTW;
+                if (x0 + i < w && y0 + j < h)
+                    cb.dump_clahe[pbase + (long long)(y0 + j) * w + x0 + i] = reinterpret_cast<const unsigned char *>(L.A)[(j + 3) * kBAW + i + 4];
+            }
+        // ---- stage B: Gaussian [1 2 1]^2, (sum + 8) >> 4, SWAR on even/odd bytes (16-bit fields hold <= 4088).  The thread walks
+        // down its column dword: horizontal sums of a CLAHE row are formed once and combined with those of the two rows above.
+        if (aslot < kASlots) {
+            const int i4 = acol;
+            const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kBAW4 - 1 ? i4 + 1 : kBAW4 - 1;   // edge dwords feed unused columns only
+            const int jg0 = aslot * kBRows;
+            unsigned int he1 = 0, he2 = 0, ho1 = 0, ho2 = 0;     // horizontal sums of the previous row (1) and the one before (2)
+#pragma unroll
+            for (int rr = 0; rr < kBRows + 2; rr++) {
+                const int ja = jg0 + rr;           // CLAHE row; Gaussian row jg = ja - 2 uses CLAHE rows jg .. jg + 2
+                if (ja < kBAH) {
+                    // two 16-bit fields per word by byte permutes (selector 0x0C = zero byte) of the 6 bytes at columns -1 .. 4:
+                    // LE = (-1, 1), A = (0, 2), B = (1, 3), RO = (2, 4); outputs 0, 2 = LE + 2A + B, outputs 1, 3 = A + 2B + RO
+                    const unsigned int *row = L.A + ja * kBAW4;
+                    const unsigned int m = row[i4], lf = row[il], rt = row[ir];
+                    const unsigned int LE = __builtin_amdgcn_perm(m, lf, 0x0C050C03u);
+                    const unsigned int Am = m & 0x00FF00FFu;
+                    const unsigned int Bm = __builtin_amdgcn_perm(m, m, 0x0C030C01u);
+                    const unsigned int RO = __builtin_amdgcn_perm(rt, m, 0x0C040C02u);
+                    const unsigned int he = LE + 2u * Am + Bm, ho = Am + 2u * Bm + RO;
+                    if (rr >= 2 && ja - 2 < kBGH) {
+                        const unsigned int ve = he2 + 2u * he1 + he + 0x00080008u;
+                        const unsigned int vo = ho2 + 2u * ho1 + ho + 0x00080008u;
+                        const unsigned int e4 = (ve >> 2) & 0x03FC03FCu;     // 4 * pixel 0 | 4 * pixel 2 << 16
+                        const unsigned int o4 = (vo >> 2) & 0x03FC03FCu;     // 4 * pixel 1 | 4 * pixel 3 << 16
+                        unsigned int *gp = &L.G[(ja - 2) * kBGW + 4 * i4 + 2];
+                        *reinterpret_cast<uint2 *>(gp) = make_uint2((e4 & 0xffffu) | 0x4B000000u, (o4 & 0xffffu) | 0x4B000000u);
+                        *reinterpret_cast<uint2 *>(gp + 2) = make_uint2((e4 >> 16) | 0x4B000000u, (o4 >> 16) | 0x4B000000u);
+                    }
+                    he2 = he1; he1 = he; ho2 = ho1; ho1 = ho;
+                }
+            }
+        }
+        __syncthreads();
+        if (cb.dump_gauss)
+            for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
+                int j = idx / kBTW, i = idx - j * kBTW;
+                if (x0 + i < w && y0 + j < h)
+                    cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] = (unsigned char)((L.G[(j + 2) * kBGW + i + 6] & 0xffffu) >> 2);
+            }
+        // ---- stage C: bilateral; the thread owns output pixels (x0 + 4 c4 + c, y0 + yy + r), c = 0..3, r = 0..1.
+        // Window element W[wr][wc] = Gaussian row yy + wr (wr = 0..5 <-> dy = -2..3 from output row 0), column 4 c4 + 2 + wc
+        // (wc = 0..7 <-> dx = -2..5 from output column 0); output pixel (r, c) is W[r + 2][c + 2].
+        int tc = tid;
+        asm volatile("" : "+v"(tc));
+        const int c4 = tc & 31;
+        unsigned int *hcopy = L.hist + (tc % kHistCopies) * kHistStride;
+#pragma unroll 1
+        for (int pass = 0; pass < kBTH / 32; pass++) {
+            const int yy = 2 * ((tc >> 5) + 16 * pass);
+            unsigned int W[6][8];
+            {
+                // twelve aligned 16-byte reads (512 contiguous bytes per 32 lanes: conflict-free), issued as written: left to itself
+                // the compiler narrows them to the 36 dwords that are used and emits 8-byte / 4-byte reads at a 16-byte lane stride,
+                // which lose 2 - 4 x to bank conflicts (measured: 40 % of this kernel's LDS cycles)
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 m[12];
+                const unsigned int base = (unsigned int)(size_t)(L.G + yy * kBGW + 4 * c4 + 4);       // W[0][0]: 16-byte aligned LDS address
+                constexpr int RS = kBGW * 4;
+                static_assert(5 * RS + 16 < 65536, "DS offset field");
+                asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:16\n\t"
+                             "ds_read_b128 %2, %12 offset:%c13\n\tds_read_b128 %3, %12 offset:%c14\n\t"
+                             "ds_read_b128 %4, %12 offset:%c15\n\tds_read_b128 %5, %12 offset:%c16\n\t"
+                             "ds_read_b128 %6, %12 offset:%c17\n\tds_read_b128 %7, %12 offset:%c18\n\t"
+                             "ds_read_b128 %8, %12 offset:%c19\n\tds_read_b128 %9, %12 offset:%c20\n\t"
+                             "ds_read_b128 %10, %12 offset:%c21\n\tds_read_b128 %11, %12 offset:%c22\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6]), "=&v"(m[7]), "=&v"(m[8]),
+                               "=&v"(m[9]), "=&v"(m[10]), "=&v"(m[11])
+                             : "v"(base), "i"(RS), "i"(RS + 16), "i"(2 * RS), "i"(2 * RS + 16), "i"(3 * RS), "i"(3 * RS + 16), "i"(4 * RS), "i"(4 * RS + 16),
+                               "i"(5 * RS), "i"(5 * RS + 16)
+                             : "memory");
+#pragma unroll
+                for (int wr = 0; wr < 6; wr++) {
+                    W[wr][0] = m[2 * wr].x; W[wr][1] = m[2 * wr].y; W[wr][2] = m[2 * wr].z; W[wr][3] = m[2 * wr].w;
+                    W[wr][4] = m[2 * wr + 1].x; W[wr][5] = m[2 * wr + 1].y; W[wr][6] = m[2 * wr + 1].z; W[wr][7] = m[2 * wr + 1].w;
+                }
+            }
+            // Pair weights: each is fetched once and used by both pixels of the pair when both belong to this thread.  Indexing
+            // (window coordinates): H1[r][i] = pair (r+2, 1+i)-(r+2, 2+i); H2[r][i] = (r+2, i)-(r+2, i+2); V1[rr][c] = (1+rr, c+2)-(2+rr, c+2);
+            // V2[rr][c] = (rr, c+2)-(rr+2, c+2); D1[rr][i] = (1+rr, 1+i)-(2+rr, 2+i); D2[rr][i] = (1+rr, 2+i)-(2+rr, 1+i).
+            // The two output rows are done one after the other (a scheduling barrier keeps the second row's gathers from being
+            // hoisted over the first row's sums: the register budget is 128); the pairs between them (V1[1], D1[1], D2[1]) carry over.
+            float sums[8], wsums[8];
+            float V1m[4], D1m[5], D2m[5];
+#pragma unroll
+            for (int c = 0; c < 4; c++) V1m[c] = pair_w<0>(L, W[2][c + 2], W[3][c + 2]);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                D1m[i] = pair_w<1>(L, W[2][1 + i], W[3][2 + i]);
+                D2m[i] = pair_w<1>(L, W[2][2 + i], W[3][1 + i]);
+            }
+            auto val = [&](int wr, int wc) { return __builtin_bit_cast(float, W[wr][wc]) - 8388608.0f; };     // 4 x tap value, exact
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                float H1[5], H2[6], V1o[4], V2a[4], V2b[4], D1o[4], D2o[4];
+#pragma unroll
+                for (int i = 0; i < 5; i++) H1[i] = pair_w<0>(L, W[r + 2][1 + i], W[r + 2][2 + i]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) H2[i] = pair_w<2>(L, W[r + 2][i], W[r + 2][i + 2]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    V2a[c] = pair_w<2>(L, W[r][c + 2], W[r + 2][c + 2]);              // (-2, 0)
+                    V2b[c] = pair_w<2>(L, W[r + 2][c + 2], W[r + 4][c + 2]);          // (+2, 0)
+                    // the vertical / diagonal pairs towards the row that is NOT this thread's other output row
+                    V1o[c] = r == 0 ? pair_w<0>(L, W[1][c + 2], W[2][c + 2]) : pair_w<0>(L, W[3][c + 2], W[4][c + 2]);
+                    D1o[c] = r == 0 ? pair_w<1>(L, W[1][1 + c], W[2][2 + c]) : pair_w<1>(L, W[3][2 + c], W[4][3 + c]);      // r = 0: (-1,-1); r = 1: (+1,+1)
+                    D2o[c] = r == 0 ? pair_w<1>(L, W[1][3 + c], W[2][2 + c]) : pair_w<1>(L, W[3][2 + c], W[4][1 + c]);      // r = 0: (-1,+1); r = 1: (+1,-1)
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float sum = 0.f, wsum = 0.f;
+                    acc_tap(sum, wsum, val(r, c + 2), V2a[c]);                                  // (-2,  0)
+                    acc_tap(sum, wsum, val(r + 1, c + 1), r == 0 ? D1o[c] : D1m[c]);            // (-1, -1)
+                    acc_tap(sum, wsum, val(r + 1, c + 2), r == 0 ? V1o[c] : V1m[c]);            // (-1,  0)
+                    acc_tap(sum, wsum, val(r + 1, c + 3), r == 0 ? D2o[c] : D2m[c + 1]);        // (-1, +1)
+                    acc_tap(sum, wsum, val(r + 2, c), H2[c]);                                   // ( 0, -2)
+                    acc_tap(sum, wsum, val(r + 2, c + 1), H1[c]);                               // ( 0, -1)
+                    acc_tap(sum, wsum, val(r + 2, c + 2), 1.0f);                                // centre
+                    acc_tap(sum, wsum, val(r + 2, c + 3), H1[c + 1]);                           // ( 0, +1)
+                    acc_tap(sum, wsum, val(r + 2, c + 4), H2[c + 2]);                           // ( 0, +2)
+                    acc_tap(sum, wsum, val(r + 3, c + 1), r == 0 ? D2m[c] : D2o[c]);            // (+1, -1)
+                    acc_tap(sum, wsum, val(r + 3, c + 2), r == 0 ? V1m[c] : V1o[c]);            // (+1,  0)
+                    acc_tap(sum, wsum, val(r + 3, c + 3), r == 0 ? D1m[c + 1] : D1o[c]);        // (+1, +1)
+                    acc_tap(sum, wsum, val(r + 4, c + 2), V2b[c]);                              // (+2,  0)
+                    sums[r * 4 + c] = sum; wsums[r * 4 + c] = wsum;
+                }
+                if (r == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            float z[8];
+            // cvRound(sum / wsum): only the nearest integer is needed, so the quotient is first formed with the hardware reciprocal
+            // (1 ulp; with the product's rounding |z - sum / wsum| < 3 ulp(255) = 4.6e-5) and the exact IEEE division is redone, per
+            // output row, only when some lane's z lies within 2^-13 = 1.2e-4 of a rounding boundary k + 0.5 (one pixel in ~4000),
+            // where the two could round apart.
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                bool amb = false;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int q = r * 4 + c;
+                    z[q] = (sums[q] * __builtin_amdgcn_rcpf(wsums[q])) * 0.25f;
+                    amb = amb || (__builtin_fabsf(__builtin_amdgcn_fractf(z[q]) - 0.5f) < 1.220703125e-4f);
+                }
+                if (__any(amb)) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) z[r * 4 + c] = (sums[r * 4 + c] / wsums[r * 4 + c]) * 0.25f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                unsigned int packed = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) packed = __builtin_amdgcn_cvt_pk_u8_f32(z[r * 4 + c], c, packed);
+                const int y = y0 + yy + r;
+                if (full) {
+                    *reinterpret_cast<unsigned int *>(dst + (long long)y * w + x0 + 4 * c4) = packed;
+                    // The filtered image is locally flat: lanes of one LDS atomic instruction often hit the same counter and
+                    // serialise.  Four equal pixels take one add of 4 instead of four adds (the common case in flat regions).
+                    if (packed == (packed & 0xffu) * 0x01010101u) {
+                        atomicAdd(&hcopy[packed & 0xffu], 4u);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) atomicAdd(&hcopy[(packed >> (8 * c)) & 0xffu], 1u);
+                    }
+                } else if (y < h) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (x0 + 4 * c4 + c < w) {
+                            dst[(long long)y * w + x0 + 4 * c4 + c] = (unsigned char)(packed >> (8 * c));
+                            atomicAdd(&hcopy[(packed >> (8 * c)) & 0xffu], 1u);
+                        }
+                }
+            }
+        }
     }
     __syncthreads();
-    unsigned int c = 0;
+    if (tid < 256) {
+        unsigned int c = 0;
 #pragma unroll
-    for (int k = 0; k < kHistCopies; k++) c += (L.hist16[k * 129 + (tid >> 1)] >> (16 * (tid & 1))) & 0xffffu;
-    if (c) atomicAdd(&cb.blur_hist[((long long)b * 3 + l) * 256 + tid], (int)c);
+        for (int k = 0; k < kHistCopies; k++) c += L.hist[k * kHistStride + tid];
+        if (c) atomicAdd(&cb.blur_hist[((long long)b * 3 + l) * 256 + tid], (int)c);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -495,6 +659,19 @@ __global__ __launch_bounds__(256) void k_thresholds(Geom g, const int *__restric
 // loads in flight; stage 1 computes gradient + magnitude for 4 pixels per item with SWAR [1 2 1] sums;
 // stage 2 does the NMS test with one wave per 64-pixel row segment so that the output words are wave ballots.
 // ------------------------------------------------------------------------------------------------
+constexpr int kStrip = 8;    // tiles of one tile-row handled by one workgroup
+
+__device__ __forceinline__ bool locate_strip(const Geom &g, int t, int &layer, int &sx, int &ty)
+{
+    for (int l = 0; l < g.nl; l++) {
+        int ntx = cdiv(g.w[l], kBlurTW), nty = cdiv(g.h[l], kBlurTH), nsx = cdiv(ntx, kStrip);
+        int n = nsx * nty;
+        if (t < n) { layer = l; ty = t / nsx; sx = t - ty * nsx; return true; }
+        t -= n;
+    }
+    return false;
+}
+
 constexpr int kNW4 = (kBlurTW + 8) / 4;      // 18 dwords per staged row: columns c <-> gx = x0 - 4 + c
 constexpr int kNUH = kBlurTH + 4;            // u8 rows  [y0-2, y0+TH+2)
 constexpr int kNMH = kBlurTH + 2;            // mag rows [y0-1, y0+TH+1)
@@ -871,10 +1048,10 @@ void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
     long long t = 0;
     for (int l = 0; l < g.nl; l++) {
-        int ntx = (g.w[l] + kBlurTW - 1) / kBlurTW, nty = (g.h[l] + kBlurTH - 1) / kBlurTH;
-        t += (long long)((ntx + kStrip - 1) / kStrip) * nty;
+        int ntx = (g.w[l] + kBTW - 1) / kBTW, nty = (g.h[l] + kBTH - 1) / kBTH;
+        t += (long long)((ntx + kBStrip - 1) / kBStrip) * nty;
     }
-    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(t * g.B)), dim3(256), 0, st, g, cb);
+    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(t * g.B)), dim3(kBT), 0, st, g, cb);
 }
 
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)

@@ -76,8 +76,7 @@ __global__ __launch_bounds__(512) void k_mem(float *out, const float *table, int
     for (int i = 0; i < 8; i++) off[i] = ((((lane * 2654435761u + i * 40503u + blockIdx.x * 977u) >> 7) % (unsigned)table_dwords)) * 4u;
     const unsigned lds0 = (unsigned)(size_t)(&s[0]);
     // buffer resource over the table: base, stride 0, num_records = bytes, flags for raw dword access
-    int4v rsrc;
-    rsrc.x = (int)(unsigned)(size_t)table; rsrc.y = (int)((size_t)table >> 32) & 0xffff; rsrc.z = table_dwords * 4; rsrc.w = 0x00020000;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(table), 0, table_dwords * 4, 0x00020000);
     float acc = 0.f;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
