@@ -42,21 +42,39 @@ __device__ __forceinline__ int zigzag_pos(int r, int c)
 }
 
 // np.round(block / q).astype(int32): float64 quotient, round half to even (jpeg.py:499-502).
-__device__ __forceinline__ int quantise(float y, int q)
+__device__ __forceinline__ int quantise_f64(float y, int q)
 {
     double v = (double)y / (double)q;
     return (int)rint(v);
 }
 
-// The same for the large (MFMA) blocks, where most coefficients are far below q / 2 and the result is 0 whatever the
-// quotient's last bits are: when that holds for the whole wave the float64 division (about 15 VALU instructions) is skipped.
-// 0.499f leaves the float32 rounding of the product and of q orders of magnitude of margin.  (Not used for blocks <= 16:
-// their waves rarely qualify and the test costs more than it saves, measured.)
-__device__ __forceinline__ int quantise_sparse(float y, int q)
+// The same integer from float32 operations only (the float64 division is ~15 double-rate instructions per coefficient and was
+// the longest phase of the low-frequency wave of every large leaf).  k = rint(y * (1/q)) is at most one off; the remainder
+// r = fma(-k, q, y) = y - k q is EXACT in float32 (it is a multiple of ulp(y) no larger than 1.5 q), so comparing |r| with q / 2
+// decides between k and its neighbour, and |r| == q / 2 is exactly the case where the float64 quotient is k +- 1/2 and
+// np.round goes to the even one.  (A non-zero |2r - q| is at least one ulp(y) >= 2^-24 |y|, far above the 2^-53 relative spacing
+// at which the rounded float64 quotient could fake a tie.)  Range guard: quantisers above 2^22 or quotients above 2^18 -- never
+// produced by the codec's own tables -- take the float64 division.  tests/native/quantise_check.c verifies the sequence, with the
+// reciprocal perturbed by +-4 ulp, against rint((double)y / q) on 5e8 random, tie and near-tie cases.
+__device__ __forceinline__ int quantise_f32(float y, float qf, float *quot = nullptr)      // qf = (float)q, q <= 2^22; valid while |y / q| < 2^18
 {
-    const bool tiny = fabsf(y) < 0.499f * (float)q;
-    if (__all(tiny)) return 0;
-    return quantise(y, q);
+    const float t = y * __builtin_amdgcn_rcpf(qf);
+    const float k = __builtin_rintf(t);
+    const float r = __builtin_fmaf(-k, qf, y);
+    const float h = 0.5f * qf, ar = __builtin_fabsf(r);
+    int ki = (int)k;
+    if (ar > h || (ar == h && (ki & 1))) ki += r > 0.f ? 1 : -1;
+    if (quot) *quot = t;
+    return ki;
+}
+
+__device__ __forceinline__ int quantise(float y, int q)
+{
+    float t;
+    const int ki = quantise_f32(y, (float)q, &t);
+    const bool slow = q > (1 << 22) || !(__builtin_fabsf(t) < 262144.0f);
+    if (__any(slow)) return quantise_f64(y, q);
+    return ki;
 }
 
 // Work items of one block size are the concatenation, over planes (b, l), of that plane's Morton-ordered leaf list.
@@ -112,15 +130,10 @@ __device__ __forceinline__ int4 fetch_item(const DctArgs &a, long long work_stri
     return reinterpret_cast<const int4 *>(a.work)[idx];
 }
 
-// Same mapping for a caller whose item indices only grow: scan forward from the plane of the previous item (`p`, updated)
-// instead of bisecting -- usually one or two LDS reads on the critical path instead of eight dependent ones.
-__device__ __forceinline__ int4 fetch_item_fwd(const DctArgs &a, long long work_stride, const LayerTab &lt, const int *s_pref, long long item, int &p)
-{
-    while (p + 1 < a.nplanes && (long long)s_pref[p + 1] <= item) p++;
-    const int b = p / 3, l = p - 3 * b;
-    const long long idx = (long long)b * work_stride + lt.woff[l] + (item - s_pref[p]);
-    return reinterpret_cast<const int4 *>(a.work)[idx];
-}
+// The MFMA kernels (one leaf per workgroup and iteration) keep the descriptors of their next leaves in LDS: chunks of kDescChunk
+// descriptors, one per thread, are fetched a whole chunk ahead, so that no global-memory latency sits between two leaves (a
+// descriptor fetched when it is needed costs a full HBM round trip per leaf: measured 4 700 of 16 800 cycles per 64 x 64 leaf).
+constexpr int kDescChunk = 64;
 
 // ------------------------------------------------------------------------------------------------
 // small blocks: S in {2, 4, 8, 16}; 256 threads = 256/S leaves, S threads per leaf.
@@ -182,6 +195,10 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
             float t[S];
 #pragma unroll
             for (int k = 0; k < S; k++) t[k] = sT[(slot * S + j) * (S + 1) + k];
+            float yv[S];
+            int qv[S];
+            float ymax = 0.f;
+            int qmax = 0;
 #pragma unroll
             for (int jj = 0; jj < S; jj++) {
                 float acc = 0.f;
@@ -189,7 +206,18 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
                 for (int k = 0; k < S; k++) acc = __builtin_fmaf(t[k], sD[jj * S + k], acc);
                 const int ridx = j * S + jj;
                 if (WANT_DCT) a.dct_f32[out_base + ridx] = acc;
-                sQ[slot * SS + sZ[ridx]] = quantise(acc, sQm[layer * SS + ridx]);
+                yv[jj] = acc;
+                qv[jj] = sQm[layer * SS + ridx];
+                ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
+                qmax = max(qmax, qv[jj]);
+            }
+            // one range test per row for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
+            if (!__any(qmax > (1 << 22) || !(ymax < 131072.0f))) {
+#pragma unroll
+                for (int jj = 0; jj < S; jj++) sQ[slot * SS + sZ[j * S + jj]] = quantise_f32(yv[jj], (float)qv[jj]);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < S; jj++) sQ[slot * SS + sZ[j * S + jj]] = quantise_f64(yv[jj], qv[jj]);
             }
         }
         __syncthreads();
@@ -257,6 +285,8 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
             }
         const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
         int out[16];
+        float Y[4][4], ymax = 0.f;
+        int qmax = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -265,8 +295,22 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
 #pragma unroll
                 for (int k = 0; k < 4; k++) acc = __builtin_fmaf(T[i][k], D[jj][k], acc);
                 if (WANT_DCT) a.dct_f32[out_base + i * 4 + jj] = acc;
-                out[zigzag_pos<4>(i, jj)] = quantise(acc, sQm[layer * 16 + i * 4 + jj]);
+                Y[i][jj] = acc;
+                ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
+                qmax = max(qmax, sQm[layer * 16 + i * 4 + jj]);
             }
+        // one range test per leaf for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
+        if (!__any(qmax > (1 << 22) || !(ymax < 131072.0f))) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) out[zigzag_pos<4>(i, jj)] = quantise_f32(Y[i][jj], (float)sQm[layer * 16 + i * 4 + jj]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) out[zigzag_pos<4>(i, jj)] = quantise_f64(Y[i][jj], sQm[layer * 16 + i * 4 + jj]);
+        }
         int4 *dst = reinterpret_cast<int4 *>(a.coeffs + out_base);     // offsets are sums of squares of sizes >= 2: multiples of 4
 #pragma unroll
         for (int r = 0; r < 4; r++) dst[r] = make_int4(out[4 * r], out[4 * r + 1], out[4 * r + 2], out[4 * r + 3]);
@@ -313,16 +357,23 @@ __global__ __launch_bounds__(256) void k_dct_big(Geom g, QtGeom q, DctArgs a, lo
     }
 }
 
-// LDS-DMA (global_load_lds): per-lane global source, LDS destination = wave-uniform base + lane * size.
+// LDS-DMA (global_load_lds): per-lane global source, LDS destination = wave-uniform base (M0) + lane * size.  Issued from inline
+// assembly on purpose: the compiler treats the builtin as a store to LDS that any later LDS read may alias and drains it
+// (s_waitcnt vmcnt(0)) before the very next ds_read -- which would expose the whole prefetch latency once per leaf.  Here the
+// kernel itself orders the transfers (wait_vmem_but + lds_barrier); M0 is saved / restored inside the statement.
 __device__ __forceinline__ void glds16(const float *g, float *lds_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 __device__ __forceinline__ void glds4(const float *g, float *lds_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,23 +391,50 @@ struct MfmaCfg {
     static constexpr int NWAVES = NT * NT / TPW;
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int MINW = S == 32 ? 4 : S == 64 ? 3 : 2;   // waves per SIMD the register budget is sized for
+    static constexpr int NXB = S == 128 ? 1 : 2;            // X buffers (3 x 64 KiB would not fit for S = 128)
 };
 
+// scalar-base form: every lane adds its own byte offset to one wave-uniform 64-bit base (no per-lane 64-bit address arithmetic)
+__device__ __forceinline__ void glds16_s(const float *base_uniform, unsigned lane_byte_off, float *lds_wave_base)
+{
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    const unsigned long long b = (unsigned long long)(size_t)base_uniform;
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long sb = ((unsigned long long)bhi << 32) | blo;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(dst), "s"(sb) : "memory");
+}
+
 // X -> LDS by LDS-DMA (no VGPR staging): full leaves 1 KiB (256 floats) per wave instruction, clipped or unaligned ones one
-// dword per lane with the np.pad(reflect) index map applied to the source address
+// dword per lane with the np.pad(reflect) index map applied to the source address.  `xoff` = this lane's element offsets
+// (row * w + column) of its pieces of a full leaf for the layer width `w` they were computed for (dct_x_offsets).
 template <int S, int NWAVES>
-__device__ __forceinline__ void dct_load_x(const float *src, int w, int h, const int4 &d, float *sX, int wave, int lane)
+struct XOffsets { unsigned off[S * S / 256 / NWAVES]; int w; };
+
+template <int S, int NWAVES>
+__device__ __forceinline__ void dct_x_offsets(XOffsets<S, NWAVES> &xo, int w, int wave, int lane)
+{
+    constexpr int ROWS = 256 / S;                 // rows per wave instruction
+#pragma unroll
+    for (int t = 0; t < S * S / 256 / NWAVES; t++) {
+        const int chunk = t * NWAVES + wave;
+        const int r = chunk * ROWS + lane / (S / 4), c = (lane % (S / 4)) * 4;
+        xo.off[t] = (unsigned)(r * w + c) * 4u;
+    }
+    xo.w = w;
+}
+
+template <int S, int NWAVES>
+__device__ __forceinline__ void dct_load_x(const float *src, int w, int h, const int4 &d, float *sX, int wave, int lane, XOffsets<S, NWAVES> &xo)
 {
     constexpr int SS = S * S;
     const int hc = min(S, h - d.z), wc = min(S, w - d.y);
     if (hc == S && wc == S && (w & 3) == 0) {
-        constexpr int ROWS = 256 / S;                 // rows per wave instruction
+        if (xo.w != w) dct_x_offsets<S, NWAVES>(xo, w, wave, lane);     // the layer changed (wave-uniform)
+        const float *leaf = src + (long long)d.z * w + d.y;
 #pragma unroll
-        for (int t = 0; t < SS / 256 / NWAVES; t++) {
-            const int chunk = t * NWAVES + wave;
-            const int r = chunk * ROWS + lane / (S / 4), c = (lane % (S / 4)) * 4;
-            glds16(src + (long long)(d.z + r) * w + d.y + c, sX + chunk * 256);
-        }
+        for (int t = 0; t < SS / 256 / NWAVES; t++) glds16_s(leaf, xo.off[t], sX + (t * NWAVES + wave) * 256);
     } else {
 #pragma unroll 4
         for (int t = 0; t < SS / 64 / NWAVES; t++) {
@@ -368,18 +446,43 @@ __device__ __forceinline__ void dct_load_x(const float *src, int w, int h, const
     }
 }
 
+// Synchronisation of the MFMA kernels.  __syncthreads() is "s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier": it would drain, three
+// times per leaf, every global-memory operation of the wave -- the LDS-DMA prefetch of the NEXT leaf and the coefficient stores
+// of the previous one included -- and expose their latency.  What the three hand-offs through LDS need is the wave's LDS
+// operations only; the one thing that has to have LANDED from global memory, the current leaf's X, is waited for with a
+// COUNTED vmcnt that leaves the younger stores in flight (vector-memory operations retire in issue order).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_vmem_but() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+#ifdef AEJ_X_STAMPS
+// diagnostic build only (tools/profiling/variants.py): cycles spent per phase of the leaf loop, summed per workgroup (wave 0)
+__device__ long long g_stamps[2][512][12];
+#define AEJ_STAMP(i) { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
+extern "C" __attribute__((visibility("default"))) int aej_debug_read_stamps(long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define AEJ_STAMP(i)
+#endif
+
 template <int S, bool WANT_DCT>
-__global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
+__global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items,
+                                                                                      const int4 *__restrict__ work /* = a.work, read-only: scalar loads */)
 {
     using C = MfmaCfg<S>;
     constexpr int NT = C::NT, TPW = C::TPW, NWAVES = C::NWAVES, NTHREADS = C::NTHREADS;
     constexpr int SS = S * S;
-    constexpr int NXB = S == 64 ? 2 : 1;          // X double-buffered (next leaf prefetched by LDS-DMA): pays only for 64x64 leaves
+    constexpr int NXB = C::NXB;        // X double-buffered: the next leaf's X is fetched by LDS-DMA while this one is transformed
+    constexpr int NCOPY = SS / (NTHREADS * 4);                 // 16-byte coefficient stores per thread and leaf
+    constexpr int NYOUNG = NCOPY + (WANT_DCT ? 16 * TPW : 0);  // global stores a wave issues AFTER the prefetch of the next X
+    static_assert(NYOUNG < 60, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sXb = smem;                 // [NXB][S][S]  X, the current one later reused as int staging for the zigzag scatter
     float *sP = smem + NXB * SS;       // [S][S]  P = T^T
-    LayerTab &lt = *reinterpret_cast<LayerTab *>(smem + (NXB + 1) * SS);
-    int *s_pref = reinterpret_cast<int *>(smem + (NXB + 1) * SS) + (sizeof(LayerTab) + 3) / 4;   // [nplanes + 1]
+    int4 *s_desc = reinterpret_cast<int4 *>(smem + (NXB + 1) * SS);                      // [2][kDescChunk] leaf descriptors
+    LayerTab &lt = *reinterpret_cast<LayerTab *>(s_desc + 2 * kDescChunk);
+    int *s_pref = reinterpret_cast<int *>(s_desc + 2 * kDescChunk) + (sizeof(LayerTab) + 3) / 4;   // [nplanes + 1]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wj = wave % NT, wi0 = wave / NT;       // tile column; first tile row (the others are wi0 + t * NT / TPW)
@@ -392,41 +495,122 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
     for (int s = 0; s < S / 2; s++) dreg[s] = a.D[(J0 + li) * S + 2 * s + lh];
 
     dct_prologue(g, q, a, s_pref, lt);
+    // The waits inside the loop are written by hand (inline assembly the compiler's wait-count bookkeeping cannot see), so the
+    // loads issued so far are consumed HERE: an empty statement that takes each register as an operand makes the compiler
+    // wait for it now instead of guarding its first use in the loop with counted waits that would also catch the prefetch.
+#pragma unroll
+    for (int s = 0; s < S / 2; s++) asm volatile("" : "+v"(dreg[s]));
     long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
     const long long wstride = q.work_stride[a.k];
     const long long step = gridDim.x;
     long long item = blockIdx.x;
-    int4 cur = make_int4(0, 0, 0, 0), nxt = make_int4(0, 0, 0, 0);
-    int plane_hint = 0;
-    if (item < count) cur = fetch_item_fwd(a, wstride, lt, s_pref, item, plane_hint);
-    if (item + step < count) nxt = fetch_item_fwd(a, wstride, lt, s_pref, item + step, plane_hint);
-    int pb = 0;
-    if (NXB == 2 && item < count) {
-        const int b0 = cur.x / 3, l0 = cur.x - b0 * 3;
-        dct_load_x<S, NWAVES>(a.norm + (long long)b0 * g.pstride + lt.poff[l0], lt.w[l0], lt.h[l0], cur, sXb, wave, lane);
-    }
-    for (; item < count; item += step) {
-        const int b = cur.x / 3, layer = cur.x - b * 3;
-        const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
-        const int *qm = a.qm[layer];
-        float *sX = sXb + pb * SS;
-        if (NXB == 1) dct_load_x<S, NWAVES>(a.norm + (long long)b * g.pstride + lt.poff[layer], lt.w[layer], lt.h[layer], cur, sX, wave, lane);
-        __syncthreads();                  // X of this leaf has landed (the barrier drains the LDS-DMA queue)
-        if (NXB == 2 && item + step < count) {
-            // prefetch the next leaf into the other buffer: it lands under this leaf's first MFMA chain
-            const int bn = nxt.x / 3, ln = nxt.x - bn * 3;
-            dct_load_x<S, NWAVES>(a.norm + (long long)bn * g.pstride + lt.poff[ln], lt.w[ln], lt.h[ln], nxt, sXb + (pb ^ 1) * SS, wave, lane);
+    // leaf k of this workgroup is work item blockIdx.x + k * gridDim.x; chunk c = leaves [c * kDescChunk, (c + 1) * kDescChunk)
+    auto load_chunk = [&](long long c) {           // threads 0 .. kDescChunk - 1: one descriptor each, into s_desc[c & 1]
+        if (tid < kDescChunk) {
+            const long long it = (long long)blockIdx.x + (c * kDescChunk + tid) * step;
+            int4 d = make_int4(0, 0, 0, 0);
+            if (it < count) d = fetch_item(a, wstride, lt, s_pref, it);
+            s_desc[(c & 1) * kDescChunk + tid] = d;
         }
-        int4 nn = make_int4(0, 0, 0, 0);
-        if (item + 2 * step < count) nn = fetch_item_fwd(a, wstride, lt, s_pref, item + 2 * step, plane_hint);
-
+    };
+    load_chunk(0);
+    load_chunk(1);
+    __syncthreads();
+    long long k = 0;                               // index of the current leaf of this workgroup
+    // A leaf descriptor is the same in every lane: its fields are moved to scalar registers (readfirstlane) as soon as they are
+    // read from LDS, so that everything derived from them -- plane, layer, addresses, the layer's geometry (selected from the
+    // kernel arguments, not looked up in LDS) -- is scalar-ALU work.  Vector instructions of this wave compete for issue slots with
+    // the MFMAs of the other waves on the SIMD; measured, the ~150 vector instructions of address arithmetic per leaf cost
+    // 2 000 cycles there.
+    struct LeafU { int plane, x, y, coef; };
+    auto uniform = [](const int4 &d) {
+        return LeafU{ __builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z),
+                      __builtin_amdgcn_readfirstlane(d.w) };
+    };
+    auto plane_of = [&](const LeafU &d, int &b, int &layer, int &w, int &h, const float *&src) {
+        b = d.plane / 3;
+        layer = d.plane - 3 * b;
+        w = layer == 0 ? g.w[0] : layer == 1 ? g.w[1] : g.w[2];
+        h = layer == 0 ? g.h[0] : layer == 1 ? g.h[1] : g.h[2];
+        const long long poff = layer == 0 ? g.poff[0] : layer == 1 ? g.poff[1] : g.poff[2];
+        src = a.norm + (long long)b * g.pstride + poff;
+    };
+    LeafU cur = uniform(s_desc[0]), nxt = uniform(s_desc[1]);
+    int pb = 0;
+    XOffsets<S, NWAVES> xo;
+    xo.w = -1;
+    if (NXB == 2 && item < count) {
+        int b0, l0, w0, h0;
+        const float *src0;
+        plane_of(cur, b0, l0, w0, h0, src0);
+        dct_load_x<S, NWAVES>(src0, w0, h0, make_int4(cur.plane, cur.x, cur.y, cur.coef), sXb, wave, lane, xo);
+        wait_vmem_but<0>();
+    }
+    // quantisers of this lane's outputs (as floats: they are < 2^24), kept in registers while consecutive leaves belong to the same
+    // layer (the work lists are ordered by plane, so the layer changes a few hundred times per launch)
+    float qf[TPW][16];
+    int q_layer = -1;
+    bool q_slow = false;               // some quantiser of the layer is too large for the float32 quantiser (never for the codec's own tables)
+#ifdef AEJ_X_STAMPS
+    long long st_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (; item < count; item += step) {
+        AEJ_STAMP(7)
+#ifdef AEJ_X_STAMPS
+        st_acc[6] += 1;
+#endif
+        int b, layer, lw, lhh;
+        const float *src;
+        plane_of(cur, b, layer, lw, lhh, src);
+        const long long coff = layer == 0 ? q.coeff_off[0] : layer == 1 ? q.coeff_off[1] : q.coeff_off[2];
+        const long long out_base = (long long)b * q.coeff_stride + coff + cur.coef;
+        float *sX = sXb + pb * SS;
+        if (S == 128 || layer != q_layer) {   // wave-uniform (the 128 x 128 kernel has no registers to spare: it reloads per leaf)
+            // (selected without indexing the kernel-argument array: that would be a dependent kernarg load per leaf)
+            const int *qm = layer == 0 ? a.qm[0] : layer == 1 ? a.qm[1] : a.qm[2];
+            int qmax = 0;
+#pragma unroll
+            for (int t = 0; t < TPW; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int qi = qm[((wi0 + t * (NT / TPW)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * S + J0 + li];
+                    qmax = max(qmax, qi);
+                    qf[t][r] = (float)qi;
+                }
+            q_slow = __any(qmax > (1 << 22));
+            q_layer = layer;
+            if (S != 128) {                       // rare path: leave no load pending across the prefetch below
+#pragma unroll
+                for (int t = 0; t < TPW; t++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) asm volatile("" : "+v"(qf[t][r]));
+            }
+        }
+        if (NXB == 1) {
+            dct_load_x<S, NWAVES>(src, lw, lhh, make_int4(cur.plane, cur.x, cur.y, cur.coef), sX, wave, lane, xo);
+            wait_vmem_but<0>();
+        }
+        lds_barrier();                    // X of this leaf has landed: every wave waited for its own pieces before arriving
+        AEJ_STAMP(0)
+        if (NXB == 2 && item + step < count) {
+            // prefetch the next leaf into the other buffer: it lands under this leaf's MFMA chains
+            int bn, ln, wn, hn;
+            const float *srcn;
+            plane_of(nxt, bn, ln, wn, hn, srcn);
+            dct_load_x<S, NWAVES>(srcn, wn, hn, make_int4(nxt.plane, nxt.x, nxt.y, nxt.coef), sXb + (pb ^ 1) * SS, wave, lane, xo);
+        }
+        AEJ_STAMP(11)
+        // entering a chunk: the chunk before it is finished, its buffer takes the chunk after this one (needed 64 leaves from now)
+        if ((k & (kDescChunk - 1)) == 0 && k > 0) load_chunk(k / kDescChunk + 1);
+        AEJ_STAMP(1)
         floatx16 acc[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
         mfma_chain<S, TPW, kMfmaPF>(sX, (NT / TPW) * 32, wi0 * 32 + li, lh, dreg, acc);
+        AEJ_STAMP(2)
         // accumulator layout: row = (r & 3) + 8 * (r >> 2) + 4 * lh, col = li
 #pragma unroll
         for (int t = 0; t < TPW; t++)
@@ -435,34 +619,58 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
                 int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 sP[((wi0 + t * (NT / TPW)) * 32 + row) * S + J0 + li] = acc[t][r];
             }
-        __syncthreads();
+        lds_barrier();
+        AEJ_STAMP(3)
 
-        // quantisers of this lane's outputs: loaded here so that their latency hides under the second MFMA chain
-        int qv[TPW][16];
-#pragma unroll
-        for (int t = 0; t < TPW; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) qv[t][r] = qm[((wi0 + t * (NT / TPW)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * S + J0 + li];
 #pragma unroll
         for (int t = 0; t < TPW; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
         mfma_chain<S, TPW, kMfmaPF>(sP, (NT / TPW) * 32, wi0 * 32 + li, lh, dreg, acc);
+        AEJ_STAMP(4)
         int *sQ = reinterpret_cast<int *>(sX);   // every wave finished reading sX before the barrier above
+        // one range test per leaf for the float32 quantiser (|y| < 2^17 and q >= 1 give |y / q| < 2^18, its proven range)
+        float ymax = 0.f;
+#pragma unroll
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) ymax = __builtin_fmaxf(__builtin_fmaxf(ymax, __builtin_fabsf(acc[t][r])), __builtin_fabsf(acc[t][r + 1]));
+        const bool slow = q_slow || __any(!(ymax < 131072.0f));
+        // Most coefficients of a large leaf are far below q / 2: when that holds for the whole wave the result is 0 whatever the
+        // quotient's last bits are (0.499f leaves the float32 rounding of the product orders of magnitude of margin) and the
+        // quantiser is skipped -- per output register, because vector instructions of this wave only issue while no float32 MFMA
+        // of another wave occupies the SIMD (the float32 MFMA runs at exactly the vector rate), so instructions NOT executed
+        // are what counts: one vote for all sixteen registers followed by a branch-free quantiser was measured 8 % slower.
 #pragma unroll
         for (int t = 0; t < TPW; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int row = (wi0 + t * (NT / TPW)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (WANT_DCT) a.dct_f32[out_base + row * S + J0 + li] = acc[t][r];
-                sQ[zigzag_pos<S>(row, J0 + li)] = quantise_sparse(acc[t][r], qv[t][r]);
+                const float y = acc[t][r], qq = qf[t][r];
+                int v = 0;
+                if (!__all(__builtin_fabsf(y) < 0.499f * qq)) v = slow ? quantise_f64(y, (int)qq) : quantise_f32(y, qq);
+                sQ[zigzag_pos<S>(row, J0 + li)] = v;
             }
-        __syncthreads();
+        AEJ_STAMP(8)
+        lds_barrier();
+        AEJ_STAMP(9)
         for (int idx = tid * 4; idx < SS; idx += NTHREADS * 4)
             *reinterpret_cast<int4 *>(a.coeffs + out_base + idx) = *reinterpret_cast<const int4 *>(sQ + idx);
-        if (NXB == 1) __syncthreads();    // single buffer: the next leaf's DMA must not overwrite sQ before it is copied out
-        cur = nxt; nxt = nn; pb ^= (NXB - 1);
+        AEJ_STAMP(10)
+        if (NXB == 2) wait_vmem_but<NYOUNG>();   // all but this leaf's stores: in particular the next leaf's X has landed
+        else lds_barrier();               // single buffer: the next leaf's DMA must not overwrite sQ before every wave has read it
+        k++;
+        cur = nxt;
+        // the descriptor after next: written to LDS at least one barrier ago (chunk k / 64 + 1 is stored when leaf k's chunk starts)
+        nxt = uniform(s_desc[(k + 1) & (2 * kDescChunk - 1)]);
+        pb ^= (NXB - 1);
+        AEJ_STAMP(5)
     }
+#ifdef AEJ_X_STAMPS
+    if (tid == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 12; i++) g_stamps[S == 32 ? 0 : 1][blockIdx.x][i] = st_acc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,16 +698,32 @@ void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int
     hipLaunchKernelGGL(k_work_from_leaves, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, leaves, n, ilog2(bmin), plane, wp, work_count);
 }
 
+// The MFMA kernels are persistent (a workgroup walks the work list with a grid stride), so the grid must not exceed what is
+// resident at once -- a second, partly filled round of workgroups would run alone at the end (4096 workgroups on 3072 slots:
+// 67 % efficiency).  The residency comes from the occupancy query for the actual dynamic-LDS size.
 template <int S, bool WANT_DCT>
-static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, int blocks)
+static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
 {
-    size_t lds = (size_t)(S == 64 ? 3 : 2) * S * S * sizeof(float) + sizeof(LayerTab) + 8 + (size_t)(a.nplanes + 1) * sizeof(int);
+    size_t lds = (size_t)(MfmaCfg<S>::NXB + 1) * S * S * sizeof(float) + 2 * kDescChunk * sizeof(int4) + sizeof(LayerTab) + 8 +
+                 (size_t)(a.nplanes + 1) * sizeof(int);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dct_mfma<S, WANT_DCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(MfmaCfg<S>::NTHREADS), lds, st, g, q, a, max_items);
+    static size_t occ_lds = ~(size_t)0;
+    static int slots = 0;
+    if (lds != occ_lds) {
+        int per_cu = 0, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dct_mfma<S, WANT_DCT>, MfmaCfg<S>::NTHREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        slots = per_cu * cus;
+        occ_lds = lds;
+    }
+    const int blocks = (int)(max_items < slots ? (max_items < 1 ? 1 : max_items) : slots);
+    hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(MfmaCfg<S>::NTHREADS), lds, st, g, q, a, max_items,
+                       reinterpret_cast<const int4 *>(a.work));
 }
 
 int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
@@ -515,9 +739,9 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
 #define AEJ_SMALL(S, PER, HI)                                                                                              \
     if (wd) hipLaunchKernelGGL((k_dct_small<S, true>), dim3(cap(PER, HI)), dim3(256), pref, st, g, q, a, max_items);       \
     else hipLaunchKernelGGL((k_dct_small<S, false>), dim3(cap(PER, HI)), dim3(256), pref, st, g, q, a, max_items)
-#define AEJ_MFMA(S, HI)                                                                 \
-    if (wd) launch_mfma_t<S, true>(st, g, q, a, max_items, cap(1, HI));                  \
-    else launch_mfma_t<S, false>(st, g, q, a, max_items, cap(1, HI))
+#define AEJ_MFMA(S)                                                     \
+    if (wd) launch_mfma_t<S, true>(st, g, q, a, max_items);              \
+    else launch_mfma_t<S, false>(st, g, q, a, max_items)
     switch (size) {
     case 2: AEJ_SMALL(2, 128, 2048); break;
     case 4:
@@ -526,9 +750,9 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
         break;
     case 8: AEJ_SMALL(8, 32, 4096); break;
     case 16: AEJ_SMALL(16, 16, 4096); break;
-    case 32: AEJ_MFMA(32, 4096); break;
-    case 64: AEJ_MFMA(64, 768); break;
-    case 128: AEJ_MFMA(128, 256); break;
+    case 32: AEJ_MFMA(32); break;
+    case 64: AEJ_MFMA(64); break;
+    case 128: AEJ_MFMA(128); break;
     case 256:
         if (!a.scratch) return -1;   // callers reserve it whenever the settings allow this size
         if (wd) hipLaunchKernelGGL((k_dct_big<256, true>), dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a, max_items);
