@@ -50,6 +50,8 @@ SIGNATURES = {
     "aej_set_stream": (_I, [_P, _P]),
     "aej_set_hysteresis_speculation": (_I, [_P, _I]),
     "aej_get_hysteresis_stats": (_I, [_P, _P]),
+    "aej_set_graph_mode": (_I, [_P, _I]),
+    "aej_get_graph_stats": (_I, [_P, _P]),
     "aej_last_hysteresis_passes": (_I, [_P]),
     "aej_set_hysteresis_hint": (_I, [_P, _I, _I]),
     "aej_set_profiling": (_I, [_P, _I]),
@@ -165,6 +167,15 @@ class Context:
         buf = (ctypes.c_int64 * 4)()
         self.check(self.lib.aej_get_hysteresis_stats(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
         return {"calls": int(buf[0]), "speculative": int(buf[1]), "misses": int(buf[2]), "enqueued": int(buf[3])}
+
+    def set_graph_mode(self, mode):
+        """0 = never replay a captured hipGraph (default), 1 = automatic (small calls), 2 = whenever possible (include/aej.h)"""
+        self.check(self.lib.aej_set_graph_mode(self.handle, int(mode)))
+
+    def graph_stats(self):
+        buf = (ctypes.c_int64 * 3)()
+        self.check(self.lib.aej_get_graph_stats(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
+        return {"launches": int(buf[0]), "captures": int(buf[1]), "cached": int(buf[2])}
 
     def set_speculation(self, on):
         self.check(self.lib.aej_set_hysteresis_speculation(self.handle, 1 if on else 0))

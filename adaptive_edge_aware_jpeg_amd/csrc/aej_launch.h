@@ -45,6 +45,9 @@ void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass);
+void launch_hyst_finish(hipStream_t st, const Geom &g, const CannyBuffers &cb, int first_pass);   // one workgroup: passes first_pass .. fix-point
+constexpr long long kHystFinishTiles = 4096;   // problems of at most this many 64x64 tiles finish their hysteresis inside one launch
+void launch_zero(hipStream_t st, void *p16, size_t bytes_multiple_of_16);
 void launch_bits_to_edge(hipStream_t st, const Geom &g, const unsigned long long *strong, unsigned char *edge01);
 void launch_bits_to_map(hipStream_t st, const Geom &g, const unsigned long long *weak, const unsigned long long *strong, unsigned char *map);
 

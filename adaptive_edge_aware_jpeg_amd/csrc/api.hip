@@ -33,8 +33,22 @@ struct aej_ctx {
     int hyst_margin = 4;               // extra passes enqueued on top of the hint: shrinks to 2 while calls keep converging early, grows after a miss
     int hyst_streak = 0;               // consecutive calls that converged with at least 2 spare passes
     int hyst_enqueued = 0;             // passes enqueued speculatively by the current call (0 = verified path)
+    bool capturing = false;            // the stream is being captured into a hipGraph: kernel nodes only (zero-fill by kernel, no copies)
     bool hyst_speculate = true;        // aej_set_hysteresis_speculation: false = every whole-path call runs the verified loop
     long long n_encode_calls = 0, n_spec_calls = 0, n_spec_misses = 0;   // aej_get_hysteresis_stats
+    // launch-latency path (aej_set_graph_mode): the whole speculative launch sequence of one encode call captured in a hipGraph,
+    // keyed by everything its kernel arguments depend on, and replayed on a private stream
+    int graph_mode = 0;                // 0 off (default: measured slower than eager launches), 1 automatic (small batches only), 2 always when possible
+    hipStream_t gstream = nullptr;
+    hipEvent_t gevent = nullptr;
+    struct GraphEntry {
+        const void *rgb; void *coeffs, *leaves, *states, *counts, *dct, *ws;
+        int batch, H, W, in_u8, passes;
+        hipGraphExec_t exec;
+        unsigned long long last_use;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long long graph_clock = 0, n_graph_launches = 0, n_graph_captures = 0;
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;
     hipEvent_t ev[24] = {};
@@ -76,6 +90,12 @@ static void collect_marks(aej_ctx *ctx)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ev[i - 1], ctx->ev[i]) == hipSuccess && ctx->ev_stage[i] >= 0) ctx->stage_ms[ctx->ev_stage[i]] += ms;
     }
+}
+
+static void drop_graphs(aej_ctx *ctx)
+{
+    for (auto &e : ctx->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    ctx->graphs.clear();
 }
 
 // ---- constant tables ---------------------------------------------------------------------------------
@@ -306,6 +326,9 @@ extern "C" void aej_destroy(aej_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    drop_graphs(ctx);
+    if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
+    if (ctx->gevent) (void)hipEventDestroy(ctx->gevent);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int i = 0; i < 24; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -397,6 +420,7 @@ extern "C" int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, con
     }
     size_t oSw = put(sw, sizeof sw), oCw = put(cw, sizeof cw);
 
+    drop_graphs(ctx);                  // captured kernel arguments point into the old tables
     if (ctx->tables) { AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream)); AEJ_HIP_CHECK(hipFree(ctx->tables)); ctx->tables = nullptr; }
     AEJ_HIP_CHECK(hipMalloc(&ctx->tables, blob.size()));
     AEJ_HIP_CHECK(hipMemcpy(ctx->tables, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -436,12 +460,22 @@ static int ensure_canny_tables(aej_ctx *ctx)
 // Speculative mode (whole-path encode, after a first call): enqueue as many passes as the previous call needed plus a
 // margin WITHOUT reading anything back -- a pass whose work list is empty is a ~2 us no-op -- and let the caller verify
 // pass_count[n] == 0 together with its final synchronisation (finish_hysteresis).
+static bool hyst_small(const Geom &g) { return hyst_tiles_per_image(g) * g.B <= kHystFinishTiles; }
+
 static int run_hysteresis(aej_ctx *ctx, const Geom &g, CannyWs &w, bool speculate = false, int first_pass = 0)
 {
     hipStream_t st = ctx->stream;
     const int group = 8;
     int pass = first_pass;
     ctx->hyst_enqueued = 0;
+    if (first_pass == 0 && hyst_small(g)) {
+        // small problem: pass 0 over every tile, then one workgroup iterates to the fix-point inside a single launch
+        // (k_hyst_finish) -- nothing to speculate on, nothing to read back
+        launch_hyst_pass(st, g, w.cb, 0);
+        launch_hyst_finish(st, g, w.cb, 1);
+        ctx->last_hyst_passes = 2;
+        return 0;
+    }
     if (speculate && ctx->hyst_speculate && ctx->hyst_hint > 0 && first_pass == 0) {
         int n = ctx->hyst_hint + ctx->hyst_margin;
         if (n > kMaxHystPasses - group) n = kMaxHystPasses - group;
@@ -483,14 +517,16 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool specula
 
 static int clear_canny_ws(aej_ctx *ctx, const CannyWs &w)
 {
-    AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), ctx->stream));
+    if (ctx->capturing) launch_zero(ctx->stream, w.zero_begin, (size_t)(w.zero_end - w.zero_begin));       // both ends are 256-byte aligned (Carver)
+    else AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), ctx->stream));
     return 0;
 }
 
 static int run_quadtree(aej_ctx *ctx, const Geom &g, const QtGeom &q, QtWs &w, const unsigned long long *edge_bits)
 {
     hipStream_t st = ctx->stream;
-    AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));
+    if (ctx->capturing) launch_zero(st, w.zero_begin, (size_t)(w.zero_end - w.zero_begin));
+    else AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));
     w.qb.edge_bits = edge_bits;
     launch_qt_cells(st, g, q, edge_bits, w.qb);
     launch_qt_count(st, g, q, w.qb);
@@ -628,6 +664,152 @@ extern "C" int aej_encode_plan(aej_ctx *ctx, int batch, int H, int W, aej_plan *
     return 0;
 }
 
+// everything behind the hysteresis: quadtree, then one DCT launch per block size
+static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &w, int32_t *coeffs, float *dct_f32)
+{
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
+    mark(ctx, AEJ_STAGE_QUADTREE);
+    int k = 0;
+    for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
+        DctArgs a;
+        a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
+        a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
+        a.scratch = w.big;
+        a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
+        for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
+        if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k])) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
+        mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
+    }
+    AEJ_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the counters one call reads back: the quadtree's overflow flag and, when the hysteresis passes were enqueued speculatively,
+// their work-list sizes
+static int enqueue_readback(aej_ctx *ctx, EncodeWs &w, int n_spec)
+{
+    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qt.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (n_spec > 0) AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag + 1, w.canny.cb.pass_count, (size_t)(n_spec + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+// after the final synchronisation of a speculative call: did the edge map reach its fix-point within the n passes?  Updates the
+// hint / margin for the next call; returns true when the hysteresis has to be finished and quadtree + DCT redone.
+static bool speculation_missed(aej_ctx *ctx, int n)
+{
+    const int *pc = ctx->h_flag + 1;
+    ctx->n_spec_calls++;
+    if (pc[n] == 0) {                       // converged within the speculative passes: remember how many were needed
+        int used = n;
+        while (used > 1 && pc[used - 1] == 0) used--;
+        ctx->hyst_hint = used;
+        ctx->last_hyst_passes = used;
+        if (n - used >= 2) {
+            if (++ctx->hyst_streak >= 8 && ctx->hyst_margin > 2) { ctx->hyst_margin--; ctx->hyst_streak = 0; }
+        } else {
+            ctx->hyst_streak = 0;
+        }
+        return false;
+    }
+    ctx->hyst_streak = 0;
+    ctx->n_spec_misses++;
+    if (ctx->hyst_margin < 8) ctx->hyst_margin += 2;
+    return true;
+}
+
+constexpr long long kGraphAutoPixels = 8LL << 20;      // automatic graph mode: calls of at most 8 Mpx (launch latency matters there)
+constexpr size_t kMaxGraphs = 8;
+
+// Launch-latency path: the speculative sequence (about 25 launches for 4-64 blocks) as ONE hipGraphLaunch.  The graph is captured
+// on a private stream (the caller's may be the legacy null stream, which cannot be captured) ordered behind the caller's stream
+// by an event, and cached under every pointer / shape / pass count its kernel arguments contain.
+static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g, const QtGeom &q, EncodeWs &w, int32_t *coeffs, int32_t *leaves,
+                        uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, bool &used)
+{
+    used = false;
+    const bool small = hyst_small(g);               // hysteresis = pass 0 + one finishing launch, no pass count to guess (n = -1)
+    int n = small ? -1 : ctx->hyst_hint + ctx->hyst_margin;
+    if (n > kMaxHystPasses - 8) n = kMaxHystPasses - 8;
+    if (!ctx->gstream) {
+        AEJ_HIP_CHECK(hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking));
+        AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->gevent, hipEventDisableTiming));
+    }
+    aej_ctx::GraphEntry *hit = nullptr;
+    for (auto &e : ctx->graphs)
+        if (e.rgb == rgb && e.coeffs == coeffs && e.leaves == leaves && e.states == states && e.counts == counts && e.dct == dct_f32 && e.ws == workspace &&
+            e.batch == g.B && e.H == g.H && e.W == g.W && e.in_u8 == (int)in_u8 && e.passes == n) { hit = &e; break; }
+    hipStream_t user = ctx->stream;
+    if (!hit) {
+        // first sight of this combination of buffers: only remember it and let the caller run the ordinary path -- a caller that
+        // allocates fresh outputs for every call would otherwise pay a capture per call; the second sight captures
+        if (ctx->graphs.size() >= kMaxGraphs) {           // evict the least recently used
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->graphs.size(); i++) if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
+            if (ctx->graphs[lru].exec) (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
+            ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
+        }
+        ctx->graphs.push_back({ rgb, coeffs, leaves, states, counts, dct_f32, workspace, g.B, g.H, g.W, (int)in_u8, n, nullptr, ++ctx->graph_clock });
+        return 0;
+    }
+    if (!hit->exec) {
+        hipGraph_t graph = nullptr;
+        ctx->stream = ctx->gstream;                       // every enqueue below goes to the capturing stream
+        ctx->capturing = true;
+        hipError_t e = hipStreamBeginCapture(ctx->gstream, hipStreamCaptureModeThreadLocal);
+        int rc = e == hipSuccess ? 0 : hip_fail(ctx, e, "hipStreamBeginCapture", __FILE__, __LINE__);
+        if (!rc) rc = clear_canny_ws(ctx, w.canny);
+        if (!rc) rc = run_color_planes(ctx, rgb, in_u8, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs);
+        if (!rc) {
+            hipStream_t st = ctx->stream;
+            launch_clahe_pad_hist(st, g, w.canny.cb);
+            launch_clahe_lut(st, g, w.canny.cb);
+            launch_clahe_blur(st, g, w.canny.cb);
+            launch_thresholds(st, g, w.canny.cb);
+            launch_sobel_nms(st, g, w.canny.cb);
+            if (small) {
+                launch_hyst_pass(st, g, w.canny.cb, 0);
+                launch_hyst_finish(st, g, w.canny.cb, 1);
+            } else {
+                for (int i = 0; i < n; i++) launch_hyst_pass(st, g, w.canny.cb, i);
+            }
+            rc = enqueue_back(ctx, g, q, w, coeffs, dct_f32);
+        }
+        hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(ctx->gstream, &graph) : hipSuccess;
+        ctx->stream = user;
+        ctx->capturing = false;
+        if (rc || e2 != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            return rc ? rc : 0;                           // not captured: the caller runs the ordinary path
+        }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess || !exec) { (void)hipGetLastError(); return 0; }
+        hit->exec = exec;
+        ctx->n_graph_captures++;
+    }
+    hit->last_use = ++ctx->graph_clock;
+    AEJ_HIP_CHECK(hipEventRecord(ctx->gevent, user));     // inputs produced on the caller's stream are complete before the graph reads them
+    AEJ_HIP_CHECK(hipStreamWaitEvent(ctx->gstream, ctx->gevent, 0));
+    AEJ_HIP_CHECK(hipGraphLaunch(hit->exec, ctx->gstream));
+    // the counter read-back stays outside the graph (ordinary copies behind it on the same stream): a graph with memcpy / memset
+    // nodes faulted on its second replay ("write access to a read-only page") whenever other device-to-host copies had run in
+    // between -- the runtime appears to recycle the staging those nodes were captured with
+    ctx->stream = ctx->gstream;
+    const int rb = enqueue_readback(ctx, w, small ? 0 : n);
+    ctx->stream = user;
+    if (rb) return rb;
+    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->gstream));
+    ctx->n_graph_launches++;
+    ctx->hyst_enqueued = small ? 0 : n;
+    ctx->last_hyst_passes = small ? 2 : n;
+    used = true;
+    return 0;
+}
+
 static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
                              uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
 {
@@ -645,62 +827,37 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     hipStream_t st = ctx->stream;
     w.canny.cb.space_w = ctx->d_space_w;
     w.canny.cb.color_w = ctx->d_color_w;
-    ctx->n_ev = 0;
-    ctx->n_encode_calls++;
-    mark(ctx, -1);
-    if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
-    mark(ctx, AEJ_STAGE_CLEAR);
-
-    if ((rc = run_color_planes(ctx, rgb, in_u8, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs))) return rc;
-    mark(ctx, AEJ_STAGE_COLOR_PLANES);
-    if ((rc = run_canny_chain(ctx, g, w.canny, true))) return rc;
-
     w.qt.qb.leaves = leaves;
     w.qt.qb.states = states;
     w.qt.qb.counts = reinterpret_cast<long long *>(counts);
-    for (int attempt = 0;; attempt++) {
-        if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
-        mark(ctx, AEJ_STAGE_QUADTREE);
-        int k = 0;
-        for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
-            DctArgs a;
-            a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
-            a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
-            a.scratch = w.big;
-            a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
-            for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
-            if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k])) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
-            mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
-        }
-        AEJ_HIP_CHECK(hipGetLastError());
-        // one read-back for the whole call: the overflow flag and, when the hysteresis passes were enqueued speculatively,
-        // their work-list counters
-        const int n = ctx->hyst_enqueued;
-        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qt.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-        if (n > 0) AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag + 1, w.canny.cb.pass_count, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    ctx->n_ev = 0;
+    ctx->n_encode_calls++;
+
+    bool graphed = false;
+    const bool want_graph = ctx->graph_mode != 0 && !ctx->profiling && (hyst_small(g) || (ctx->hyst_speculate && ctx->hyst_hint > 0)) && planes_fast_ok(g) &&
+                            (ctx->graph_mode == 2 || (long long)batch * H * W <= kGraphAutoPixels);
+    if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, g, q, w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) return rc;
+    if (!graphed) {
+        mark(ctx, -1);
+        if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
+        mark(ctx, AEJ_STAGE_CLEAR);
+        if ((rc = run_color_planes(ctx, rgb, in_u8, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs))) return rc;
+        mark(ctx, AEJ_STAGE_COLOR_PLANES);
+        if ((rc = run_canny_chain(ctx, g, w.canny, true))) return rc;
+        if ((rc = enqueue_back(ctx, g, q, w, coeffs, dct_f32))) return rc;
+        // one read-back for the whole call
+        if ((rc = enqueue_readback(ctx, w, ctx->hyst_enqueued))) return rc;
+        AEJ_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
+    const int n = ctx->hyst_enqueued;
+    if (n > 0 && speculation_missed(ctx, n)) {
+        // rare: the edge map was not at its fix-point when the quadtree ran -- finish the hysteresis, redo what follows
+        if ((rc = run_hysteresis(ctx, g, w.canny, false, n))) return rc;
+        if ((rc = enqueue_back(ctx, g, q, w, coeffs, dct_f32))) return rc;
+        if ((rc = enqueue_readback(ctx, w, 0))) return rc;
         AEJ_HIP_CHECK(hipStreamSynchronize(st));
         if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
-        if (n == 0) break;
-        const int *pc = ctx->h_flag + 1;
-        if (attempt == 0) ctx->n_spec_calls++;
-        if (pc[n] == 0) {                       // converged within the speculative passes: remember how many were needed
-            int used = n;
-            while (used > 1 && pc[used - 1] == 0) used--;
-            ctx->hyst_hint = used;
-            ctx->last_hyst_passes = used;
-            if (n - used >= 2) {
-                if (++ctx->hyst_streak >= 8 && ctx->hyst_margin > 2) { ctx->hyst_margin--; ctx->hyst_streak = 0; }
-            } else {
-                ctx->hyst_streak = 0;
-            }
-            break;
-        }
-        ctx->hyst_streak = 0;
-        ctx->n_spec_misses++;
-        if (ctx->hyst_margin < 8) ctx->hyst_margin += 2;
-        // rare: the edge map was not at its fix-point when the quadtree ran -- finish the hysteresis, redo what follows
-        if (attempt > 0) return fail(ctx, AEJ_ERR_STATE, "hysteresis verification failed twice");
-        if ((rc = run_hysteresis(ctx, g, w.canny, false, n))) return rc;
     }
     if (ctx->profiling) collect_marks(ctx);
     return 0;
@@ -1129,6 +1286,23 @@ extern "C" int aej_get_hysteresis_stats(aej_ctx *ctx, int64_t *out_host)
     out_host[1] = ctx->n_spec_calls;
     out_host[2] = ctx->n_spec_misses;
     out_host[3] = ctx->hyst_enqueued;
+    return 0;
+}
+
+extern "C" int aej_set_graph_mode(aej_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return AEJ_ERR_ARG;
+    ctx->graph_mode = mode;
+    if (mode == 0) drop_graphs(ctx);
+    return 0;
+}
+
+extern "C" int aej_get_graph_stats(aej_ctx *ctx, int64_t *out_host)
+{
+    if (!ctx || !out_host) return AEJ_ERR_ARG;
+    out_host[0] = (int64_t)ctx->n_graph_launches;
+    out_host[1] = (int64_t)ctx->n_graph_captures;
+    out_host[2] = (int64_t)ctx->graphs.size();
     return 0;
 }
 

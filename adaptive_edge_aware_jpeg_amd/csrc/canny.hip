@@ -146,7 +146,8 @@ constexpr int kBAH = kBTH + 6;            // CLAHE rows  [y0-3, y0+TH+3)
 constexpr int kBGH = kBTH + 4;            // Gauss rows  [y0-2, y0+TH+2)
 constexpr int kBGW = kBAW + 4;            // Gaussian row stride in dwords; staged column c is stored at c + 2, so that the 8-dword window of
                                           // a bilateral thread (columns 4 c4 + 2 .. 4 c4 + 9) is two ALIGNED 16-byte reads (conflict-free)
-constexpr int kBStrip = 8;                // tiles of one tile-row handled by one workgroup (tables / histogram stay in LDS)
+constexpr int kBStripMax = 8;             // tiles of one tile-row handled by one workgroup (tables / histogram stay in LDS); fewer when
+                                          // the batch is small, so that a single image still spreads over the whole chip
 constexpr int kASlots = kBT / kBAW4;      // 15 row slots: thread t owns column dword t % 34 and rows t / 34 + 15 k
 constexpr int kAIter = (kBAH + kASlots - 1) / kASlots;   // 5
 constexpr int kBRows = 5;                 // Gaussian output rows per thread: rows 5 * (t / 34) .. + 4
@@ -228,10 +229,10 @@ __device__ __forceinline__ void blur_prefetch(const unsigned char *src, int w, i
     }
 }
 
-__device__ __forceinline__ bool locate_blur_strip(const Geom &g, int t, int &layer, int &sx, int &ty)
+__device__ __forceinline__ bool locate_blur_strip(const Geom &g, int strip, int t, int &layer, int &sx, int &ty)
 {
     for (int l = 0; l < g.nl; l++) {
-        int ntx = cdiv(g.w[l], kBTW), nty = cdiv(g.h[l], kBTH), nsx = cdiv(ntx, kBStrip);
+        int ntx = cdiv(g.w[l], kBTW), nty = cdiv(g.h[l], kBTH), nsx = cdiv(ntx, strip);
         int n = nsx * nty;
         if (t < n) { layer = l; ty = t / nsx; sx = t - ty * nsx; return true; }
         t -= n;
@@ -239,7 +240,7 @@ __device__ __forceinline__ bool locate_blur_strip(const Geom &g, int t, int &lay
     return false;
 }
 
-__global__ __launch_bounds__(kBT, 4) void k_clahe_blur(Geom g, CannyBuffers cb)
+__global__ __launch_bounds__(kBT, 4) void k_clahe_blur(Geom g, CannyBuffers cb, int strip)
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;
@@ -247,11 +248,11 @@ __global__ __launch_bounds__(kBT, 4) void k_clahe_blur(Geom g, CannyBuffers cb)
     const int strips = gridDim.x / g.B;
     const int b = (int)(wg / strips);
     int l, sx, ty;
-    if (!locate_blur_strip(g, (int)(wg - (long long)b * strips), l, sx, ty)) return;
+    if (!locate_blur_strip(g, strip, (int)(wg - (long long)b * strips), l, sx, ty)) return;
     const int w = g.w[l], h = g.h[l];
     const int ntx = cdiv(w, kBTW);
     const int y0 = ty * kBTH;
-    const int tx_begin = sx * kBStrip, tx_end = min(ntx, tx_begin + kBStrip);
+    const int tx_begin = sx * strip, tx_end = min(ntx, tx_begin + strip);
     const long long pbase = (long long)b * g.pstride + g.poff[l];
     const unsigned char *src = cb.u8a + pbase;
     const unsigned char *glut = cb.lut + ((long long)b * 3 + l) * 4096;     // [ty][tx][256]
@@ -659,12 +660,12 @@ __global__ __launch_bounds__(256) void k_thresholds(Geom g, const int *__restric
 // loads in flight; stage 1 computes gradient + magnitude for 4 pixels per item with SWAR [1 2 1] sums;
 // stage 2 does the NMS test with one wave per 64-pixel row segment so that the output words are wave ballots.
 // ------------------------------------------------------------------------------------------------
-constexpr int kStrip = 8;    // tiles of one tile-row handled by one workgroup
+constexpr int kStripMax = 8;    // tiles of one tile-row handled by one workgroup (fewer for small batches, see launch_sobel_nms)
 
-__device__ __forceinline__ bool locate_strip(const Geom &g, int t, int &layer, int &sx, int &ty)
+__device__ __forceinline__ bool locate_strip(const Geom &g, int strip, int t, int &layer, int &sx, int &ty)
 {
     for (int l = 0; l < g.nl; l++) {
-        int ntx = cdiv(g.w[l], kBlurTW), nty = cdiv(g.h[l], kBlurTH), nsx = cdiv(ntx, kStrip);
+        int ntx = cdiv(g.w[l], kBlurTW), nty = cdiv(g.h[l], kBlurTH), nsx = cdiv(ntx, strip);
         int n = nsx * nty;
         if (t < n) { layer = l; ty = t / nsx; sx = t - ty * nsx; return true; }
         t -= n;
@@ -698,7 +699,7 @@ __device__ __forceinline__ void nms_prefetch(const unsigned char *src, int w, in
 
 // workgroup = strip of kStrip tiles of one tile-row; the blurred bytes of the next tile are prefetched into registers while
 // the current tile is processed
-__global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
+__global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int strip)
 {
     __shared__ NmsLds L;
     const int tid = threadIdx.x;
@@ -706,11 +707,11 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb)
     const int strips = gridDim.x / g.B;
     const int b = (int)(wg / strips);
     int l, sx, ty;
-    if (!locate_strip(g, (int)(wg - (long long)b * strips), l, sx, ty)) return;
+    if (!locate_strip(g, strip, (int)(wg - (long long)b * strips), l, sx, ty)) return;
     const int w = g.w[l], h = g.h[l];
     const int ntx = cdiv(w, kBlurTW);
     const int y0 = ty * kBlurTH;
-    const int tx_begin = sx * kStrip, tx_end = min(ntx, tx_begin + kStrip);
+    const int tx_begin = sx * strip, tx_end = min(ntx, tx_begin + strip);
     const long long pbase = (long long)b * g.pstride + g.poff[l];
     const unsigned char *src = cb.u8b + pbase;
     const int low = cb.thr[((long long)b * 3 + l) * 2], high = cb.thr[((long long)b * 3 + l) * 2 + 1];
@@ -861,13 +862,14 @@ __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed,
 // writes have been acknowledged, see the s_waitcnt below).
 constexpr int kChaseDepth = 32;
 
-template <bool CHASE>
-__global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int pass, long long tiles_per_img, long long total_tiles)
+// One pass over the work list of `pass` by the waves [wave, wave + nwaves, ...).  FUSED = several passes run inside one launch
+// (k_hyst_finish): the list written by the previous pass of the same launch is then read with agent-scope loads, because a
+// CU's vector L1 is not refreshed by other waves' stores (between launches the kernel boundary does that).
+template <bool CHASE, bool FUSED>
+__device__ __forceinline__ void hyst_pass_body(const Geom &g, const CannyBuffers &cb, int pass, long long tiles_per_img, long long total_tiles,
+                                               long long wave, long long nwaves, long long n)
 {
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * 4;
-    const long long n = pass == 0 ? total_tiles : (long long)cb.pass_count[pass];
     int *flags_cur = cb.hflags + (long long)(pass & 1) * total_tiles;
     int *flags_nxt = cb.hflags + (long long)((pass + 1) & 1) * total_tiles;
     const int *list_cur = cb.hlist + (long long)(pass & 1) * total_tiles;
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
     };
 
     for (long long item = wave; item < n; item += nwaves) {
-        long long T = pass == 0 ? item : (long long)list_cur[item];
+        long long T = pass == 0 ? item : (long long)(FUSED ? __hip_atomic_load(&list_cur[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list_cur[item]);
         if (lane == 0) flags_cur[T] = 0;
         for (int depth = 0;; depth++) {
             const int b = (int)(T / tiles_per_img);
@@ -970,6 +972,29 @@ __global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int 
     }
 }
 
+template <bool CHASE>
+__global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int pass, long long tiles_per_img, long long total_tiles)
+{
+    const long long n = pass == 0 ? total_tiles : (long long)cb.pass_count[pass];
+    hyst_pass_body<CHASE, false>(g, cb, pass, tiles_per_img, total_tiles, (long long)blockIdx.x * 4 + (threadIdx.x >> 6), (long long)gridDim.x * 4, n);
+}
+
+// Small problems (a single image, a few images): after pass 0, ONE workgroup of 16 waves runs every further pass to the fix-point
+// inside one launch -- the work lists of passes >= 1 hold tens to hundreds of tiles, so a launch per pass is pure launch latency
+// (8 launches x 10 us for one 1080p image), and because the kernel itself iterates until a pass queues nothing, the caller needs
+// neither a speculative pass count nor a read-back.  Every wave reaches every barrier (the loop bound is wave-uniform).
+constexpr int kFinishThreads = 1024;
+__global__ __launch_bounds__(kFinishThreads) void k_hyst_finish(Geom g, CannyBuffers cb, int first_pass, long long tiles_per_img, long long total_tiles)
+{
+    for (int pass = first_pass; pass < kMaxHystPasses; pass++) {
+        const long long n = (long long)__hip_atomic_load(&cb.pass_count[pass], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == 0) break;
+        hyst_pass_body<true, true>(g, cb, pass, tiles_per_img, total_tiles, (long long)(threadIdx.x >> 6), kFinishThreads / 64, n);
+        __syncthreads();               // s_waitcnt vmcnt(0) + barrier: this pass's stores and atomics have been performed at the L2
+        // (the pass bound cannot be reached in practice; if it were, the last counter stays non-zero and the host reports it)
+    }
+}
+
 // bit-plane -> uint8 expansions (stand-alone EdgeDetection.canny output and the stage dump for the tests)
 __global__ __launch_bounds__(256) void k_bits_to_edge(Geom g, const unsigned long long *__restrict__ strong, unsigned char *__restrict__ edge)
 {
@@ -1019,6 +1044,22 @@ __global__ __launch_bounds__(256) void k_pack_edge_bits(Geom g, const unsigned c
     }
 }
 
+// zero-fill as a kernel: the graph-replay path of aej_encode_batch holds kernel nodes only (the runtime's memset / memcpy
+// graph nodes proved unsafe to replay once other copies had run in between, see api.hip encode_graph)
+__global__ __launch_bounds__(256) void k_zero16(uint4 *__restrict__ p, long long n16)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+void launch_zero(hipStream_t st, void *p, size_t bytes)      // p 16-byte aligned, bytes a multiple of 16
+{
+    const long long n16 = (long long)(bytes / 16);
+    if (n16 <= 0) return;
+    long long blocks = (n16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_zero16, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint4 *>(p), n16);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1044,14 +1085,27 @@ void launch_clahe_lut(hipStream_t st, const Geom &g, const CannyBuffers &cb)
     hipLaunchKernelGGL(k_clahe_lut, dim3(16, g.nl, g.B), dim3(256), 0, st, g, cb.tile_hist, cb.lut);
 }
 
-void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
+// strips per image for a strip length; the longest strip that still gives every CU a few workgroups is used
+static long long strips_per_image(const Geom &g, int TW, int TH, int strip)
 {
     long long t = 0;
     for (int l = 0; l < g.nl; l++) {
-        int ntx = (g.w[l] + kBTW - 1) / kBTW, nty = (g.h[l] + kBTH - 1) / kBTH;
-        t += (long long)((ntx + kBStrip - 1) / kBStrip) * nty;
+        int ntx = (g.w[l] + TW - 1) / TW, nty = (g.h[l] + TH - 1) / TH;
+        t += (long long)((ntx + strip - 1) / strip) * nty;
     }
-    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(t * g.B)), dim3(kBT), 0, st, g, cb);
+    return t;
+}
+static int pick_strip(const Geom &g, int TW, int TH, int strip_max, long long want_workgroups)
+{
+    int strip = strip_max;
+    while (strip > 1 && strips_per_image(g, TW, TH, strip) * g.B < want_workgroups) strip >>= 1;
+    return strip;
+}
+
+void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
+{
+    const int strip = pick_strip(g, kBTW, kBTH, kBStripMax, 1024);       // 256 CUs x 2 resident workgroups x 2
+    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), 0, st, g, cb, strip);
 }
 
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
@@ -1061,12 +1115,14 @@ void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
-    long long t = 0;
-    for (int l = 0; l < g.nl; l++) {
-        int ntx = (g.w[l] + kBlurTW - 1) / kBlurTW, nty = (g.h[l] + kBlurTH - 1) / kBlurTH;
-        t += (long long)((ntx + kStrip - 1) / kStrip) * nty;
-    }
-    hipLaunchKernelGGL(k_sobel_nms, dim3((unsigned)(t * g.B)), dim3(256), 0, st, g, cb);
+    const int strip = pick_strip(g, kBlurTW, kBlurTH, kStripMax, 2048);
+    hipLaunchKernelGGL(k_sobel_nms, dim3((unsigned)(strips_per_image(g, kBlurTW, kBlurTH, strip) * g.B)), dim3(256), 0, st, g, cb, strip);
+}
+
+void launch_hyst_finish(hipStream_t st, const Geom &g, const CannyBuffers &cb, int first_pass)
+{
+    long long t = hyst_tiles_per_image(g);
+    hipLaunchKernelGGL(k_hyst_finish, dim3(1), dim3(kFinishThreads), 0, st, g, cb, first_pass, t, t * g.B);
 }
 
 void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass)

@@ -106,6 +106,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle comparison")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for cpu_baseline; 0 = min(available cores, 16)")
+    ap.add_argument("--graph", type=int, choices=[0, 1, 2], default=0,
+                    help="aej_set_graph_mode: 0 never replay a captured hipGraph (the library default), 1 automatic (calls of at most 8 Mpx), 2 whenever possible")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiler runs (tools/profiling/*.sh): only the W warm-up and K timed steps, so every kernel is launched a known "
                          "number of times; prints value / ms_per_step only")
@@ -226,6 +228,7 @@ def main():
 
     jpeg = A.Jpeg(A.JpegCompressionSettings(space, qrange, brange), device=local_rank)
     ctx = jpeg._bind()
+    ctx.set_graph_mode(args.graph)
     plan = ctx.plan(B, H, W)
     coeffs = ctx.empty((B * plan.coeff_stride,), torch.int32)
     leaves = ctx.empty((B * plan.leaf_stride, 4), torch.int32)
@@ -376,6 +379,7 @@ def main():
                        "misses": h1["misses"] - h0["misses"], "passes_enqueued_last_call": h1["enqueued"],
                        "passes_needed_last_call": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle))},
         "verified_mode_ms_per_step": round(dt_v / args.steps * 1e3, 3),
+        "graph": dict(ctx.graph_stats(), mode=args.graph),
         "whole_path": {"bytes_per_px": whole_bpp, "achieved_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4)},
         "stages": per_stage,
         "stage_ms_source": f"{n_prof} separate profiled steps after the timed region (sum {sum(stage_ms.values()):.3f} ms)",

@@ -96,7 +96,7 @@ def test_speculation_on_off_and_stats(env, oracle):
     """The speculative hysteresis enqueue and the verified loop give the same bytes; the miss counter counts."""
     torch, A, bench = env
     from adaptive_edge_aware_jpeg_amd._lib import get_context
-    B, H, W = 2, 1080, 1920
+    B, H, W = 6, 1080, 1920                              # > kHystFinishTiles 64x64 tiles: the per-pass (speculative) hysteresis, not the one-launch finish
     dev = torch.device("cuda", 0)
     x1 = bench.synth_batch(torch, B, H, W, 1, dev)
     codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
@@ -163,3 +163,43 @@ def test_xyz_helper_space_and_float64_input(env, oracle):
         A.convert("XYZ", "YCbCr", x)
     with pytest.raises(ValueError):
         A.JpegCompressionSettings("XYZ")                                          # not a codec space (jpeg.py:164-165)
+
+
+def test_graph_replay_path_matches_oracle(env, oracle):
+    """Launch-latency path (BASELINE config 2, one 1920x1080 image): from the third call with the same buffers on, the whole launch
+    sequence is one captured hipGraph; its outputs are the oracle's, also when the input changes between replays and when the
+    speculative pass count is too small (miss -> eager completion)."""
+    torch, A, bench = env
+    from adaptive_edge_aware_jpeg_amd._lib import get_context
+    dev = torch.device("cuda", 0)
+    space, qr, br = "YCbCr", (40, 80), (4, 64)
+    H, W = 1080, 1920
+    xs = [bench.synth_batch(torch, 1, H, W, seed, dev) for seed in (20250718, 99)]
+    refs = [oracle.encode_image(x[0].cpu().numpy(), space, qr, br) for x in xs]
+    codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
+    ctx = codec._bind()
+    ctx.set_graph_mode(2)
+    try:
+        plan = ctx.plan(1, H, W)
+        out = (ctx.empty((plan.coeff_stride,), torch.int32), ctx.empty((plan.leaf_stride, 4), torch.int32),
+               ctx.empty((plan.state_stride,), torch.uint8), ctx.empty((1, 3, 4), torch.int64))
+        x = xs[0].clone()
+        g0 = ctx.graph_stats()
+        from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+        for it in range(6):
+            which = it & 1
+            x.copy_(xs[which])                          # same input buffer, new contents: the graph must pick them up
+            codec.encode_into(ctx, x, plan, *out)
+            check_image(EncodedBatch(plan, *out), 0, refs[which], f"graph call {it}")
+        g1 = ctx.graph_stats()
+        assert g1["captures"] - g0["captures"] == 1 and g1["launches"] - g0["launches"] >= 3, (g0, g1)
+        # a replay whose pass count is too small: the miss is detected and repaired eagerly
+        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
+        s0 = ctx.hysteresis_stats()
+        for it in range(3):                              # 1st: remembered, 2nd: captured + replayed, 3rd: replayed
+            ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
+            codec.encode_into(ctx, x, plan, *out)
+            check_image(EncodedBatch(plan, *out), 0, refs[1], f"graph miss call {it}")
+        assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 3
+    finally:
+        ctx.set_graph_mode(0)
