@@ -41,6 +41,12 @@ _lib_lock = threading.Lock()
 
 # name -> (restype, argtypes); exactly the symbols declared in include/aej.h
 _P, _I, _I64, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
+class CannyParams(ctypes.Structure):
+    """aej_canny_params (include/aej.h)"""
+    _fields_ = [("canny_low_ratio", ctypes.c_double), ("canny_high_ratio", ctypes.c_double), ("clahe_clip_limit", ctypes.c_double),
+                ("bilateral_sigma_color", ctypes.c_double), ("bilateral_sigma_space", ctypes.c_double), ("use_l2_gradient", ctypes.c_int)]
+
+
 SIGNATURES = {
     "aej_abi_version": (_I, []),
     "aej_create": (_P, [_I, _P]),
@@ -67,6 +73,7 @@ SIGNATURES = {
     "aej_color_planes": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "aej_canny_workspace_bytes": (_U64, [_I, _I]),
     "aej_canny": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _U64]),
+    "aej_set_canny_params": (_I, [_P, _P]),
     "aej_quadtree_workspace_bytes": (_U64, [_I, _I, _I, _I]),
     "aej_quadtree_capacity": (_I, [_I, _I, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "aej_quadtree": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _U64]),
@@ -167,6 +174,15 @@ class Context:
         buf = (ctypes.c_int64 * 4)()
         self.check(self.lib.aej_get_hysteresis_stats(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
         return {"calls": int(buf[0]), "speculative": int(buf[1]), "misses": int(buf[2]), "enqueued": int(buf[3])}
+
+    def set_canny_params(self, params=None):
+        """aej_set_canny_params: (low_ratio, high_ratio, clip_limit, sigma_color, sigma_space, use_l2) or None for the defaults"""
+        if params is None:
+            self.check(self.lib.aej_set_canny_params(self.handle, None))
+            return
+        lo, hi, clip, sc, ss, l2 = params
+        v = CannyParams(float(lo), float(hi), float(clip), float(sc), float(ss), 1 if l2 else 0)
+        self.check(self.lib.aej_set_canny_params(self.handle, ctypes.cast(ctypes.pointer(v), ctypes.c_void_p)))
 
     def set_graph_mode(self, mode):
         """0 = never replay a captured hipGraph (default), 1 = automatic (small calls), 2 = whenever possible (include/aej.h)"""

@@ -34,6 +34,10 @@ struct CannyBuffers {
     int *pass_count;        // [kMaxHystPasses + 1] tiles queued for pass p (pass 0 = every tile)
     const float *space_w;   // [13]
     const float *color_w;   // [256]
+    // run-time hyper-parameters of EdgeDetection.canny (edge_detection.py:31-40; aej_set_canny_params)
+    double low_q = 0.10 * 100, high_q = 0.30 * 100;     // np.percentile arguments
+    double clip_limit = 0.75;                           // CLAHE clipLimit (<= 0: no clipping)
+    int l2 = 1;                                         // cv.Canny L2gradient
     // optional stage dumps (stand-alone entry point only)
     unsigned char *dump_clahe, *dump_gauss;
 };
@@ -106,7 +110,7 @@ struct IdctArgs {
 };
 void launch_work_from_tables(hipStream_t st, const Geom &g, const QtGeom &q, const int *leaves, const long long *counts, LeafWork *const *work,
                              int *work_count, int *bad /* [1], zeroed by the caller: set when the tables do not fit the plan */);
-void launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const IdctArgs &a, long long max_items);
+int launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const IdctArgs &a, long long max_items);
 int launch_color_inverse(hipStream_t st, int space, const float *in, float *out, long long n);
 int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float *planes, float *rgb);
 

@@ -27,6 +27,8 @@ struct aej_ctx {
     const int *d_zz[kMaxSizes] = {};
     const int *d_qm[3][kMaxSizes] = {};
     const float *d_space_w = nullptr, *d_color_w = nullptr;
+    float *d_bilateral = nullptr;      // [16 + 256] space / colour weights of the bilateral filter (own allocation: aej_set_canny_params rebuilds it)
+    aej_canny_params canny = { 0.10, 0.30, 0.75, 75.0, 75.0, 1 };     // edge_detection.py:31-40 defaults
     int *h_flag = nullptr;             // pinned host word for counter read-backs
     int last_hyst_passes = 0;
     int hyst_hint = 0;                 // passes the previous encode needed (speculative enqueue, verified at the end of the call)
@@ -330,6 +332,7 @@ extern "C" void aej_destroy(aej_ctx *ctx)
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
     if (ctx->gevent) (void)hipEventDestroy(ctx->gevent);
     if (ctx->tables) (void)hipFree(ctx->tables);
+    if (ctx->d_bilateral) (void)hipFree(ctx->d_bilateral);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int i = 0; i < 24; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
@@ -405,21 +408,6 @@ extern "C" int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, con
             qpos += (size_t)s * s;
         }
     }
-    // bilateralFilter(d=5, sigmaColor=75, sigmaSpace=75) weights (edge_detection.py:37-39,78; OpenCV bilateral_filter)
-    float sw[16] = { 0 }, cw[256];
-    {
-        double cc = -0.5 / (75.0 * 75.0), sc = -0.5 / (75.0 * 75.0);
-        for (int i = 0; i < 256; i++) cw[i] = (float)exp((double)i * (double)i * cc);
-        int t = 0;
-        for (int i = -2; i <= 2; i++)
-            for (int j = -2; j <= 2; j++) {
-                double r = sqrt((double)i * i + (double)j * j);
-                if (r > 2.0) continue;
-                sw[t++] = (float)exp(r * r * sc);
-            }
-    }
-    size_t oSw = put(sw, sizeof sw), oCw = put(cw, sizeof cw);
-
     drop_graphs(ctx);                  // captured kernel arguments point into the old tables
     if (ctx->tables) { AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream)); AEJ_HIP_CHECK(hipFree(ctx->tables)); ctx->tables = nullptr; }
     AEJ_HIP_CHECK(hipMalloc(&ctx->tables, blob.size()));
@@ -435,24 +423,61 @@ extern "C" int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, con
         ctx->d_zz[i] = reinterpret_cast<const int *>(base + oZf[i]);
         for (int l = 0; l < 3; l++) ctx->d_qm[l][i] = reinterpret_cast<const int *>(base + oQ[l][i]);
     }
-    ctx->d_space_w = reinterpret_cast<const float *>(base + oSw);
-    ctx->d_color_w = reinterpret_cast<const float *>(base + oCw);
     ctx->space = space; ctx->bmin = bmin; ctx->bmax = bmax; ctx->nsizes = nsizes;
     ctx->has_settings = true;
     return 0;
 }
 
-// the bilateral tables are needed by aej_canny even without codec settings
+// bilateralFilter(d = 5, sigmaColor, sigmaSpace) weights (edge_detection.py:37-39,78; OpenCV bilateral_filter): (float)exp(double)
+// tables built on the host, once per parameter set
 static int ensure_canny_tables(aej_ctx *ctx)
 {
     if (ctx->d_color_w) return 0;
-    // default settings of the reference (jpeg.py:150-155) with unit quantisation matrices
-    std::vector<int32_t> q;
-    for (int l = 0; l < 3; l++)
-        for (int s = 4; s <= 64; s *= 2) q.insert(q.end(), (size_t)s * s, 1);
-    int rc = aej_set_settings(ctx, AEJ_YCOCG, 4, 64, q.data());
-    ctx->has_settings = false;
-    return rc;
+    float tab[16 + 256] = { 0 };
+    double sigc = ctx->canny.bilateral_sigma_color, sigs = ctx->canny.bilateral_sigma_space;
+    if (sigc <= 0) sigc = 1;
+    if (sigs <= 0) sigs = 1;
+    const double cc = -0.5 / (sigc * sigc), sc = -0.5 / (sigs * sigs);
+    for (int i = 0; i < 256; i++) tab[16 + i] = (float)exp((double)i * (double)i * cc);
+    int t = 0;
+    for (int i = -2; i <= 2; i++)
+        for (int j = -2; j <= 2; j++) {
+            double r = sqrt((double)i * i + (double)j * j);
+            if (r > 2.0) continue;
+            tab[t++] = (float)exp(r * r * sc);
+        }
+    if (!ctx->d_bilateral) AEJ_HIP_CHECK(hipMalloc(&ctx->d_bilateral, sizeof tab));
+    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    AEJ_HIP_CHECK(hipMemcpy(ctx->d_bilateral, tab, sizeof tab, hipMemcpyHostToDevice));
+    ctx->d_space_w = ctx->d_bilateral;
+    ctx->d_color_w = ctx->d_bilateral + 16;
+    return 0;
+}
+
+static void apply_canny_params(const aej_ctx *ctx, CannyBuffers &cb)
+{
+    cb.space_w = ctx->d_space_w;
+    cb.color_w = ctx->d_color_w;
+    cb.low_q = ctx->canny.canny_low_ratio * 100;       // `canny_low_ratio * 100`, edge_detection.py:81-82
+    cb.high_q = ctx->canny.canny_high_ratio * 100;
+    cb.clip_limit = ctx->canny.clahe_clip_limit;
+    cb.l2 = ctx->canny.use_l2_gradient ? 1 : 0;
+}
+
+extern "C" int aej_set_canny_params(aej_ctx *ctx, const aej_canny_params *p)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    const aej_canny_params def = { 0.10, 0.30, 0.75, 75.0, 75.0, 1 };
+    const aej_canny_params v = p ? *p : def;
+    if (!(v.canny_low_ratio >= 0.0 && v.canny_low_ratio <= 1.0 && v.canny_high_ratio >= 0.0 && v.canny_high_ratio <= 1.0))
+        return fail(ctx, AEJ_ERR_ARG, "Canny threshold ratios must lie in [0, 1] (np.percentile takes 0..100)");
+    if (!(v.clahe_clip_limit == v.clahe_clip_limit) || !(v.bilateral_sigma_color == v.bilateral_sigma_color) || !(v.bilateral_sigma_space == v.bilateral_sigma_space))
+        return fail(ctx, AEJ_ERR_ARG, "NaN Canny hyper-parameter");
+    const bool tables_change = v.bilateral_sigma_color != ctx->canny.bilateral_sigma_color || v.bilateral_sigma_space != ctx->canny.bilateral_sigma_space;
+    ctx->canny = v;
+    drop_graphs(ctx);                      // captured kernel arguments carry the old values
+    if (tables_change) { ctx->d_color_w = nullptr; ctx->d_space_w = nullptr; }
+    return 0;
 }
 
 // ---- Canny chain on a prepared uint8 buffer (cb.u8a) ------------------------------------------------------
@@ -825,8 +850,8 @@ static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     carve_encode(workspace, g, q, w);
     if (w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", w.bytes, (unsigned long long)workspace_bytes);
     hipStream_t st = ctx->stream;
-    w.canny.cb.space_w = ctx->d_space_w;
-    w.canny.cb.color_w = ctx->d_color_w;
+    if ((rc = ensure_canny_tables(ctx))) return rc;
+    apply_canny_params(ctx, w.canny.cb);
     w.qt.qb.leaves = leaves;
     w.qt.qb.states = states;
     w.qt.qb.counts = reinterpret_cast<long long *>(counts);
@@ -930,8 +955,7 @@ extern "C" int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t
     Carver c(workspace);
     CannyWs w;
     carve_canny(c, g, w);
-    w.cb.space_w = ctx->d_space_w;
-    w.cb.color_w = ctx->d_color_w;
+    apply_canny_params(ctx, w.cb);
     long long n = (long long)H * W;
     if (stages) { w.cb.dump_clahe = stages + n; w.cb.dump_gauss = stages + 2 * n; }
     if ((rc = clear_canny_ws(ctx, w))) return rc;
@@ -1157,7 +1181,7 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
         a.scratch = w.big;
         a.D = ctx->d_D[k]; a.zz = ctx->d_zz[k]; a.zzinv = ctx->d_zzinv[k];
         for (int l = 0; l < 3; l++) { a.qm[l] = ctx->d_qm[l][k]; a.mid[l] = (float)kMid[ctx->space][l]; a.scale[l] = (float)kScale[ctx->space][l]; }
-        launch_idct(st, s, g, q, a, w.work_cap[k]);
+        if (launch_idct(st, s, g, q, a, w.work_cap[k])) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no IDCT kernel for block size %d with %d planes", s, a.nplanes);
     }
     if (launch_upsample_color(st, ctx->space, g, w.planes, rgb_out)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
     AEJ_HIP_CHECK(hipGetLastError());

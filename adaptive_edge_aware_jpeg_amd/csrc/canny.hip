@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_clahe_pad_hist(Geom g, const unsigned c
 // ------------------------------------------------------------------------------------------------
 // CLAHE LUT per tile: clip, redistribute, cumulative sum, scale (CLAHE_CalcLut_Body)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict__ tile_hist, unsigned char *__restrict__ lut)
+__global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict__ tile_hist, unsigned char *__restrict__ lut, double clip_limit)
 {
     __shared__ int s[256];
     __shared__ int s_red[4];
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
     const long long base = (((long long)b * 3 + l) * 16 + tile) * 256;
     const int area = g.ctw[l] * g.cth[l];
     const float lutScale = 255.0f / (float)area;
-    int clip = (int)(0.75 * (double)area / 256.0);
-    if (clip < 1) clip = 1;
+    int clip = 0x7fffffff;                 // clipLimit <= 0: nothing is clipped (clahe.cpp)
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * (double)area / 256.0); if (clip < 1) clip = 1; }
     int hv = tile_hist[base + tid];
     int excess = hv > clip ? hv - clip : 0;
     if (hv > clip) hv = clip;
@@ -624,7 +624,7 @@ __device__ __forceinline__ double pct_from(const int *cum /* inclusive */, const
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_thresholds(Geom g, const int *__restrict__ blur_hist, int *__restrict__ thr)
+__global__ __launch_bounds__(256) void k_thresholds(Geom g, const int *__restrict__ blur_hist, int *__restrict__ thr, double low_q, double high_q, int l2)
 {
     __shared__ int cum[256];
     __shared__ int s_a, s_b;
@@ -638,15 +638,17 @@ __global__ __launch_bounds__(256) void k_thresholds(Geom g, const int *__restric
         __syncthreads();
     }
     long long n = (long long)g.w[l] * g.h[l];
-    double lo = pct_from(cum, nullptr, n, 0.10 * 100, tid, &s_a, &s_b);
-    double hi = pct_from(cum, nullptr, n, 0.30 * 100, tid, &s_a, &s_b);
+    double lo = pct_from(cum, nullptr, n, low_q, tid, &s_a, &s_b);
+    double hi = pct_from(cum, nullptr, n, high_q, tid, &s_a, &s_b);
     if (tid == 0) {
-        // cv::Canny, L2gradient=true (canny.cpp)
+        // cv::Canny (canny.cpp): with L2gradient the squared magnitudes are compared
         if (lo > hi) { double t = lo; lo = hi; hi = t; }
-        if (lo > 32767.0) lo = 32767.0;
-        if (hi > 32767.0) hi = 32767.0;
-        if (lo > 0) lo *= lo;
-        if (hi > 0) hi *= hi;
+        if (l2) {
+            if (lo > 32767.0) lo = 32767.0;
+            if (hi > 32767.0) hi = 32767.0;
+            if (lo > 0) lo *= lo;
+            if (hi > 0) hi *= hi;
+        }
         thr[((long long)b * 3 + l) * 2 + 0] = (int)floor(lo);
         thr[((long long)b * 3 + l) * 2 + 1] = (int)floor(hi);
     }
@@ -699,6 +701,7 @@ __device__ __forceinline__ void nms_prefetch(const unsigned char *src, int w, in
 
 // workgroup = strip of kStrip tiles of one tile-row; the blurred bytes of the next tile are prefetched into registers while
 // the current tile is processed
+template <bool L2>
 __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int strip)
 {
     __shared__ NmsLds L;
@@ -787,7 +790,13 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int gx = x0 - 4 + 4 * i4 + p;
-                    int m = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, gv[p]), __builtin_bit_cast(s16x2, gv[p]), 0, false);   // dx^2 + dy^2
+                    int m;
+                    if (L2) {
+                        m = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, gv[p]), __builtin_bit_cast(s16x2, gv[p]), 0, false);   // dx^2 + dy^2
+                    } else {                                                                                                  // |dx| + |dy|
+                        const int dxv = (int)(short)(gv[p] & 0xffffu), dyv = (int)gv[p] >> 16;
+                        m = (dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv);
+                    }
                     if (!aligned && (gx < 0 || gx >= w || gy < 0 || gy >= h)) m = 0;      // magnitude outside the image is 0
                     L.M[jm * kNMW + 4 * i4 + p] = m;
                     L.G[jm * kNMW + 4 * i4 + p] = (int)gv[p];
@@ -1082,7 +1091,7 @@ void launch_clahe_pad_hist(hipStream_t st, const Geom &g, const CannyBuffers &cb
 
 void launch_clahe_lut(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
-    hipLaunchKernelGGL(k_clahe_lut, dim3(16, g.nl, g.B), dim3(256), 0, st, g, cb.tile_hist, cb.lut);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(16, g.nl, g.B), dim3(256), 0, st, g, cb.tile_hist, cb.lut, cb.clip_limit);
 }
 
 // strips per image for a strip length; the longest strip that still gives every CU a few workgroups is used
@@ -1110,13 +1119,15 @@ void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
-    hipLaunchKernelGGL(k_thresholds, dim3(g.nl, g.B), dim3(256), 0, st, g, cb.blur_hist, cb.thr);
+    hipLaunchKernelGGL(k_thresholds, dim3(g.nl, g.B), dim3(256), 0, st, g, cb.blur_hist, cb.thr, cb.low_q, cb.high_q, cb.l2);
 }
 
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
     const int strip = pick_strip(g, kBlurTW, kBlurTH, kStripMax, 2048);
-    hipLaunchKernelGGL(k_sobel_nms, dim3((unsigned)(strips_per_image(g, kBlurTW, kBlurTH, strip) * g.B)), dim3(256), 0, st, g, cb, strip);
+    const dim3 grid((unsigned)(strips_per_image(g, kBlurTW, kBlurTH, strip) * g.B));
+    if (cb.l2) hipLaunchKernelGGL(k_sobel_nms<true>, grid, dim3(256), 0, st, g, cb, strip);
+    else hipLaunchKernelGGL(k_sobel_nms<false>, grid, dim3(256), 0, st, g, cb, strip);
 }
 
 void launch_hyst_finish(hipStream_t st, const Geom &g, const CannyBuffers &cb, int first_pass)

@@ -318,6 +318,126 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 16 x 16 blocks on the matrix pipe: one WAVE per leaf, v_mfma_f32_16x16x4_f32, no LDS and no barrier between the products.
+// The instruction accumulates its four k values as the k-ascending fma chain (checked bit for bit on hardware,
+// tools/ubench/mfma16_order.hip), so four of them in a row are exactly the contract's chain over k = 0..15.
+//   P = X^T.D^T : A operand of step s = X[4 s + g][i] (lane = 16 g + i), i.e. the lanes of a 16-lane group read 64 contiguous
+//                 bytes of one plane row STRAIGHT FROM GLOBAL MEMORY into the operand register; B = D[i][4 s + g], loop-invariant.
+//                 P[i][j] = T[j][i]; the C layout leaves P[4 g + r][i] in register r.
+//   Y = T.D^T   : A operand of step s = T[i][4 s + g] = P[4 s + g][i]: a 4 x 4 transpose between the four 16-lane groups and
+//                 the four registers -- two v_permlane32_swap + two v_permlane16_swap (gfx950), no LDS round trip.
+// Y[4 g + r][i] sits in register r: quantise, stage the leaf's 1 KiB through a wave-private LDS slab at the zigzag positions,
+// and write it with ONE 16-byte store per lane.  The next leaf's pixels and the descriptor after that are in flight meanwhile.
+// ------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <bool WANT_DCT>
+__global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
+{
+    constexpr int S = 16, SS = 256;
+    __shared__ float sQf[3 * SS];
+    __shared__ int sOut[4][SS];
+    __shared__ LayerTab lt;
+    extern __shared__ int s_pref[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * SS; i += 256) sQf[i] = (float)(a.qm[i / SS] ? a.qm[i / SS][i % SS] : 1);
+    dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
+    long long count = s_pref[a.nplanes];
+    if (count > max_items) count = max_items;
+    const long long wstride = q.work_stride[a.k];
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), gq = lane >> 4, i = lane & 15;
+    float dB[4];
+    int zz[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) dB[s] = a.D[i * S + 4 * s + gq];
+#pragma unroll
+    for (int r = 0; r < 4; r++) zz[r] = zigzag_pos<S>(4 * gq + r, i);
+    int *out_slab = sOut[wv];
+    const long long nw = (long long)gridDim.x * 4;
+    long long item = (long long)blockIdx.x * 4 + wv;
+
+    // Everything about a leaf is wave-uniform, so descriptors live in SGPRs (readfirstlane) and the plane / clipping arithmetic is
+    // scalar.  Items past the end are clamped to the last one (its loads are harmless and unused): no divergent branch, so no
+    // wait sits between a load and the work it is meant to overlap.
+    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto fetch = [&](long long it) {                       // -> descriptor in VECTOR registers, load still in flight
+        if (it > count - 1) it = count - 1;
+        int lo = 0, hi = a.nplanes;                        // largest p with s_pref[p] <= it (scalar search on LDS values)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)rfl(s_pref[mid]) <= it) lo = mid; else hi = mid;
+        }
+        const int b = lo / 3, l = lo - 3 * b;
+        return reinterpret_cast<const int4 *>(a.work)[(long long)b * wstride + lt.woff[l] + (it - rfl(s_pref[lo]))];
+    };
+    auto load_x = [&](const int4 &d, float (&x)[4]) {      // d scalar
+        const int b = d.x / 3, layer = d.x - b * 3;
+        const int w = rfl(lt.w[layer]), h = rfl(lt.h[layer]);
+        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer] + (long long)d.z * w + d.y;
+        if (d.z + S <= h && d.y + S <= w) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) x[s] = src[(4 * s + gq) * w + i];
+        } else {                                           // clipped at the plane border: np.pad(reflect) indices
+            const int hc = min(S, h - d.z), wc = min(S, w - d.y);
+            const int col = reflect_pad_idx(i, wc);
+#pragma unroll
+            for (int s = 0; s < 4; s++) x[s] = src[(long long)reflect_pad_idx(4 * s + gq, hc) * w + col];
+        }
+    };
+    auto rfl4 = [&](const int4 &v) { return make_int4(rfl(v.x), rfl(v.y), rfl(v.z), rfl(v.w)); };
+    if (item >= count) return;
+    int4 d_cur = rfl4(fetch(item));
+    int4 dv_nxt = fetch(item + nw);
+    float x_cur[4], x_nxt[4];
+    load_x(d_cur, x_cur);
+    for (; item < count; item += nw) {
+        const int4 d_nxt = rfl4(dv_nxt);                       // requested one leaf ago
+        load_x(d_nxt, x_nxt);                                  // next leaf's pixels ...
+        dv_nxt = fetch(item + 2 * nw);                         // ... and the descriptor after it: both in flight under this leaf's work
+        const int b = d_cur.x / 3, layer = d_cur.x - b * 3;
+        floatx4 p = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int s = 0; s < 4; s++) p = __builtin_amdgcn_mfma_f32_16x16x4f32(x_cur[s], dB[s], p, 0, 0, 0);
+        // (__float_as_uint, not __builtin_bit_cast: hipcc 7.2 folds a bit_cast of an ext-vector ELEMENT to element 0)
+        const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[0]), __float_as_uint(p[2]), false, false);
+        const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[1]), __float_as_uint(p[3]), false, false);
+        const unsigned p02a = p02[0], p02b = p02[1], p13a = p13[0], p13b = p13[1];
+        const auto q01 = __builtin_amdgcn_permlane16_swap(p02a, p13a, false, false);
+        const auto q23 = __builtin_amdgcn_permlane16_swap(p02b, p13b, false, false);
+        const unsigned t0 = q01[0], t1 = q01[1], t2 = q23[0], t3 = q23[1];
+        const float t[4] = { __uint_as_float(t0), __uint_as_float(t1), __uint_as_float(t2), __uint_as_float(t3) };
+        floatx4 y = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int s = 0; s < 4; s++) y = __builtin_amdgcn_mfma_f32_16x16x4f32(t[s], dB[s], y, 0, 0, 0);
+        const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + d_cur.w;
+        float qf[4], ymax = 0.f, qmax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ridx = (4 * gq + r) * S + i;
+            if (WANT_DCT) a.dct_f32[out_base + ridx] = y[r];
+            qf[r] = sQf[layer * SS + ridx];
+            ymax = __builtin_fmaxf(ymax, __builtin_fabsf(y[r]));
+            qmax = __builtin_fmaxf(qmax, qf[r]);
+        }
+        // one range test per leaf for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
+        if (!__any(qmax > 4194304.0f || !(ymax < 131072.0f))) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) out_slab[zz[r]] = quantise_f32(y[r], qf[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) out_slab[zz[r]] = quantise_f64(y[r], (int)qf[r]);
+        }
+        // (LDS operations of one wave execute in order: the reads below see this wave's writes, and the next leaf's writes
+        // come after these reads)
+        const int4 o = reinterpret_cast<const int4 *>(out_slab)[lane];
+        reinterpret_cast<int4 *>(a.coeffs + out_base)[lane] = o;
+        d_cur = d_nxt;
+#pragma unroll
+        for (int s = 0; s < 4; s++) x_cur[s] = x_nxt[s];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // S = 256 (aej_bigblock.h): T = D.X into this workgroup's scratch, then Y = T.D^T, quantise, zigzag scatter
 // ------------------------------------------------------------------------------------------------
 template <int S, bool WANT_DCT>
@@ -749,7 +869,10 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
         else hipLaunchKernelGGL((k_dct4<false>), dim3(cap(256, 8192)), dim3(256), pref, st, g, q, a, max_items);
         break;
     case 8: AEJ_SMALL(8, 32, 4096); break;
-    case 16: AEJ_SMALL(16, 16, 4096); break;
+    case 16:
+        if (wd) hipLaunchKernelGGL((k_dct16_mfma<true>), dim3(cap(4, 2048)), dim3(256), pref, st, g, q, a, max_items);
+        else hipLaunchKernelGGL((k_dct16_mfma<false>), dim3(cap(4, 2048)), dim3(256), pref, st, g, q, a, max_items);
+        break;
     case 32: AEJ_MFMA(32); break;
     case 64: AEJ_MFMA(64); break;
     case 128: AEJ_MFMA(128); break;

@@ -484,9 +484,10 @@ static void launch_idct_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, c
     hipLaunchKernelGGL(k_idct_mfma<S>, dim3(blocks), dim3(IdctCfg<S>::NTHREADS), lds, st, g, q, a);
 }
 
-void launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const IdctArgs &a, long long max_items)
+int launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const IdctArgs &a, long long max_items)      // 0 = launched (or nothing to do)
 {
-    if (max_items <= 0 || a.nplanes > kMaxPlanes) return;
+    if (a.nplanes > kMaxPlanes) return -1;         // the per-plane prefix table would not fit the launch's LDS
+    if (max_items <= 0) return 0;
     const size_t pref = (size_t)(a.nplanes + 1) * sizeof(int);
     auto cap = [&](long long per_block, int hi) {
         long long b = (max_items + per_block - 1) / per_block;
@@ -501,10 +502,12 @@ void launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const
     case 64: launch_idct_mfma_t<64>(st, g, q, a, cap(1, 768)); break;
     case 128: launch_idct_mfma_t<128>(st, g, q, a, cap(1, 256)); break;
     case 256:
-        if (a.scratch) hipLaunchKernelGGL(k_idct_big<256>, dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a);
+        if (!a.scratch) return -1;
+        hipLaunchKernelGGL(k_idct_big<256>, dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a);
         break;
-    default: break;
+    default: return -1;
     }
+    return 0;
 }
 
 template <int SPACE>

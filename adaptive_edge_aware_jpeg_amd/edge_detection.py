@@ -25,16 +25,20 @@ class EdgeDetection:
         gaussian_kernel: int = 3,
         return_stages: bool = False,
     ) -> np.ndarray:
-        """Returns the float32 {0,1} edge map.  The hyper-parameters are compile-time constants of the
-        kernels (no caller of the reference overrides them, jpeg.py:376); other values raise."""
+        """Returns the float32 {0,1} edge map.  The threshold ratios, the CLAHE clip limit, the bilateral sigmas and the
+        gradient norm are run-time values of the kernels (``aej_set_canny_params``); the stencil shapes -- ``aperture_size`` 3,
+        ``clahe_tile_grid`` (4, 4), ``bilateral_diameter`` 5, ``gaussian_kernel`` 3, the values the reference's only caller uses
+        (jpeg.py:376) -- are structural, other values raise."""
         if not isinstance(img, np.ndarray):
             raise TypeError("Input must be a numpy array.")
         if img.ndim != 2:
             raise ValueError("Input array must be a 2D.")
-        given = (aperture_size, use_L2_gradient, canny_low_ratio, canny_high_ratio, clahe_clip_limit,
-                 tuple(clahe_tile_grid), bilateral_diameter, bilateral_sigma_color, bilateral_sigma_space, gaussian_kernel)
-        if given != (3, True, 0.10, 0.30, 0.75, (4, 4), 5, 75, 75, 3):
-            raise NotImplementedError("the HIP Canny chain is built for the reference's default hyper-parameters only")
+        shape = (aperture_size, tuple(clahe_tile_grid), bilateral_diameter, gaussian_kernel)
+        if shape != (3, (4, 4), 5, 3):
+            raise NotImplementedError("the HIP Canny chain is built for aperture_size=3, clahe_tile_grid=(4, 4), bilateral_diameter=5, "
+                                      f"gaussian_kernel=3 (got {shape})")
+        params = (canny_low_ratio, canny_high_ratio, clahe_clip_limit, bilateral_sigma_color, bilateral_sigma_space, bool(use_L2_gradient))
+        default = params == (0.10, 0.30, 0.75, 75, 75, True)
         ctx = get_context()
         t = ctx.torch
         H, W = img.shape
@@ -44,9 +48,15 @@ class EdgeDetection:
         thr = ctx.empty((2,), t.int32) if return_stages else None
         nbytes = ctx.lib.aej_canny_workspace_bytes(H, W)
         ws = ctx.workspace(nbytes)
-        ctx.check(ctx.lib.aej_canny(ctx.handle, plane.data_ptr(), H, W, edge.data_ptr(),
-                                    stages.data_ptr() if return_stages else None,
-                                    thr.data_ptr() if return_stages else None, ws.data_ptr(), ctypes.c_uint64(nbytes)))
+        if not default:
+            ctx.set_canny_params(params)
+        try:
+            ctx.check(ctx.lib.aej_canny(ctx.handle, plane.data_ptr(), H, W, edge.data_ptr(),
+                                        stages.data_ptr() if return_stages else None,
+                                        thr.data_ptr() if return_stages else None, ws.data_ptr(), ctypes.c_uint64(nbytes)))
+        finally:
+            if not default:
+                ctx.set_canny_params(None)          # the context is shared with Jpeg, whose Canny stage uses the defaults
         out = edge.cpu().numpy().astype(np.float32)
         if return_stages:
             return out, stages.cpu().numpy(), tuple(int(v) for v in thr.cpu().numpy())

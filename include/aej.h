@@ -153,6 +153,17 @@ AEJ_API int aej_color_planes(aej_ctx *ctx, const float *rgb, int batch, int H, i
  * stages (optional): 5*H*W uint8 = scaled, CLAHE, Gaussian, bilateral, NMS map (0 weak,1 none,2 strong);
  * thresholds (optional): 2 int32 = the integer low/high passed to the NMS test. */
 AEJ_API uint64_t aej_canny_workspace_bytes(int H, int W);
+/* The keyword arguments of EdgeDetection.canny (edge_detection.py:31-40) that are run-time values of the kernels; they apply to
+ * aej_canny and to the Canny stage of aej_encode_batch until changed (NULL = the reference's defaults 0.10, 0.30, 0.75, 75, 75,
+ * true, which is what Jpeg._block_split uses, jpeg.py:376).  aperture_size = 3, clahe_tile_grid = (4, 4),
+ * bilateral_diameter = 5 and gaussian_kernel = 3 are structural (stencil shapes) and not selectable. */
+typedef struct aej_canny_params {
+    double canny_low_ratio, canny_high_ratio;     /* np.percentile(blur, ratio * 100) */
+    double clahe_clip_limit;                      /* cv.createCLAHE(clipLimit=...); <= 0 disables clipping */
+    double bilateral_sigma_color, bilateral_sigma_space;
+    int use_l2_gradient;                          /* cv.Canny(L2gradient=...) */
+} aej_canny_params;
+AEJ_API int aej_set_canny_params(aej_ctx *ctx, const aej_canny_params *params);
 AEJ_API int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t *edge, uint8_t *stages,
               int32_t *thresholds, void *workspace, uint64_t workspace_bytes);
 

@@ -335,7 +335,7 @@ static inline int reflect101(int i, int n)
  * a-4  CLAHE(clipLimit=0.75, tileGridSize=(4,4)).apply(u8)  (edge_detection.py:73-74)
  *      OpenCV 4.x clahe.cpp (CLAHE_CalcLut_Body / CLAHE_Interpolation_Body), 8-bit.
  * ---------------------------------------------------------------------------------------- */
-ORC_API void orc_clahe(const uint8_t *src, uint8_t *dst, int H, int W)
+static void clahe_impl(const uint8_t *src, uint8_t *dst, int H, int W, double clip_limit)
 {
     const int TX = 4, TY = 4;
     int Hp = H, Wp = W;
@@ -343,8 +343,8 @@ ORC_API void orc_clahe(const uint8_t *src, uint8_t *dst, int H, int W)
     int tw = Wp / TX, th = Hp / TY;
     int area = tw * th;
     float lutScale = 255.0f / (float)area;
-    int clip = (int)(0.75 * (double)area / 256.0);
-    if (clip < 1) clip = 1;
+    int clip = 0;                         /* clahe.cpp: clipLimit_ <= 0 means no clipping */
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * (double)area / 256.0); if (clip < 1) clip = 1; }
     uint8_t lut[16][256];
     for (int ty = 0; ty < TY; ty++)
         for (int tx = 0; tx < TX; tx++) {
@@ -354,14 +354,16 @@ ORC_API void orc_clahe(const uint8_t *src, uint8_t *dst, int H, int W)
                 int sy = reflect101(y, H);
                 for (int x = tx * tw; x < (tx + 1) * tw; x++) hist[src[(int64_t)sy * W + reflect101(x, W)]]++;
             }
-            int clipped = 0;
-            for (int i = 0; i < 256; i++)
-                if (hist[i] > clip) { clipped += hist[i] - clip; hist[i] = clip; }
-            int batch = clipped / 256, resid = clipped - batch * 256;
-            for (int i = 0; i < 256; i++) hist[i] += batch;
-            if (resid != 0) {
-                int step = 256 / resid; if (step < 1) step = 1;
-                for (int i = 0; i < 256 && resid > 0; i += step, resid--) hist[i]++;
+            if (clip > 0) {
+                int clipped = 0;
+                for (int i = 0; i < 256; i++)
+                    if (hist[i] > clip) { clipped += hist[i] - clip; hist[i] = clip; }
+                int batch = clipped / 256, resid = clipped - batch * 256;
+                for (int i = 0; i < 256; i++) hist[i] += batch;
+                if (resid != 0) {
+                    int step = 256 / resid; if (step < 1) step = 1;
+                    for (int i = 0; i < 256 && resid > 0; i += step, resid--) hist[i]++;
+                }
             }
             int sum = 0;
             for (int i = 0; i < 256; i++) {
@@ -397,6 +399,8 @@ ORC_API void orc_clahe(const uint8_t *src, uint8_t *dst, int H, int W)
     }
 }
 
+ORC_API void orc_clahe(const uint8_t *src, uint8_t *dst, int H, int W) { clahe_impl(src, dst, H, W, 0.75); }
+
 /* ------------------------------------------------------------------------------------------
  * a-5  GaussianBlur(u8, (3,3), 0)  (edge_detection.py:77): kernel [1 2 1]/4, 8-bit fixed point path
  *      => (sum [1 2 1;2 4 2;1 2 1]*p + 8) >> 4, BORDER_REFLECT_101.
@@ -419,9 +423,11 @@ ORC_API void orc_gauss3(const uint8_t *src, uint8_t *dst, int H, int W)
  *      radius 2, circular mask (13 taps, row-major), weights (float)exp(double), w = sw*cw,
  *      wsum += w, sum = fma(val, w, sum), out = cvRound(sum / wsum), BORDER_REFLECT_101.
  * ---------------------------------------------------------------------------------------- */
-ORC_API void orc_bilateral_tables(float *space_w /*13*/, int *dy /*13*/, int *dx /*13*/, float *color_w /*256*/)
+static void bilateral_tables_impl(float *space_w /*13*/, int *dy /*13*/, int *dx /*13*/, float *color_w /*256*/, double sigma_color, double sigma_space)
 {
-    double cc = -0.5 / (75.0 * 75.0), sc = -0.5 / (75.0 * 75.0);
+    if (sigma_color <= 0) sigma_color = 1;      /* bilateral_filter.dispatch.cpp */
+    if (sigma_space <= 0) sigma_space = 1;
+    double cc = -0.5 / (sigma_color * sigma_color), sc = -0.5 / (sigma_space * sigma_space);
     for (int i = 0; i < 256; i++) color_w[i] = (float)exp((double)i * (double)i * cc);
     int k = 0;
     for (int i = -2; i <= 2; i++)
@@ -433,11 +439,13 @@ ORC_API void orc_bilateral_tables(float *space_w /*13*/, int *dy /*13*/, int *dx
         }
 }
 
-ORC_API void orc_bilateral5(const uint8_t *src, uint8_t *dst, int H, int W)
+ORC_API void orc_bilateral_tables(float *space_w, int *dy, int *dx, float *color_w) { bilateral_tables_impl(space_w, dy, dx, color_w, 75.0, 75.0); }
+
+static void bilateral5_impl(const uint8_t *src, uint8_t *dst, int H, int W, double sigma_color, double sigma_space)
 {
     float sw[13], cw[256];
     int dy[13], dx[13];
-    orc_bilateral_tables(sw, dy, dx, cw);
+    bilateral_tables_impl(sw, dy, dx, cw, sigma_color, sigma_space);
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             int v0 = src[(int64_t)y * W + x];
@@ -453,6 +461,8 @@ ORC_API void orc_bilateral5(const uint8_t *src, uint8_t *dst, int H, int W)
             dst[(int64_t)y * W + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
         }
 }
+
+ORC_API void orc_bilateral5(const uint8_t *src, uint8_t *dst, int H, int W) { bilateral5_impl(src, dst, H, W, 75.0, 75.0); }
 
 /* ------------------------------------------------------------------------------------------
  * a-7  np.percentile(blur, 10) / (blur, 30)  (edge_detection.py:81-82): method 'linear' on the
@@ -476,14 +486,16 @@ static double percentile_from_hist(const int64_t *hist, int64_t n, double q)
     return r;
 }
 
-ORC_API void orc_percentiles(const uint8_t *img, int64_t n, double *lo, double *hi)
+static void percentiles_impl(const uint8_t *img, int64_t n, double q_lo, double q_hi, double *lo, double *hi)
 {
     int64_t hist[256];
     memset(hist, 0, sizeof hist);
     for (int64_t i = 0; i < n; i++) hist[img[i]]++;
-    *lo = percentile_from_hist(hist, n, 0.10 * 100);
-    *hi = percentile_from_hist(hist, n, 0.30 * 100);
+    *lo = percentile_from_hist(hist, n, q_lo);
+    *hi = percentile_from_hist(hist, n, q_hi);
 }
+
+ORC_API void orc_percentiles(const uint8_t *img, int64_t n, double *lo, double *hi) { percentiles_impl(img, n, 0.10 * 100, 0.30 * 100, lo, hi); }
 
 /* ------------------------------------------------------------------------------------------
  * a-8  cv.Canny(u8, lo, hi, apertureSize=3, L2gradient=True)  (edge_detection.py:85)
@@ -491,21 +503,25 @@ ORC_API void orc_percentiles(const uint8_t *img, int64_t n, double *lo, double *
  *      image = 0, NMS with the integer tan(22.5) test, hysteresis over 8-neighbours.  dst is 255/0.
  *      The map (0 = weak candidate, 1 = suppressed, 2 = strong) is exported too for stage-level parity tests.
  * ---------------------------------------------------------------------------------------- */
-ORC_API void orc_canny_thresholds(double lo, double hi, int *low, int *high)
+static void canny_thresholds_impl(double lo, double hi, int l2, int *low, int *high)
 {
     if (lo > hi) { double t = lo; lo = hi; hi = t; }
-    if (lo > 32767.0) lo = 32767.0;
-    if (hi > 32767.0) hi = 32767.0;
-    if (lo > 0) lo *= lo;
-    if (hi > 0) hi *= hi;
+    if (l2) {                                /* L2gradient: squared magnitudes are compared */
+        if (lo > 32767.0) lo = 32767.0;
+        if (hi > 32767.0) hi = 32767.0;
+        if (lo > 0) lo *= lo;
+        if (hi > 0) hi *= hi;
+    }
     *low = (int)floor(lo);
     *high = (int)floor(hi);
 }
 
-ORC_API void orc_canny(const uint8_t *src, uint8_t *dst, uint8_t *nms_out /* may be NULL */, int H, int W, double lo, double hi)
+ORC_API void orc_canny_thresholds(double lo, double hi, int *low, int *high) { canny_thresholds_impl(lo, hi, 1, low, high); }
+
+static void canny_impl(const uint8_t *src, uint8_t *dst, uint8_t *nms_out /* may be NULL */, int H, int W, double lo, double hi, int l2)
 {
     int low, high;
-    orc_canny_thresholds(lo, hi, &low, &high);
+    canny_thresholds_impl(lo, hi, l2, &low, &high);
     int64_t n = (int64_t)H * W;
     int16_t *gx = (int16_t *)malloc(n * 2), *gy = (int16_t *)malloc(n * 2);
     int32_t *mag = (int32_t *)calloc((size_t)(H + 2) * (W + 2), 4);
@@ -521,7 +537,7 @@ ORC_API void orc_canny(const uint8_t *src, uint8_t *dst, uint8_t *nms_out /* may
             int dy = (g + 2 * h + i) - (a + 2 * b + c);
             gx[(int64_t)y * W + x] = (int16_t)dx;
             gy[(int64_t)y * W + x] = (int16_t)dy;
-            mag[(int64_t)(y + 1) * (W + 2) + (x + 1)] = dx * dx + dy * dy;
+            mag[(int64_t)(y + 1) * (W + 2) + (x + 1)] = l2 ? dx * dx + dy * dy : (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
         }
 #undef SRC
     int64_t *stack = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
@@ -570,7 +586,35 @@ ORC_API void orc_canny(const uint8_t *src, uint8_t *dst, uint8_t *nms_out /* may
     free(stack); free(map); free(mag); free(gx); free(gy);
 }
 
-/* whole EdgeDetection.canny (edge_detection.py:70-86); edge01 gets 1 for edge (== 1.0f in the reference) */
+ORC_API void orc_canny(const uint8_t *src, uint8_t *dst, uint8_t *nms_out, int H, int W, double lo, double hi) { canny_impl(src, dst, nms_out, H, W, lo, hi, 1); }
+
+/* whole EdgeDetection.canny (edge_detection.py:70-86); edge01 gets 1 for edge (== 1.0f in the reference).
+ * params (edge_detection.py:31-40; NULL = the defaults): { canny_low_ratio, canny_high_ratio, clahe_clip_limit,
+ * bilateral_sigma_color, bilateral_sigma_space, use_L2_gradient }.  aperture_size 3, tile grid (4, 4), bilateral diameter 5
+ * and the 3 x 3 Gaussian are structural in this restatement (as in the kernels). */
+ORC_API void orc_edge_pipeline_ex(const float *plane, uint8_t *edge01, int H, int W, uint8_t *stages /* 4*H*W or NULL */, double *thr /*2 or NULL*/,
+                                  const double *params /* 6 or NULL */)
+{
+    static const double defaults[6] = { 0.10, 0.30, 0.75, 75.0, 75.0, 1.0 };
+    const double *p = params ? params : defaults;
+    int64_t n = (int64_t)H * W;
+    uint8_t *a = (uint8_t *)malloc(n), *b = (uint8_t *)malloc(n);
+    orc_to_u8(plane, a, n);
+    if (stages) memcpy(stages, a, n);
+    clahe_impl(a, b, H, W, p[2]);
+    if (stages) memcpy(stages + n, b, n);
+    orc_gauss3(b, a, H, W);
+    if (stages) memcpy(stages + 2 * n, a, n);
+    bilateral5_impl(a, b, H, W, p[3], p[4]);
+    if (stages) memcpy(stages + 3 * n, b, n);
+    double lo, hi;
+    percentiles_impl(b, n, p[0] * 100, p[1] * 100, &lo, &hi);
+    if (thr) { thr[0] = lo; thr[1] = hi; }
+    canny_impl(b, a, NULL, H, W, lo, hi, p[5] != 0.0);
+    for (int64_t i = 0; i < n; i++) edge01[i] = a[i] ? 1 : 0;
+    free(a); free(b);
+}
+
 ORC_API void orc_edge_pipeline(const float *plane, uint8_t *edge01, int H, int W, uint8_t *stages /* 4*H*W or NULL */, double *thr /*2 or NULL*/)
 {
     int64_t n = (int64_t)H * W;

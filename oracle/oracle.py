@@ -166,14 +166,20 @@ def canny(img, lo, hi, return_nms=False):
     return (out, nms) if return_nms else out
 
 
-def edge_pipeline(plane, return_stages=False):
-    """EdgeDetection.canny (edge_detection.py:70-86) -> uint8 {0,1}; optionally the 4 u8 stages + thresholds."""
+def edge_pipeline(plane, return_stages=False, params=None):
+    """EdgeDetection.canny (edge_detection.py:70-86) -> uint8 {0,1}; optionally the 4 u8 stages + thresholds.
+    params = (canny_low_ratio, canny_high_ratio, clahe_clip_limit, bilateral_sigma_color, bilateral_sigma_space, use_L2_gradient)
+    of edge_detection.py:31-40, None = the defaults."""
     plane = np.ascontiguousarray(plane, dtype=np.float32)
     H, W = plane.shape
     edge = np.empty((H, W), np.uint8)
     stages = np.empty((4, H, W), np.uint8) if return_stages else None
     thr = (ctypes.c_double * 2)()
-    lib().orc_edge_pipeline(_p(plane), _p(edge), H, W, _p(stages) if return_stages else None, thr)
+    if params is not None:
+        pv = (ctypes.c_double * 6)(*[float(v) for v in params])
+        lib().orc_edge_pipeline_ex(_p(plane), _p(edge), H, W, _p(stages) if return_stages else None, thr, pv)
+    else:
+        lib().orc_edge_pipeline(_p(plane), _p(edge), H, W, _p(stages) if return_stages else None, thr)
     if return_stages:
         return edge, stages, (thr[0], thr[1])
     return edge

@@ -193,13 +193,35 @@ def test_graph_replay_path_matches_oracle(env, oracle):
             check_image(EncodedBatch(plan, *out), 0, refs[which], f"graph call {it}")
         g1 = ctx.graph_stats()
         assert g1["captures"] - g0["captures"] == 1 and g1["launches"] - g0["launches"] >= 3, (g0, g1)
-        # a replay whose pass count is too small: the miss is detected and repaired eagerly
-        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
-        s0 = ctx.hysteresis_stats()
+        # a replay whose pass count is too small (needs the per-pass hysteresis, i.e. more than kHystFinishTiles tiles: 6 images):
+        # the miss is detected after the replay and repaired eagerly; outputs equal the eager path's
+        B = 6
+        xb = bench.synth_batch(torch, B, H, W, 5, dev)
+        planb = ctx.plan(B, H, W)
+        def outs():
+            return (ctx.empty((B * planb.coeff_stride,), torch.int32), ctx.empty((B * planb.leaf_stride, 4), torch.int32),
+                    ctx.empty((B * planb.state_stride,), torch.uint8), ctx.empty((B, 3, 4), torch.int64))
+        ctx.set_graph_mode(0)
+        want = outs()
+        codec.encode_into(ctx, xb, planb, *want)
+        torch.cuda.synchronize()
+        ctx.set_graph_mode(2)
+        got = outs()
+        s0, g2 = ctx.hysteresis_stats(), ctx.graph_stats()
         for it in range(3):                              # 1st: remembered, 2nd: captured + replayed, 3rd: replayed
             ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
-            codec.encode_into(ctx, x, plan, *out)
-            check_image(EncodedBatch(plan, *out), 0, refs[1], f"graph miss call {it}")
+            for t in got:
+                t.zero_()
+            codec.encode_into(ctx, xb, planb, *got)
+            torch.cuda.synchronize()
+            assert torch.equal(got[3], want[3]), f"graph miss call {it}: counts"
+            for im in range(B):
+                for l in range(3):
+                    nc, nl, ns, _ = (int(v) for v in want[3][im, l])
+                    c0, l0, s0_ = im * planb.coeff_stride + planb.coeff_off[l], im * planb.leaf_stride + planb.leaf_off[l], im * planb.state_stride + planb.state_off[l]
+                    assert torch.equal(got[0][c0:c0 + nc], want[0][c0:c0 + nc]) and torch.equal(got[1][l0:l0 + nl], want[1][l0:l0 + nl]) \
+                        and torch.equal(got[2][s0_:s0_ + ns], want[2][s0_:s0_ + ns]), f"graph miss call {it}: image {im} layer {l}"
         assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 3
+        assert ctx.graph_stats()["launches"] - g2["launches"] >= 2
     finally:
         ctx.set_graph_mode(0)

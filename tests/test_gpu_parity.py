@@ -115,6 +115,36 @@ def test_canny_chain_stages(A, ctx, oracle, H, W, seed, shift):
     assert e.dtype == np.float32 and np.array_equal(e.astype(np.uint8), eo)
 
 
+@pytest.mark.parametrize("params", [
+    dict(canny_low_ratio=0.20, canny_high_ratio=0.55),
+    dict(clahe_clip_limit=2.0), dict(clahe_clip_limit=40.0), dict(clahe_clip_limit=0.0),
+    dict(bilateral_sigma_color=20, bilateral_sigma_space=3.5),
+    dict(use_L2_gradient=False),
+    dict(use_L2_gradient=False, canny_low_ratio=0.6, canny_high_ratio=0.4, clahe_clip_limit=1.5, bilateral_sigma_color=150, bilateral_sigma_space=0),
+])
+def test_canny_hyper_parameters(A, oracle, params):
+    """EdgeDetection.canny's keyword arguments (edge_detection.py:31-40): the run-time ones against the oracle stage by stage,
+    the structural ones raise; a call with other values leaves the shared context on the defaults."""
+    H, W = 203, 333
+    img = synth(oracle, H, W, 11)
+    plane = oracle.color_forward("YCbCr", img.reshape(-1, 3)).reshape(H, W, 3)[:, :, 0].copy()
+    full = dict(canny_low_ratio=0.10, canny_high_ratio=0.30, clahe_clip_limit=0.75, bilateral_sigma_color=75, bilateral_sigma_space=75, use_L2_gradient=True)
+    full.update(params)
+    tup = (full["canny_low_ratio"], full["canny_high_ratio"], full["clahe_clip_limit"], full["bilateral_sigma_color"], full["bilateral_sigma_space"],
+           full["use_L2_gradient"])
+    e, st, thr = A.EdgeDetection.canny(plane, return_stages=True, **params)
+    eo, so, pct = oracle.edge_pipeline(plane, return_stages=True, params=tup)
+    for i, name in enumerate(("scaled", "clahe", "gauss", "bilateral")):
+        assert np.array_equal(st[i], so[i]), name
+    assert np.array_equal(e.astype(np.uint8), eo)
+    assert eo.sum() > 0
+    # defaults restored
+    assert np.array_equal(A.EdgeDetection.canny(plane).astype(np.uint8), oracle.edge_pipeline(plane))
+    for bad in (dict(aperture_size=5), dict(clahe_tile_grid=(8, 8)), dict(bilateral_diameter=9), dict(gaussian_kernel=5)):
+        with pytest.raises(NotImplementedError):
+            A.EdgeDetection.canny(plane, **bad)
+
+
 def test_canny_extremes(A, oracle):
     flat = np.full((128, 192), 0.5, np.float32)
     assert A.EdgeDetection.canny(flat).sum() == 0
