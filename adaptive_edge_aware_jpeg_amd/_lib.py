@@ -211,7 +211,7 @@ class Context:
         self.check(self.lib.aej_set_settings(self.handle, SPACE_IDS[space], bmin, bmax, q.ctypes.data_as(ctypes.c_void_p)))
         self.settings_key = key
 
-    N_STAGES = 16
+    N_STAGES = 18
 
     def set_profiling(self, on):
         self.check(self.lib.aej_set_profiling(self.handle, 1 if on else 0))

@@ -77,12 +77,16 @@ void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuff
 
 // dct.hip
 constexpr int kBigBlocks = 128;      // workgroups (and scratch slots of 256 KiB) of the 256 x 256 kernels
+constexpr int kMaxBlock = 1024;      // largest block size with a kernel (the reference takes any power of two, jpeg.py:216-219; its GUI stops at 256)
+// sizes >= 256 run one workgroup per leaf with the first product in a global scratch slot of S x S floats per workgroup
+constexpr int big_blocks(int S) { return S <= 256 ? kBigBlocks : S == 512 ? 64 : 32; }
+constexpr long long big_scratch_floats_for(int S) { return S >= 256 ? (long long)big_blocks(S) * S * S : 0; }
 struct DctArgs {
     const float *norm;        // [B][pstride] normalised planes
     int *coeffs;              // out [B][coeff_stride]
     float *dct_f32;           // optional
     const LeafWork *work;     // work lists for this size (per-plane segments, see QtGeom)
-    float *scratch;           // [kBigBlocks][256 * 256] intermediate product of the 256 x 256 kernel, else null
+    float *scratch;           // [big_blocks(S)][S * S] intermediate product of the kernels for S >= 256 (sized for the largest S), else null
     const int *work_count;    // [nplanes][kMaxSizes]
     int k;                    // size index
     int nplanes;
@@ -100,7 +104,7 @@ struct IdctArgs {
     const int *coeffs;        // [B][coeff_stride] zigzag-ordered quantised coefficients
     float *planes;            // out [B][pstride] de-normalised layers
     const LeafWork *work;
-    float *scratch;           // [kBigBlocks][256 * 256] for the 256 x 256 kernel, else null
+    float *scratch;           // [big_blocks(S)][S * S] for the kernels of S >= 256, else null
     const int *work_count;    // [nplanes][kMaxSizes]
     int k, nplanes;
     const float *D;           // [s][s]

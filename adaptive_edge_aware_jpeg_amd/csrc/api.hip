@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -368,8 +369,12 @@ extern "C" int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, con
 {
     if (!ctx) return AEJ_ERR_ARG;
     if (space < 0 || space > 6) return fail(ctx, AEJ_ERR_ARG, "Unsupported color space id: %d", space);
-    if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 2 || bmax > 256)
-        return fail(ctx, bmax > 256 ? AEJ_ERR_UNSUPPORTED : AEJ_ERR_ARG, "block size range (%d, %d): powers of two in [2, 256] required", bmin, bmax);
+    if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 2)
+        return fail(ctx, AEJ_ERR_ARG, "block size range (%d, %d): powers of two with 2 <= min <= max required", bmin, bmax);
+    if (bmax > kMaxBlock)
+        return fail(ctx, AEJ_ERR_UNSUPPORTED, "block size range (%d, %d): no kernel for blocks above %d", bmin, bmax, kMaxBlock);
+    if (ilog2(bmax) - ilog2(bmin) + 1 > kMaxSizes)
+        return fail(ctx, AEJ_ERR_UNSUPPORTED, "block size range (%d, %d) spans more than %d sizes", bmin, bmax, kMaxSizes);
     if (!qmats_host) return fail(ctx, AEJ_ERR_ARG, "qmats_host is NULL");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
     int nsizes = 0;
@@ -636,7 +641,12 @@ static int run_color_planes(aej_ctx *ctx, const void *rgb, bool in_u8, const Geo
 }
 
 // ---- whole path ---------------------------------------------------------------------------------------------
-static long long big_scratch_floats(int bmax) { return bmax >= 256 ? (long long)kBigBlocks * 256 * 256 : 0; }
+static long long big_scratch_floats(int bmax)      // the launches of different sizes run one after the other: one scratch, sized for the largest
+{
+    long long m = 0;
+    for (int s = 256; s <= bmax; s *= 2) m = std::max(m, big_scratch_floats_for(s));
+    return m;
+}
 
 struct EncodeWs {
     float *big;              // scratch of the 256 x 256 DCT kernel (null unless the settings allow that size)
@@ -1358,6 +1368,6 @@ extern "C" int aej_get_stage_ms(aej_ctx *ctx, float *ms_host)
 extern "C" const char *aej_stage_name(int i)
 {
     static const char *names[AEJ_N_STAGES] = { "clear", "color_planes", "clahe_lut", "clahe_blur", "thresholds", "sobel_nms",
-                                               "hysteresis", "quadtree", "dct2", "dct4", "dct8", "dct16", "dct32", "dct64", "dct128", "dct256" };
+                                               "hysteresis", "quadtree", "dct2", "dct4", "dct8", "dct16", "dct32", "dct64", "dct128", "dct256", "dct512", "dct1024" };
     return i >= 0 && i < AEJ_N_STAGES ? names[i] : "";
 }

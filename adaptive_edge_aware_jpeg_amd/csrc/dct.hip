@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a,
 }
 
 // ------------------------------------------------------------------------------------------------
-// S = 256 (aej_bigblock.h): T = D.X into this workgroup's scratch, then Y = T.D^T, quantise, zigzag scatter
+// S = 256, 512, 1024 (aej_bigblock.h): T = D.X into this workgroup's scratch, then Y = T.D^T, quantise, zigzag scatter
 // ------------------------------------------------------------------------------------------------
 template <int S, bool WANT_DCT>
 __global__ __launch_bounds__(256) void k_dct_big(Geom g, QtGeom q, DctArgs a, long long max_items)
@@ -876,11 +876,14 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
     case 32: AEJ_MFMA(32); break;
     case 64: AEJ_MFMA(64); break;
     case 128: AEJ_MFMA(128); break;
-    case 256:
-        if (!a.scratch) return -1;   // callers reserve it whenever the settings allow this size
-        if (wd) hipLaunchKernelGGL((k_dct_big<256, true>), dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a, max_items);
-        else hipLaunchKernelGGL((k_dct_big<256, false>), dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a, max_items);
-        break;
+#define AEJ_BIG(S)                                                                                                               \
+    if (!a.scratch) return -1;   /* callers reserve it whenever the settings allow this size */                                 \
+    if (wd) hipLaunchKernelGGL((k_dct_big<S, true>), dim3(cap(1, big_blocks(S))), dim3(256), pref, st, g, q, a, max_items);      \
+    else hipLaunchKernelGGL((k_dct_big<S, false>), dim3(cap(1, big_blocks(S))), dim3(256), pref, st, g, q, a, max_items)
+    case 256: AEJ_BIG(256); break;
+    case 512: AEJ_BIG(512); break;
+    case 1024: AEJ_BIG(1024); break;
+#undef AEJ_BIG
     default: return -1;
     }
 #undef AEJ_SMALL

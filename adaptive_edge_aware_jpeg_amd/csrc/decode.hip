@@ -503,7 +503,15 @@ int launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const 
     case 128: launch_idct_mfma_t<128>(st, g, q, a, cap(1, 256)); break;
     case 256:
         if (!a.scratch) return -1;
-        hipLaunchKernelGGL(k_idct_big<256>, dim3(cap(1, kBigBlocks)), dim3(256), pref, st, g, q, a);
+        hipLaunchKernelGGL(k_idct_big<256>, dim3(cap(1, big_blocks(256))), dim3(256), pref, st, g, q, a);
+        break;
+    case 512:
+        if (!a.scratch) return -1;
+        hipLaunchKernelGGL(k_idct_big<512>, dim3(cap(1, big_blocks(512))), dim3(256), pref, st, g, q, a);
+        break;
+    case 1024:
+        if (!a.scratch) return -1;
+        hipLaunchKernelGGL(k_idct_big<1024>, dim3(cap(1, big_blocks(1024))), dim3(256), pref, st, g, q, a);
         break;
     default: return -1;
     }

@@ -433,6 +433,7 @@ def main():
         t0 = time.perf_counter()
         RS.encode_image(imgs[0], space, qrange, brange)
         t_rs = time.perf_counter() - t0
+        t_fan, n_fan = RS.fan_out(imgs[:cores], space, qrange, brange, cores)      # (ii): one image per worker process
         out["cpu_baseline"] = {"value": round(n_img * H * W / cdt / 1e6, 2), "unit": "MP/s", "cores": cores, "kind": "port",
                                "sample": f"{n_img} of the {B} bench images ({W}x{H}) over {cores} threads (one image per call), whole path a-1..a-15 in the C oracle, "
                                          f"{cdt:.1f} s; single core: 1 image in {t1:.1f} s",
@@ -440,7 +441,10 @@ def main():
                                "reference_structured": {"value": round(H * W / t_rs / 1e6, 2), "unit": "MP/s", "cores": 1, "kind": "port",
                                                         "sample": f"1 bench image ({W}x{H}), {t_rs:.1f} s: the reference's control structure (one Python thread, "
                                                                   "per-node quadtree tests, per-leaf pad / DCT / quantise / zigzag loops) with the C oracle standing in for "
-                                                                  "its OpenCV / numba calls -- not the reference binary stack (cv2 / numba absent)"}}
+                                                                  "its OpenCV / numba calls -- not the reference binary stack (cv2 / numba absent)",
+                                                        "fan_out": {"value": round(n_fan * H * W / t_fan / 1e6, 2), "unit": "MP/s", "cores": n_fan,
+                                                                    "sample": f"{n_fan} bench images, one per worker process (fresh interpreters, as the reference's "
+                                                                              f"sweep fans out, metrics_computation.py:253), {t_fan:.1f} s wall including interpreter start-up"}}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -83,7 +83,8 @@ AEJ_API int aej_last_hysteresis_passes(aej_ctx *ctx); /* diagnostic: passes enqu
 enum {
     AEJ_STAGE_CLEAR = 0, AEJ_STAGE_COLOR_PLANES, AEJ_STAGE_CLAHE_LUT, AEJ_STAGE_CLAHE_BLUR, AEJ_STAGE_THRESHOLDS,
     AEJ_STAGE_SOBEL_NMS, AEJ_STAGE_HYSTERESIS, AEJ_STAGE_QUADTREE, AEJ_STAGE_DCT_2, AEJ_STAGE_DCT_4, AEJ_STAGE_DCT_8,
-    AEJ_STAGE_DCT_16, AEJ_STAGE_DCT_32, AEJ_STAGE_DCT_64, AEJ_STAGE_DCT_128, AEJ_STAGE_DCT_256, AEJ_N_STAGES
+    AEJ_STAGE_DCT_16, AEJ_STAGE_DCT_32, AEJ_STAGE_DCT_64, AEJ_STAGE_DCT_128, AEJ_STAGE_DCT_256, AEJ_STAGE_DCT_512, AEJ_STAGE_DCT_1024,
+    AEJ_N_STAGES
 };
 /* Diagnostic: aej_encode_batch enqueues (passes + margin) hysteresis passes without reading back and verifies convergence
  * with its final synchronisation (falling back to the verified loop and redoing quadtree + DCT when they were too few).

@@ -113,3 +113,25 @@ def encode_image(rgb, space="YCoCg", qrange=(40, 80), brange=(4, 64)):
         out.append({"root_size": roots[i], "states": np.asarray(states_per_layer[i], np.uint8),
                     "leaves": np.array([[n.x, n.y, n.size] for n in leaves_per_layer[i]], np.int32).reshape(-1, 3), "coeffs": coeffs})
     return out
+
+
+def fan_out(images, space, qrange, brange, workers):
+    """one image per worker PROCESS over the host cores, as the reference's sweep does
+    (test/analysis/metrics_computation.py:253, a process pool with one ``Jpeg`` per worker).  Fresh interpreters (no fork of
+    the calling process, which may hold a GPU context); every worker loads its image from a shared .npy, encodes it with
+    encode_image() above and exits.  Returns the wall seconds from the first spawn to the last exit."""
+    import os, subprocess, sys, tempfile, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "imgs.npy")
+        np.save(path, np.ascontiguousarray(images, dtype=np.float32))
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from oracle import reference_structured as RS; "
+                "im = np.load(%r, mmap_mode='r')[int(sys.argv[1])]; RS.encode_image(np.array(im), %r, %r, %r)" % (root, path, space, tuple(qrange), tuple(brange)))
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(i)], env=dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1"))
+                 for i in range(min(workers, len(images)))]
+        rcs = [p.wait() for p in procs]
+        dt = time.perf_counter() - t0
+    if any(rcs):
+        raise RuntimeError(f"reference-structured worker failed: exit codes {rcs}")
+    return dt, len(procs)

@@ -480,10 +480,12 @@ def test_device_round_trip_matches_oracle(A, oracle, space, H, W, br):
     assert np.array_equal(A.Jpeg(A.JpegCompressionSettings()).decompress(data).data, dec[0])
 
 
-@pytest.mark.parametrize("space,H,W,br", [("YCbCr", 600, 800, (8, 256)), ("YCoCg", 530, 520, (4, 256)), ("OKLAB", 300, 700, (256, 256))])
+@pytest.mark.parametrize("space,H,W,br", [("YCbCr", 600, 800, (8, 256)), ("YCoCg", 530, 520, (4, 256)), ("OKLAB", 300, 700, (256, 256)),
+                                         ("YCbCr", 1100, 1300, (8, 512)), ("YCoCg", 640, 1500, (512, 512)), ("YCbCr", 1200, 2300, (8, 1024))])
 def test_block_size_256(A, oracle, space, H, W, br):
-    """The GUI's largest block (main_frame.py block-size slider): 256 x 256 leaves, whole and clipped at the plane border
-    (np.pad reflect), through the tiled big-block kernels -- encode and decode against the oracle."""
+    """The GUI's largest block (main_frame.py block-size slider) and the larger powers of two the reference's Jpeg itself accepts
+    (jpeg.py:216-219): 256 / 512 / 1024 leaves, whole and clipped at the plane border (np.pad reflect), through the tiled
+    big-block kernels -- encode and decode against the oracle."""
     img = oracle.synth_image(H, W, 3, "flat").astype(np.float32) / np.float32(255.0)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
     img = img + (0.05 * np.sin(xx / 90.0) * np.cos(yy / 70.0))[..., None].astype(np.float32)      # smooth, no edges
@@ -492,7 +494,7 @@ def test_block_size_256(A, oracle, space, H, W, br):
     codec = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), br))
     enc = codec.compress_batch(img[None], want_dct=True)
     ref = oracle.encode_image(img, space, (40, 80), br)
-    assert any(256 in set(ref[l]["leaves"][:, 2].tolist()) for l in range(3))
+    assert any(br[1] in set(ref[l]["leaves"][:, 2].tolist()) for l in range(3))
     for l in range(3):
         got = enc.layer(0, l)
         assert np.array_equal(got["states"], ref[l]["states"]) and np.array_equal(got["leaves"], ref[l]["leaves"])
@@ -505,6 +507,8 @@ def test_block_size_256(A, oracle, space, H, W, br):
 def test_unsupported_inputs_fail_loudly(A):
     codec = A.Jpeg(A.JpegCompressionSettings("YCbCr"))
     with pytest.raises(NotImplementedError):
-        A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 512))).compress_batch(np.zeros((1, 64, 64, 3), np.float32))
+        A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (16, 2048))).compress_batch(np.zeros((1, 64, 64, 3), np.float32))   # no kernel above 1024
+    with pytest.raises(NotImplementedError):
+        A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (2, 512))).compress_batch(np.zeros((1, 64, 64, 3), np.float32))     # more than 8 sizes
     with pytest.raises(ValueError):
         codec.compress_batch(np.zeros((64, 64, 3), np.float32))
