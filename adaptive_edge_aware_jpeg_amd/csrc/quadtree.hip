@@ -300,6 +300,29 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
         }
     }
     const ChunkEdges E = chunk_edges(g, q, l, b, edge_bits, chunk, lane);
+    if (!E.e4 && (q.cell << 4) <= q.bmax) {
+        // A chunk without a single edge pixel whose own size does not exceed the maximum block: no node inside it splits, so
+        // the only cell that can originate anything is the chunk's first one (the chunk itself as a leaf, or as the origin of a
+        // larger node: the general walk, on lane 0 alone).  No sibling tests, no wave reductions -- this is every chunk of a
+        // flat region (41 % of the bench planes' area).
+        CellNodes z[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { z[i].nsym = 0; z[i].syms = 0; z[i].leaf_lvl = -1; }
+        if (lane == 0 && (long long)chunk * 256 < ncell2) {
+            int ccx, ccy;
+            morton_decode(chunk, ccx, ccy);
+            z[0] = eval_cell(q, l, g.w[l], g.h[l], E, pyr, chunk * 256u, ccx * 16, ccy * 16);
+        }
+        lane_code[((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * 64 + lane] = (unsigned short)pack_lane(z);
+        if (lane == 0) {
+            int *o = chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
+            const int lv = z[0].leaf_lvl, sz = lv >= 0 ? q.cell << lv : 0;
+            o[0] = z[0].nsym; o[1] = lv >= 0 ? 1 : 0; o[2] = sz * sz; o[3] = 0;
+#pragma unroll
+            for (int k = 0; k < kMaxSizes; k++) o[4 + k] = (k == lv) ? 1 : 0;
+        }
+        return;
+    }
     int nsym = 0, nleaf = 0, ncoef = 0;
     int nsz[kMaxSizes];
 #pragma unroll
@@ -404,7 +427,8 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
     const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
     CellNodes c[4];
     const unsigned code = qb.lane_code[((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * 64 + lane];
-    if (!__any(code != 0)) return;        // nothing originates in this chunk (about half of the root square lies outside the plane)
+    const unsigned long long originators = __ballot(code != 0);
+    if (originators == 0) return;         // nothing originates in this chunk (about half of the root square lies outside the plane)
     unpack_lane(code, chunk * 256u + (unsigned)lane * 4u, q.ltot[l], c);
     int ccx, ccy, lx, ly;
     morton_decode(chunk, ccx, ccy);
@@ -417,18 +441,20 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
         if (c[i].leaf_lvl >= 0) { nleaf++; int s = q.cell << c[i].leaf_lvl; ncoef += s * s; }
         if (c[i].leaf_lvl == 0) n0++;
     }
-    // one scan for the three small counters (prefix sums < 1024 each), one for the coefficient offsets
-    const int pk = nsym | nleaf << 10 | n0 << 20;
-    const int pks = wave_incl_scan(pk, lane) - pk;
-    int sym_pos = coff[0] + (pks & 1023);
-    int leaf_pos = coff[1] + ((pks >> 10) & 1023);
-    int rank0 = (pks >> 20) & 1023;
-    int coef_pos = coff[2] + wave_incl_scan(ncoef, lane) - ncoef;
-    const int big = c[0].leaf_lvl;                     // > 0 when this lane holds a leaf larger than a cell
-    int rank_big = 0;
-    for (int k = 1; k < q.nsizes; k++) {
-        unsigned long long m = __ballot(big == k);
-        if (big == k) rank_big = __popcll(m & ((1ull << lane) - 1ull));
+    int sym_pos = coff[0], leaf_pos = coff[1], rank0 = 0, coef_pos = coff[2], rank_big = 0;
+    if (originators != 1ull) {            // (lane 0 alone -- a chunk without edges, k_qt_count's short path -- starts at the chunk's offsets)
+        // one scan for the three small counters (prefix sums < 1024 each), one for the coefficient offsets
+        const int pk = nsym | nleaf << 10 | n0 << 20;
+        const int pks = wave_incl_scan(pk, lane) - pk;
+        sym_pos += pks & 1023;
+        leaf_pos += (pks >> 10) & 1023;
+        rank0 = (pks >> 20) & 1023;
+        coef_pos += wave_incl_scan(ncoef, lane) - ncoef;
+        const int big = c[0].leaf_lvl;                     // > 0 when this lane holds a leaf larger than a cell
+        for (int k = 1; k < q.nsizes; k++) {
+            unsigned long long m = __ballot(big == k);
+            if (big == k) rank_big = __popcll(m & ((1ull << lane) - 1ull));
+        }
     }
 
     unsigned char *st = qb.states + (long long)b * q.state_stride + q.state_off[l];
