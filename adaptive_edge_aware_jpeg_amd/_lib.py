@@ -57,6 +57,10 @@ SIGNATURES = {
     "aej_set_hysteresis_speculation": (_I, [_P, _I]),
     "aej_get_hysteresis_stats": (_I, [_P, _P]),
     "aej_set_graph_mode": (_I, [_P, _I]),
+    "aej_set_sub_batches": (_I, [_P, _I]),
+    "aej_encode_batch_begin": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _U64]),
+    "aej_encode_batch_end": (_I, [_P]),
+    "aej_get_split_calls": (ctypes.c_int64, [_P]),
     "aej_get_graph_stats": (_I, [_P, _P]),
     "aej_last_hysteresis_passes": (_I, [_P]),
     "aej_set_hysteresis_hint": (_I, [_P, _I, _I]),
@@ -183,6 +187,13 @@ class Context:
         lo, hi, clip, sc, ss, l2 = params
         v = CannyParams(float(lo), float(hi), float(clip), float(sc), float(ss), 1 if l2 else 0)
         self.check(self.lib.aej_set_canny_params(self.handle, ctypes.cast(ctypes.pointer(v), ctypes.c_void_p)))
+
+    def set_sub_batches(self, n):
+        """0 = automatic (default), 1 = never split a call, 2..8 = that many sub-batches on private streams (include/aej.h)"""
+        self.check(self.lib.aej_set_sub_batches(self.handle, int(n)))
+
+    def split_calls(self):
+        return int(self.lib.aej_get_split_calls(self.handle))
 
     def set_graph_mode(self, mode):
         """0 = never replay a captured hipGraph (default), 1 = automatic (small calls), 2 = whenever possible (include/aej.h)"""

@@ -16,6 +16,7 @@
 
 using namespace aej;
 
+struct aej_pending;
 struct aej_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -52,6 +53,22 @@ struct aej_ctx {
     };
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0, n_graph_launches = 0, n_graph_captures = 0;
+    // sub-batch pipelining (aej_set_sub_batches): a large call is cut into sub-batches that run the whole chain on private streams,
+    // each one stage behind the previous, so that HBM-bound stages (colour planes, DCT) of one run beside the issue-bound stages
+    // (blur, Sobel / NMS, quadtree) of another
+    int sub_mode = 0;                  // 0 automatic, 1 never split, n > 1 split into n (when the batch allows)
+    static constexpr int kMaxSub = 8;
+    hipStream_t sub_stream[kMaxSub] = {};
+    hipEvent_t sub_color_done[kMaxSub] = {}, sub_in = nullptr;
+    int *sub_flag[kMaxSub] = {};       // pinned read-back words per sub-batch (layout of h_flag)
+    long long n_split_calls = 0;
+    int sub_chain = -1;                // colour stages wait for a stage of the previous part (g_last_color_done): 1 its colour stage, 2 its blur, 3 its
+                                       // Sobel / NMS; 0 no staggering; -1 (default) = 1 between the sub-batches of one call, 2 between whole calls --
+                                       // measured best of each (64 x 4K: sub-batches 8.1 / 8.35 / 8.35 / 8.4 ms for 1 / 2 / 3 / 0, two contexts
+                                       // 8.0 / 7.8 / 7.9 / 8.4).  AEJ_SUB_CHAIN overrides (tuning knob).
+    int chain_hook = 0;                // run_canny_chain publishes chain_event after the blur (2) / Sobel (3) stage of the part being enqueued
+    hipEvent_t chain_event = nullptr;
+    struct aej_pending *pending = nullptr;     // the call between aej_encode_batch_begin and aej_encode_batch_end
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;
     hipEvent_t ev[24] = {};
@@ -94,6 +111,19 @@ static void collect_marks(aej_ctx *ctx)
         if (hipEventElapsedTime(&ms, ctx->ev[i - 1], ctx->ev[i]) == hipSuccess && ctx->ev_stage[i] >= 0) ctx->stage_ms[ctx->ev_stage[i]] += ms;
     }
 }
+
+// The colour stage of every encode part (a whole call or a sub-batch) waits for the colour stage of the part enqueued before it on
+// the same device -- by any context -- and publishes its own completion here.  Within one call this staggers the sub-batches;
+// across contexts it keeps two calls in flight out of phase (begun together they would run their HBM-bound stages side by side
+// and their issue-bound stages side by side, which gains nothing; one stage apart, colour planes / DCT of one run beside blur /
+// Sobel of the other).  Waiting on an event that has long completed costs nothing.
+#include <mutex>
+static std::mutex g_chain_mutex;
+static hipEvent_t g_last_color_done[64] = {};      // per device; owned by the context that recorded it
+static int g_calls_in_flight[64] = {};             // per device: calls between aej_encode_batch_begin and _end (guarded by g_chain_mutex)
+
+static void free_pending(aej_ctx *ctx);      // defined with aej_pending
+static bool call_in_flight(const aej_ctx *ctx);
 
 static void drop_graphs(aej_ctx *ctx)
 {
@@ -322,6 +352,7 @@ extern "C" aej_ctx *aej_create(int device, void *hip_stream)
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
+    if (const char *e = getenv("AEJ_SUB_CHAIN")) ctx->sub_chain = atoi(e);      // tuning knob of the sub-batch pipelining (tools/profiling)
     return ctx;
 }
 
@@ -329,11 +360,28 @@ extern "C" void aej_destroy(aej_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (call_in_flight(ctx)) {
+        (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lock(g_chain_mutex);
+        if (ctx->device < 64 && g_calls_in_flight[ctx->device] > 0) g_calls_in_flight[ctx->device]--;
+    }
+    free_pending(ctx);
+    {
+        std::lock_guard<std::mutex> lock(g_chain_mutex);
+        for (int i = 0; i < aej_ctx::kMaxSub; i++)
+            if (ctx->sub_color_done[i] && ctx->device < 64 && g_last_color_done[ctx->device] == ctx->sub_color_done[i]) g_last_color_done[ctx->device] = nullptr;
+    }
     drop_graphs(ctx);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
     if (ctx->gevent) (void)hipEventDestroy(ctx->gevent);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->d_bilateral) (void)hipFree(ctx->d_bilateral);
+    for (int i = 0; i < aej_ctx::kMaxSub; i++) {
+        if (ctx->sub_stream[i]) (void)hipStreamDestroy(ctx->sub_stream[i]);
+        if (ctx->sub_color_done[i]) (void)hipEventDestroy(ctx->sub_color_done[i]);
+        if (ctx->sub_flag[i]) (void)hipHostFree(ctx->sub_flag[i]);
+    }
+    if (ctx->sub_in) (void)hipEventDestroy(ctx->sub_in);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int i = 0; i < 24; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
@@ -368,6 +416,7 @@ static void zigzag_order(int s, std::vector<int> &zz)
 extern "C" int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, const int32_t *qmats_host)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "aej_set_settings between aej_encode_batch_begin and aej_encode_batch_end");
     if (space < 0 || space > 6) return fail(ctx, AEJ_ERR_ARG, "Unsupported color space id: %d", space);
     if (!is_pow2(bmin) || !is_pow2(bmax) || bmin > bmax || bmin < 2)
         return fail(ctx, AEJ_ERR_ARG, "block size range (%d, %d): powers of two with 2 <= min <= max required", bmin, bmax);
@@ -472,6 +521,7 @@ static void apply_canny_params(const aej_ctx *ctx, CannyBuffers &cb)
 extern "C" int aej_set_canny_params(aej_ctx *ctx, const aej_canny_params *p)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "aej_set_canny_params between aej_encode_batch_begin and aej_encode_batch_end");
     const aej_canny_params def = { 0.10, 0.30, 0.75, 75.0, 75.0, 1 };
     const aej_canny_params v = p ? *p : def;
     if (!(v.canny_low_ratio >= 0.0 && v.canny_low_ratio <= 1.0 && v.canny_high_ratio >= 0.0 && v.canny_high_ratio <= 1.0))
@@ -532,12 +582,18 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool specula
     launch_clahe_pad_hist(st, g, w.cb);
     launch_clahe_lut(st, g, w.cb);
     mark(ctx, AEJ_STAGE_CLAHE_LUT);
+    auto publish = [&]() {
+        std::lock_guard<std::mutex> lock(g_chain_mutex);
+        if (hipEventRecord(ctx->chain_event, st) == hipSuccess && ctx->device < 64) g_last_color_done[ctx->device] = ctx->chain_event;
+    };
     launch_clahe_blur(st, g, w.cb);
     mark(ctx, AEJ_STAGE_CLAHE_BLUR);
+    if (ctx->chain_hook == 2) publish();
     launch_thresholds(st, g, w.cb);
     mark(ctx, AEJ_STAGE_THRESHOLDS);
     launch_sobel_nms(st, g, w.cb);
     mark(ctx, AEJ_STAGE_SOBEL_NMS);
+    if (ctx->chain_hook == 3) publish();
     int rc = run_hysteresis(ctx, g, w, speculate);
     if (rc) return rc;
     mark(ctx, AEJ_STAGE_HYSTERESIS);
@@ -668,6 +724,8 @@ static void carve_encode(void *base, const Geom &g, const QtGeom &q, EncodeWs &w
     w.bytes = (c.off + 255) & ~255ull;
 }
 
+static unsigned long long sub_ws_bytes(Geom g, const QtGeom &q, int nsub);      // sub-batch pipelining, below
+
 static int check_encode_args(aej_ctx *ctx, int batch, int H, int W)
 {
     if (!ctx) return AEJ_ERR_ARG;
@@ -696,6 +754,10 @@ extern "C" int aej_encode_plan(aej_ctx *ctx, int batch, int H, int W, aej_plan *
     }
     plan->coeff_stride = q.coeff_stride; plan->leaf_stride = q.leaf_stride; plan->state_stride = q.state_stride;
     plan->workspace_bytes = w.bytes;
+    // a call that is cut into sub-batches uses one slice per sub-batch (their fixed parts make the sum slightly larger); with the
+    // automatic mode the decision can change with later settings, so the plan covers every split the context could choose
+    for (int n = 2; n <= aej_ctx::kMaxSub && n <= batch; n++)
+        plan->workspace_bytes = std::max<uint64_t>(plan->workspace_bytes, sub_ws_bytes(g, q, n) * (unsigned long long)n);
     return 0;
 }
 
@@ -730,15 +792,21 @@ static int enqueue_readback(aej_ctx *ctx, EncodeWs &w, int n_spec)
     return 0;
 }
 
-// after the final synchronisation of a speculative call: did the edge map reach its fix-point within the n passes?  Updates the
-// hint / margin for the next call; returns true when the hysteresis has to be finished and quadtree + DCT redone.
-static bool speculation_missed(aej_ctx *ctx, int n)
+// after the final synchronisation of a speculative call: did the edge map reach its fix-point within the n passes whose work-list
+// sizes are pc[0..n]?  -> passes actually needed, or -1 (the hysteresis has to be finished and quadtree + DCT redone)
+static int speculation_used(const int *pc, int n)
 {
-    const int *pc = ctx->h_flag + 1;
+    if (pc[n] != 0) return -1;
+    int used = n;
+    while (used > 1 && pc[used - 1] == 0) used--;
+    return used;
+}
+
+// hint / margin for the next call from this call's outcome: `used` = passes needed (the largest over the sub-batches), or -1 = miss
+static void speculation_update(aej_ctx *ctx, int n, int used)
+{
     ctx->n_spec_calls++;
-    if (pc[n] == 0) {                       // converged within the speculative passes: remember how many were needed
-        int used = n;
-        while (used > 1 && pc[used - 1] == 0) used--;
+    if (used >= 0) {                        // converged within the speculative passes: remember how many were needed
         ctx->hyst_hint = used;
         ctx->last_hyst_passes = used;
         if (n - used >= 2) {
@@ -746,12 +814,18 @@ static bool speculation_missed(aej_ctx *ctx, int n)
         } else {
             ctx->hyst_streak = 0;
         }
-        return false;
+        return;
     }
     ctx->hyst_streak = 0;
     ctx->n_spec_misses++;
     if (ctx->hyst_margin < 8) ctx->hyst_margin += 2;
-    return true;
+}
+
+static bool speculation_missed(aej_ctx *ctx, int n)
+{
+    const int used = speculation_used(ctx->h_flag + 1, n);
+    speculation_update(ctx, n, used);
+    return used < 0;
 }
 
 constexpr long long kGraphAutoPixels = 8LL << 20;      // automatic graph mode: calls of at most 8 Mpx (launch latency matters there)
@@ -845,58 +919,256 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
     return 0;
 }
 
-static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
-                             uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
+// ---- sub-batch pipelining ------------------------------------------------------------------------------------
+// How many sub-batches a call is cut into.  Automatic: 2 for calls of at least 64 Mpx and 8 images (measured on 64 x 4K: 8.6 ->
+// 8.1 ms; 4 sub-batches 8.4 ms; smaller calls have too few workgroups per kernel to share the chip).  Never for profiled calls (the
+// stage timings describe the serial chain), graph replay, the verified (host-synchronising) hysteresis loop, or shapes that need the
+// host-built INTER_AREA tables.
+static int sub_batches(const aej_ctx *ctx, const Geom &g)
 {
+    if (ctx->sub_mode == 1 || ctx->profiling || ctx->graph_mode == 2 || !planes_fast_ok(g) || !ctx->hyst_speculate) return 1;
+    int n = ctx->sub_mode;
+    if (n == 0) {
+        // automatic: two sub-batches for a large call that has the device to itself; a caller that keeps calls in flight on other
+        // contexts (aej_encode_batch_begin / _end) already fills the gaps, and more than two chains side by side measured slower
+        bool alone;
+        { std::lock_guard<std::mutex> lock(g_chain_mutex); alone = ctx->device >= 64 || g_calls_in_flight[ctx->device] == 0; }
+        n = (alone && (long long)g.B * g.H * g.W >= (64LL << 20) && g.B >= 8) ? 2 : 1;
+    }
+    if (n > aej_ctx::kMaxSub) n = aej_ctx::kMaxSub;
+    if (n > g.B) n = g.B;
+    return n;
+}
+
+static unsigned long long encode_ws_bytes(const Geom &g, const QtGeom &q)
+{
+    EncodeWs w;
+    carve_encode(nullptr, g, q, w);
+    return w.bytes;
+}
+
+// bytes of the workspace slice of one sub-batch (sized for the largest of them)
+static unsigned long long sub_ws_bytes(Geom g, const QtGeom &q, int nsub)
+{
+    g.B = (g.B + nsub - 1) / nsub;
+    return encode_ws_bytes(g, q);
+}
+
+// One call in flight: everything aej_encode_batch_end needs to verify (and, after a speculation miss, repair) what
+// aej_encode_batch_begin enqueued.  Part 0 is the whole batch on the context's stream, or parts 0..n-1 are the sub-batches.
+struct EncodePart { Geom g; EncodeWs w; bool whole_call = false; int n_spec = 0; int32_t *coeffs = nullptr; float *dct = nullptr; hipStream_t stream = nullptr; int *flag = nullptr; bool used = false; };
+struct aej_pending {
+    bool active = false, complete = false;     // complete: already synchronised and verified (graph replay)
+    QtGeom q;
+    std::vector<EncodePart> parts;
+};
+
+static void free_pending(aej_ctx *ctx) { delete ctx->pending; ctx->pending = nullptr; }
+
+static bool call_in_flight(const aej_ctx *ctx) { return ctx->pending && ctx->pending->active; }
+
+static aej_pending &pending_of(aej_ctx *ctx)
+{
+    if (!ctx->pending) ctx->pending = new aej_pending;
+    return *ctx->pending;
+}
+
+// the launch sequence of one part on ctx->stream / ctx->h_flag (both set by the caller): clear, colour planes, Canny chain with the
+// speculative hysteresis, quadtree, DCT, counter read-back.  `after` / `done`: sub-batch staggering (null for the unsplit call).
+static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void *rgb, bool in_u8, hipEvent_t done)
+{
+    int rc;
+    mark(ctx, -1);
+    if ((rc = clear_canny_ws(ctx, p.w.canny))) return rc;
+    mark(ctx, AEJ_STAGE_CLEAR);
+    // one stage behind the part enqueued before this one (g_last_color_done): its colour stage (HBM-bound) has finished, its blur
+    // (issue-bound) is starting
+    const bool chain = ctx->sub_chain && done && ctx->device < 64 && !ctx->profiling;
+    const int chain_mode = ctx->sub_chain > 0 ? ctx->sub_chain : (p.whole_call ? 2 : 1);
+    if (chain) {
+        std::lock_guard<std::mutex> lock(g_chain_mutex);
+        if (hipEvent_t after = g_last_color_done[ctx->device]) AEJ_HIP_CHECK(hipStreamWaitEvent(ctx->stream, after, 0));
+    }
+    if ((rc = run_color_planes(ctx, rgb, in_u8, p.g, nullptr, p.w.norm, p.w.canny.cb.u8a, p.w.canny.cb.tile_hist, p.w.area_tabs))) return rc;
+    mark(ctx, AEJ_STAGE_COLOR_PLANES);
+    auto publish = [&]() -> int {
+        std::lock_guard<std::mutex> lock(g_chain_mutex);
+        AEJ_HIP_CHECK(hipEventRecord(done, ctx->stream));
+        g_last_color_done[ctx->device] = done;
+        return 0;
+    };
+    if (chain && chain_mode == 1 && (rc = publish())) return rc;
+    ctx->chain_hook = (chain && chain_mode > 1) ? chain_mode : 0;
+    ctx->chain_event = done;
+    if ((rc = run_canny_chain(ctx, p.g, p.w.canny, true))) return rc;      // first call (no hint yet): verified loop, synchronises this stream
+    ctx->chain_hook = 0;
+    p.n_spec = ctx->hyst_enqueued;
+    if ((rc = enqueue_back(ctx, p.g, q, p.w, p.coeffs, p.dct))) return rc;
+    return enqueue_readback(ctx, p.w, p.n_spec);      // one read-back for the whole part
+}
+
+static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                             uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes, bool &started)
+{
+    started = false;            // true once this call has put something in flight (then aej_encode_batch_end has to follow, also after an error)
     int rc = check_encode_args(ctx, batch, H, W);
     if (rc) return rc;
     if (!rgb || !coeffs || !leaves || !states || !counts || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    aej_pending &pd = pending_of(ctx);
+    if (pd.active) return fail(ctx, AEJ_ERR_STATE, "aej_encode_batch_begin: the previous call has not been ended (aej_encode_batch_end)");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
     Geom g;
-    QtGeom q;
     if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
-    if ((rc = make_qtgeom(ctx, g, ctx->bmin, ctx->bmax, q))) return rc;
-    EncodeWs w;
-    carve_encode(workspace, g, q, w);
-    if (w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", w.bytes, (unsigned long long)workspace_bytes);
-    hipStream_t st = ctx->stream;
+    if ((rc = make_qtgeom(ctx, g, ctx->bmin, ctx->bmax, pd.q))) return rc;
+    const QtGeom &q = pd.q;
     if ((rc = ensure_canny_tables(ctx))) return rc;
-    apply_canny_params(ctx, w.canny.cb);
-    w.qt.qb.leaves = leaves;
-    w.qt.qb.states = states;
-    w.qt.qb.counts = reinterpret_cast<long long *>(counts);
     ctx->n_ev = 0;
     ctx->n_encode_calls++;
+    const int nsub = sub_batches(ctx, g);
+    pd.parts.assign((size_t)nsub, EncodePart());
+    pd.complete = false;
+    hipStream_t user = ctx->stream;
+    int *user_flag = ctx->h_flag;
 
-    bool graphed = false;
-    const bool want_graph = ctx->graph_mode != 0 && !ctx->profiling && (hyst_small(g) || (ctx->hyst_speculate && ctx->hyst_hint > 0)) && planes_fast_ok(g) &&
-                            (ctx->graph_mode == 2 || (long long)batch * H * W <= kGraphAutoPixels);
-    if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, g, q, w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) return rc;
-    if (!graphed) {
-        mark(ctx, -1);
-        if ((rc = clear_canny_ws(ctx, w.canny))) return rc;
-        mark(ctx, AEJ_STAGE_CLEAR);
-        if ((rc = run_color_planes(ctx, rgb, in_u8, g, nullptr, w.norm, w.canny.cb.u8a, w.canny.cb.tile_hist, w.area_tabs))) return rc;
-        mark(ctx, AEJ_STAGE_COLOR_PLANES);
-        if ((rc = run_canny_chain(ctx, g, w.canny, true))) return rc;
-        if ((rc = enqueue_back(ctx, g, q, w, coeffs, dct_f32))) return rc;
-        // one read-back for the whole call
-        if ((rc = enqueue_readback(ctx, w, ctx->hyst_enqueued))) return rc;
-        AEJ_HIP_CHECK(hipStreamSynchronize(st));
+    if (nsub == 1) {
+        EncodePart &p = pd.parts[0];
+        p.g = g; p.coeffs = coeffs; p.dct = dct_f32; p.stream = user; p.flag = user_flag; p.n_spec = 0; p.used = true; p.whole_call = true;
+        carve_encode(workspace, g, q, p.w);
+        if (p.w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", p.w.bytes, (unsigned long long)workspace_bytes);
+        apply_canny_params(ctx, p.w.canny.cb);
+        p.w.qt.qb.leaves = leaves;
+        p.w.qt.qb.states = states;
+        p.w.qt.qb.counts = reinterpret_cast<long long *>(counts);
+        bool graphed = false;
+        const bool want_graph = ctx->graph_mode != 0 && !ctx->profiling && (hyst_small(g) || (ctx->hyst_speculate && ctx->hyst_hint > 0)) && planes_fast_ok(g) &&
+                                (ctx->graph_mode == 2 || (long long)batch * H * W <= kGraphAutoPixels);
+        if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, g, q, p.w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) return rc;
+        if (graphed) { p.n_spec = ctx->hyst_enqueued; pd.complete = true; }      // the replay path has synchronised its own stream
+        else {
+            if (!ctx->sub_color_done[0]) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->sub_color_done[0], hipEventDisableTiming));
+            if ((rc = enqueue_part(ctx, p, q, rgb, in_u8, hyst_small(g) ? nullptr : ctx->sub_color_done[0]))) return rc;      // (latency-sized calls stay out of the chain)
+        }
+        pd.active = started = true;
+        { std::lock_guard<std::mutex> lock(g_chain_mutex); if (ctx->device < 64) g_calls_in_flight[ctx->device]++; }
+        return 0;
     }
-    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
-    const int n = ctx->hyst_enqueued;
-    if (n > 0 && speculation_missed(ctx, n)) {
-        // rare: the edge map was not at its fix-point when the quadtree ran -- finish the hysteresis, redo what follows
-        if ((rc = run_hysteresis(ctx, g, w.canny, false, n))) return rc;
-        if ((rc = enqueue_back(ctx, g, q, w, coeffs, dct_f32))) return rc;
-        if ((rc = enqueue_readback(ctx, w, 0))) return rc;
-        AEJ_HIP_CHECK(hipStreamSynchronize(st));
-        if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
+
+    // ---- sub-batches on private streams
+    const unsigned long long slice = sub_ws_bytes(g, q, nsub);
+    if (slice * (unsigned long long)nsub > workspace_bytes)
+        return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small for %d sub-batches: need %llu bytes, got %llu", nsub, slice * (unsigned long long)nsub,
+                    (unsigned long long)workspace_bytes);
+    for (int i = 0; i < nsub; i++) {
+        if (!ctx->sub_color_done[i]) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->sub_color_done[i], hipEventDisableTiming));
+        if (!ctx->sub_stream[i]) {
+            AEJ_HIP_CHECK(hipStreamCreateWithFlags(&ctx->sub_stream[i], hipStreamNonBlocking));
+            AEJ_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->sub_flag[i]), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault));
+        }
     }
+    if (!ctx->sub_in) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->sub_in, hipEventDisableTiming));
+    AEJ_HIP_CHECK(hipEventRecord(ctx->sub_in, user));          // inputs produced on the caller's stream are complete before any sub-batch reads them
+    ctx->n_split_calls++;
+    const size_t px_bytes = in_u8 ? 1 : sizeof(float);
+    for (int i = 0; i < nsub && !rc; i++) {
+        EncodePart &p = pd.parts[(size_t)i];
+        const int b0 = (int)((long long)g.B * i / nsub), b1 = (int)((long long)g.B * (i + 1) / nsub);
+        p.g = g;
+        p.g.B = b1 - b0;
+        p.n_spec = 0;
+        carve_encode(static_cast<char *>(workspace) + (size_t)i * slice, p.g, q, p.w);
+        apply_canny_params(ctx, p.w.canny.cb);
+        p.w.qt.qb.leaves = leaves + (long long)b0 * q.leaf_stride * 4;
+        p.w.qt.qb.states = states + (long long)b0 * q.state_stride;
+        p.w.qt.qb.counts = reinterpret_cast<long long *>(counts) + (long long)b0 * 12;
+        p.coeffs = coeffs + (long long)b0 * q.coeff_stride;
+        p.dct = dct_f32 ? dct_f32 + (long long)b0 * q.coeff_stride : nullptr;
+        p.stream = ctx->sub_stream[i];
+        p.flag = ctx->sub_flag[i];
+        p.used = true;
+        const void *in = static_cast<const char *>(rgb) + (size_t)b0 * g.H * g.W * 3 * px_bytes;
+        ctx->stream = p.stream;
+        ctx->h_flag = p.flag;
+        hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->sub_in, 0);
+        if (e != hipSuccess) rc = hip_fail(ctx, e, "hipStreamWaitEvent", __FILE__, __LINE__);
+        else rc = enqueue_part(ctx, p, q, in, in_u8, ctx->sub_color_done[i]);
+    }
+    ctx->stream = user;
+    ctx->h_flag = user_flag;
+    pd.active = started = true;  // also after an error: the caller drains whatever was enqueued
+    { std::lock_guard<std::mutex> lock(g_chain_mutex); if (ctx->device < 64) g_calls_in_flight[ctx->device]++; }
+    return rc;
+}
+
+// completion of the call in flight: every stream it used is drained (also after an error: nothing may still be running when the
+// caller sees the result), the counters are checked and a part whose speculative pass count was too small is repaired
+static int encode_end_impl(aej_ctx *ctx, int rc_begin)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    aej_pending &pd = pending_of(ctx);
+    if (!pd.active) return rc_begin ? rc_begin : fail(ctx, AEJ_ERR_STATE, "aej_encode_batch_end without a call in flight");
+    pd.active = false;
+    { std::lock_guard<std::mutex> lock(g_chain_mutex); if (ctx->device < 64 && g_calls_in_flight[ctx->device] > 0) g_calls_in_flight[ctx->device]--; }
+    (void)hipSetDevice(ctx->device);
+    hipStream_t user = ctx->stream;
+    int *user_flag = ctx->h_flag;
+    const QtGeom &q = pd.q;
+    int rc = rc_begin, used_max = 0, n_spec = 0;
+    bool missed = false;
+    for (EncodePart &p : pd.parts) {
+        if (!p.used) continue;                    // not reached by a failed begin
+        ctx->stream = p.stream;
+        ctx->h_flag = p.flag;
+        hipError_t e = pd.complete ? hipSuccess : hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess && !rc) rc = hip_fail(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
+        if (rc) continue;
+        if (*ctx->h_flag) { rc = fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass"); continue; }
+        if (p.n_spec > 0) {
+            n_spec = p.n_spec;
+            const int used = speculation_used(ctx->h_flag + 1, p.n_spec);
+            if (used < 0) {
+                // rare: this part's edge map was not at its fix-point when its quadtree ran -- finish the hysteresis, redo what follows
+                missed = true;
+                if (!(rc = run_hysteresis(ctx, p.g, p.w.canny, false, p.n_spec)) && !(rc = enqueue_back(ctx, p.g, q, p.w, p.coeffs, p.dct)) &&
+                    !(rc = enqueue_readback(ctx, p.w, 0))) {
+                    e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess) rc = hip_fail(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
+                    else if (*ctx->h_flag) rc = fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
+                }
+                used_max = std::max(used_max, ctx->last_hyst_passes);
+            } else {
+                used_max = std::max(used_max, used);
+            }
+        } else {
+            used_max = std::max(used_max, ctx->last_hyst_passes);     // verified loop / one-launch finish: run_hysteresis left the count there
+        }
+    }
+    ctx->stream = user;
+    ctx->h_flag = user_flag;
+    if (rc) return rc;
+    if (n_spec > 0) speculation_update(ctx, n_spec, missed ? -1 : used_max);
+    if (used_max > 0) { ctx->last_hyst_passes = used_max; if (n_spec > 0) ctx->hyst_hint = used_max; }
+    ctx->hyst_enqueued = n_spec;
     if (ctx->profiling) collect_marks(ctx);
     return 0;
 }
+
+static int encode_batch_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                             uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
+{
+    bool started;
+    const int rc = encode_begin_impl(ctx, rgb, in_u8, batch, H, W, coeffs, leaves, states, counts, dct_f32, workspace, workspace_bytes, started);
+    return started ? encode_end_impl(ctx, rc) : rc;
+}
+
+extern "C" int aej_encode_batch_begin(aej_ctx *ctx, const void *rgb, int rgb_is_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                                      uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
+{
+    bool started;
+    const int rc = encode_begin_impl(ctx, rgb, rgb_is_u8 != 0, batch, H, W, coeffs, leaves, states, counts, dct_f32, workspace, workspace_bytes, started);
+    return rc && started ? encode_end_impl(ctx, rc) : rc;      // a failed begin leaves nothing of its own in flight
+}
+
+extern "C" int aej_encode_batch_end(aej_ctx *ctx) { return encode_end_impl(ctx, 0); }
 
 extern "C" int aej_encode_batch(aej_ctx *ctx, const float *rgb, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
                                 uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes)
@@ -1330,6 +1602,15 @@ extern "C" int aej_set_graph_mode(aej_ctx *ctx, int mode)
     if (mode == 0) drop_graphs(ctx);
     return 0;
 }
+
+extern "C" int aej_set_sub_batches(aej_ctx *ctx, int n)
+{
+    if (!ctx || n < 0 || n > aej_ctx::kMaxSub) return AEJ_ERR_ARG;
+    ctx->sub_mode = n;
+    return 0;
+}
+
+extern "C" int64_t aej_get_split_calls(aej_ctx *ctx) { return ctx ? (int64_t)ctx->n_split_calls : -1; }
 
 extern "C" int aej_get_graph_stats(aej_ctx *ctx, int64_t *out_host)
 {

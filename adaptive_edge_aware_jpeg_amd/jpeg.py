@@ -123,6 +123,24 @@ class Jpeg:
             ctx.handle, x.data_ptr(), plan.batch, plan.H, plan.W, coeffs.data_ptr(), leaves.data_ptr(), states.data_ptr(),
             counts.data_ptr(), dct.data_ptr() if dct is not None else None, ws.data_ptr(), ctypes.c_uint64(plan.workspace_bytes)))
 
+    def encode_begin(self, ctx, x, plan, coeffs, leaves, states, counts, dct=None) -> None:
+        """First half of encode_into (``aej_encode_batch_begin``): enqueues the call and returns without waiting.  The buffers and
+        ``ctx`` belong to the call until ``encode_end(ctx)``; a second context (obtained under another ``torch.cuda.stream``)
+        with its own buffers can take the next batch meanwhile."""
+        ws = ctx.workspace(plan.workspace_bytes)
+        ctx._in_flight = (x, coeffs, leaves, states, counts, dct, ws)          # keep the tensors alive
+        ctx.check(ctx.lib.aej_encode_batch_begin(
+            ctx.handle, x.data_ptr(), 1 if x.dtype == ctx.torch.uint8 else 0, plan.batch, plan.H, plan.W, coeffs.data_ptr(), leaves.data_ptr(),
+            states.data_ptr(), counts.data_ptr(), dct.data_ptr() if dct is not None else None, ws.data_ptr(), ctypes.c_uint64(plan.workspace_bytes)))
+
+    @staticmethod
+    def encode_end(ctx) -> None:
+        """Second half (``aej_encode_batch_end``): waits for the call in flight on ``ctx`` and verifies it."""
+        try:
+            ctx.check(ctx.lib.aej_encode_batch_end(ctx.handle))
+        finally:
+            ctx._in_flight = None
+
     def compress(self, img: Image) -> bytes:
         """Compresses the input image (jpeg.py:240-272)."""
         if not isinstance(img, Image):

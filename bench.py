@@ -108,6 +108,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for cpu_baseline; 0 = min(available cores, 16)")
     ap.add_argument("--graph", type=int, choices=[0, 1, 2], default=0,
                     help="aej_set_graph_mode: 0 never replay a captured hipGraph (the library default), 1 automatic (calls of at most 8 Mpx), 2 whenever possible")
+    ap.add_argument("--sub-batches", type=int, default=0,
+                    help="aej_set_sub_batches: 0 automatic (the library default: 4 sub-batches on private streams for calls of at least 64 Mpx), 1 never, 2..8")
+    ap.add_argument("--pipeline", type=int, choices=[1, 2, 3, 4], default=2,
+                    help="contexts (each on its own stream, with its own output buffers and workspace) the timed steps rotate over: step i is "
+                         "enqueued with aej_encode_batch_begin on context i %% n after the step that used it before has been ended; 1 = blocking calls")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiler runs (tools/profiling/*.sh): only the W warm-up and K timed steps, so every kernel is launched a known "
                          "number of times; prints value / ms_per_step only")
@@ -227,31 +232,73 @@ def main():
     batches = batches_f32 if args.ingest == "f32" else [(x * 255.0).round().to(torch.uint8) for x in batches_f32]
 
     jpeg = A.Jpeg(A.JpegCompressionSettings(space, qrange, brange), device=local_rank)
-    ctx = jpeg._bind()
-    ctx.set_graph_mode(args.graph)
-    plan = ctx.plan(B, H, W)
-    coeffs = ctx.empty((B * plan.coeff_stride,), torch.int32)
-    leaves = ctx.empty((B * plan.leaf_stride, 4), torch.int32)
-    states = ctx.empty((B * plan.state_stride,), torch.uint8)
-    counts = ctx.empty((B, 3, 4), torch.int64)
 
-    def step(i):
+    class Pipe:
+        """one context on one stream with its own outputs (and, inside the context, its own workspace)"""
+        def __init__(self, stream):
+            self.stream = stream
+            with torch.cuda.stream(stream):
+                self.ctx = jpeg._bind()
+                self.ctx.set_graph_mode(args.graph)
+                self.ctx.set_sub_batches(args.sub_batches)
+                self.plan = self.ctx.plan(B, H, W)
+                self.out = (self.ctx.empty((B * self.plan.coeff_stride,), torch.int32), self.ctx.empty((B * self.plan.leaf_stride, 4), torch.int32),
+                            self.ctx.empty((B * self.plan.state_stride,), torch.uint8), self.ctx.empty((B, 3, 4), torch.int64))
+            self.pending = False
+            self.input = 0
+
+        def end(self):
+            if self.pending:
+                self.pending = False
+                with torch.cuda.stream(self.stream):
+                    jpeg.encode_end(self.ctx)
+
+        def begin(self, which):
+            self.end()
+            with torch.cuda.stream(self.stream):
+                jpeg.encode_begin(self.ctx, batches[which], self.plan, *self.out)
+            self.pending, self.input = True, which
+
+    pipes = [Pipe(torch.cuda.current_stream(dev))] + [Pipe(torch.cuda.Stream(device=dev)) for _ in range(args.pipeline - 1)]
+    torch.cuda.synchronize()
+    ctx, plan = pipes[0].ctx, pipes[0].plan
+    coeffs, leaves, states, counts = pipes[0].out
+    n_pipe = len(pipes)
+
+    def input_of(i):
+        # inputs alternate on EVERY context (a context that saw the same batch each time could never miss its hysteresis hint)
+        return (i // n_pipe + i) & 1
+
+    def step(i):                       # throughput loop: enqueue step i on context i % n; the step that used it before is ended first
+        pipes[i % n_pipe].begin(input_of(i))
+
+    def serial_step(i):                # one blocking call at a time on context 0
         jpeg.encode_into(ctx, batches[i & 1], plan, coeffs, leaves, states, counts)
 
     def sync():
+        for p in pipes:
+            p.end()
         torch.cuda.synchronize()
+
+    def hyst_stats():
+        tot = {}
+        for p in pipes:
+            for k, v in p.ctx.hysteresis_stats().items():
+                tot[k] = (tot.get(k, 0) + v) if k != "enqueued" else max(tot.get(k, 0), v)
+        return tot
 
     # ---- the measurement: W warm-up steps, then exactly K timed steps on alternating inputs, profiling off ----
     ctx.set_profiling(False)
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 2 * n_pipe)):       # every context has seen both inputs
         step(i)
-    h0 = ctx.hysteresis_stats()
+    sync()
+    h0 = hyst_stats()
     dt_local = timed_loop(torch, dist, step, args.steps, sync)
-    h1 = ctx.hysteresis_stats()
+    h1 = hyst_stats()
     px_total, dt = aggregate_throughput(dist, B * H * W * args.steps, dt_local, dev if backend == "nccl" else None)   # SUM of pixels, MAX of seconds
     value = px_total / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
-    last_batch = (args.steps - 1) & 1
+    last_pipe, last_batch = pipes[(args.steps - 1) % n_pipe], input_of(args.steps - 1)
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch", "value": round(value, 1), "unit": "MP/s",
@@ -268,7 +315,7 @@ def main():
         from oracle import oracle as O
         O.build()
         from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
-        enc = EncodedBatch(plan, coeffs, leaves, states, counts)
+        enc = EncodedBatch(last_pipe.plan, *last_pipe.out)
         picks = sorted({0, B - 1})
         with ThreadPoolExecutor(max_workers=len(picks)) as ex:
             refs = list(ex.map(lambda b: O.encode_image(batches_f32[last_batch][b].cpu().numpy(), space, qrange, brange), picks))
@@ -281,18 +328,22 @@ def main():
                     "what": "quadtree states, leaf table and quantised zigzag coefficients of all 3 layers, bit-exact vs the CPU oracle"}
 
     # ---- the same loop with the speculation off (verified hysteresis loop) ----
+    # ---- strictly serial figure: blocking calls on one context, nothing in flight between them ----
+    serial_step(0); serial_step(1)
+    dt_s = timed_loop(torch, dist, serial_step, args.steps, sync)
+    _, dt_s = aggregate_throughput(dist, 0, dt_s, dev if backend == "nccl" else None)
     ctx.set_speculation(False)
-    step(0); step(1)
-    dt_v = timed_loop(torch, dist, step, args.steps, sync)
+    serial_step(0); serial_step(1)
+    dt_v = timed_loop(torch, dist, serial_step, args.steps, sync)
     _, dt_v = aggregate_throughput(dist, 0, dt_v, dev if backend == "nccl" else None)
     ctx.set_speculation(True)
 
     # ---- per-stage times: separate, untimed, profiled steps (HIP events on the launch stream inside the library) ----
     ctx.set_profiling(True)
     stage_acc, n_prof = {}, 4
-    step(0); step(1)
+    serial_step(0); serial_step(1)
     for i in range(n_prof):
-        step(i)
+        serial_step(i)
         for k, v in ctx.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     ctx.set_profiling(False)
@@ -378,8 +429,16 @@ def main():
         "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "speculative_calls": h1["speculative"] - h0["speculative"],
                        "misses": h1["misses"] - h0["misses"], "passes_enqueued_last_call": h1["enqueued"],
                        "passes_needed_last_call": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle))},
+        "pipeline": {"contexts": n_pipe, "what": "timed step i is enqueued (aej_encode_batch_begin) on context i % n, each context on its own stream with its own "
+                                                  "output buffers and workspace, after the step that used that context before has been ended (aej_encode_batch_end: "
+                                                  "waited for and verified); all K steps are complete inside the timed region",
+                     "serial_ms_per_step": round(dt_s / args.steps * 1e3, 3),
+                     "serial_note": "the same K steps as blocking aej_encode_batch calls on one context (nothing in flight between calls)"},
         "verified_mode_ms_per_step": round(dt_v / args.steps * 1e3, 3),
         "graph": dict(ctx.graph_stats(), mode=args.graph),
+        "sub_batches": {"mode": args.sub_batches, "split_calls": sum(p.ctx.split_calls() for p in pipes),
+                        "note": "timed steps run as sub-batches on private streams when split_calls > 0; the per-stage times below come from separate, "
+                                "unsplit profiled steps (stages of different sub-batches overlap in the timed region, so they add up to more than ms_per_step)"},
         "whole_path": {"bytes_per_px": whole_bpp, "achieved_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4)},
         "stages": per_stage,
         "stage_ms_source": f"{n_prof} separate profiled steps after the timed region (sum {sum(stage_ms.values()):.3f} ms)",

@@ -101,6 +101,22 @@ AEJ_API int aej_get_hysteresis_stats(aej_ctx *ctx, int64_t *out_host);
  * the eager launches), 1 = automatic (calls of at most 8 Mpx), 2 = whenever possible.  The graph runs on a private stream ordered behind the context's
  * stream; results are identical.  out_host[3] = { graph launches, graph captures, graphs cached }. */
 AEJ_API int aej_set_graph_mode(aej_ctx *ctx, int mode);
+/* Throughput path: aej_encode_batch cuts a large call into sub-batches (contiguous image ranges, the unit the reference's sweep
+ * hands to one worker, metrics_computation.py:253) that run the whole chain on private streams, each one stage behind the previous,
+ * so that the HBM-bound stages of one sub-batch (colour planes, DCT) run beside the issue-bound stages of another (blur, Sobel / NMS,
+ * quadtree).  n = 0: automatic (the default: 2 sub-batches for calls of at least 64 Mpx and 8 images while no other context has a call
+ * in flight on the device), 1: never, 2..8: that many.
+ * Outputs are identical; the call still returns with everything complete.  aej_encode_plan's workspace_bytes covers every split. */
+AEJ_API int aej_set_sub_batches(aej_ctx *ctx, int n);
+/* The two halves of aej_encode_batch / aej_encode_batch_u8 (same arguments; rgb_is_u8 selects the ingest): _begin enqueues the whole
+ * call and returns without waiting, _end waits for it, checks the device-side counters and repairs a speculation miss.  One call may
+ * be in flight per context; until _end returns, the context's other entry points, the workspace and the output buffers must not be
+ * used.  Two contexts on two streams, each with its own buffers, keep the GPU busy across calls: while one call drains (hysteresis
+ * tail, DCT) the other's colour stage runs (bench.py times this pipeline; the strictly serial figure is reported beside it). */
+AEJ_API int aej_encode_batch_begin(aej_ctx *ctx, const void *rgb, int rgb_is_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
+                                   uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, uint64_t workspace_bytes);
+AEJ_API int aej_encode_batch_end(aej_ctx *ctx);
+AEJ_API int64_t aej_get_split_calls(aej_ctx *ctx);   /* calls since aej_create that ran as sub-batches */
 AEJ_API int aej_get_graph_stats(aej_ctx *ctx, int64_t *out_host);
 AEJ_API int aej_set_profiling(aej_ctx *ctx, int enable);
 AEJ_API int aej_get_stage_ms(aej_ctx *ctx, float *ms_host /* [AEJ_N_STAGES] */);

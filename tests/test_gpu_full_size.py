@@ -225,3 +225,106 @@ def test_graph_replay_path_matches_oracle(env, oracle):
         assert ctx.graph_stats()["launches"] - g2["launches"] >= 2
     finally:
         ctx.set_graph_mode(0)
+
+
+def _encode_raw(torch, ctx, codec, x, plan):
+    out = (ctx.empty((x.shape[0] * plan.coeff_stride,), torch.int32), ctx.empty((x.shape[0] * plan.leaf_stride, 4), torch.int32),
+           ctx.empty((x.shape[0] * plan.state_stride,), torch.uint8), ctx.empty((x.shape[0], 3, 4), torch.int64))
+    for t in out:
+        t.zero_()
+    codec.encode_into(ctx, x, plan, *out)
+    torch.cuda.synchronize()
+    return out
+
+
+def _assert_same_encoding(torch, plan, got, want, B, what):
+    assert torch.equal(got[3], want[3]), f"{what}: counts"
+    for im in range(B):
+        for l in range(3):
+            nc, nl, ns, _ = (int(v) for v in want[3][im, l])
+            c0, l0, s0 = im * plan.coeff_stride + plan.coeff_off[l], im * plan.leaf_stride + plan.leaf_off[l], im * plan.state_stride + plan.state_off[l]
+            assert torch.equal(got[0][c0:c0 + nc], want[0][c0:c0 + nc]), f"{what}: image {im} layer {l} coefficients"
+            assert torch.equal(got[1][l0:l0 + nl], want[1][l0:l0 + nl]), f"{what}: image {im} layer {l} leaves"
+            assert torch.equal(got[2][s0:s0 + ns], want[2][s0:s0 + ns]), f"{what}: image {im} layer {l} states"
+
+
+def test_sub_batch_pipelining_is_invisible(env, oracle):
+    """aej_set_sub_batches: a call cut into sub-batches on private streams (the throughput path of the 64 x 4K bench) returns what the
+    unsplit call returns -- even and uneven splits, float and 8-bit ingest, speculative hysteresis hit and miss inside sub-batches --
+    and image 0 / the last image equal the oracle."""
+    torch, A, bench = env
+    dev = torch.device("cuda", 0)
+    space, qr, br = "YCbCr", (40, 80), (4, 64)
+    B, H, W = 14, 1080, 1920                               # 2 sub-batches of 7 images = 5460 hysteresis tiles each: the per-pass (speculative) scheme
+    x = bench.synth_batch(torch, B, H, W, 31, dev)
+    codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
+    ctx = codec._bind()
+    plan = ctx.plan(B, H, W)
+    try:
+        ctx.set_sub_batches(1)
+        want = _encode_raw(torch, ctx, codec, x, plan)
+        want2 = _encode_raw(torch, ctx, codec, x, plan)     # second call: speculative
+        _assert_same_encoding(torch, plan, want2, want, B, "unsplit, speculative")
+        from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+        for im in (0, B - 1):
+            check_image(EncodedBatch(plan, *want), im, oracle.encode_image(x[im].cpu().numpy(), space, qr, br), f"unsplit image {im}")
+        for n in (2, 3, 4, 8):
+            ctx.set_sub_batches(n)
+            c0 = ctx.split_calls()
+            got = _encode_raw(torch, ctx, codec, x, plan)
+            assert ctx.split_calls() == c0 + 1
+            _assert_same_encoding(torch, plan, got, want, B, f"{n} sub-batches")
+        # a speculative pass count that is too small inside the sub-batches: detected per sub-batch and repaired
+        ctx.set_sub_batches(2)
+        s0 = ctx.hysteresis_stats()
+        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
+        got = _encode_raw(torch, ctx, codec, x, plan)
+        _assert_same_encoding(torch, plan, got, want, B, "2 sub-batches, forced miss")
+        assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 1
+        got = _encode_raw(torch, ctx, codec, x, plan)       # the hint has recovered
+        _assert_same_encoding(torch, plan, got, want, B, "2 sub-batches after the miss")
+        assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 1
+    finally:
+        ctx.set_sub_batches(0)
+
+
+def test_begin_end_on_two_contexts(env, oracle):
+    """aej_encode_batch_begin / _end: two contexts on two streams with a call in flight each return what the blocking call returns;
+    misuse (a second begin, settings while in flight, end without begin) is refused."""
+    torch, A, bench = env
+    from adaptive_edge_aware_jpeg_amd._lib import AejError
+    dev = torch.device("cuda", 0)
+    space, qr, br = "YCbCr", (40, 80), (4, 64)
+    B, H, W = 3, 720, 1280
+    xs = [bench.synth_batch(torch, B, H, W, seed, dev) for seed in (41, 42)]
+    codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
+    ctx0 = codec._bind()
+    plan = ctx0.plan(B, H, W)
+    want = [_encode_raw(torch, ctx0, codec, x, plan) for x in xs]
+    s1 = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s1):
+        ctx1 = codec._bind()
+        assert ctx1 is not ctx0
+        out1 = (ctx1.empty((B * plan.coeff_stride,), torch.int32), ctx1.empty((B * plan.leaf_stride, 4), torch.int32),
+                ctx1.empty((B * plan.state_stride,), torch.uint8), ctx1.empty((B, 3, 4), torch.int64))
+    out0 = (ctx0.empty((B * plan.coeff_stride,), torch.int32), ctx0.empty((B * plan.leaf_stride, 4), torch.int32),
+            ctx0.empty((B * plan.state_stride,), torch.uint8), ctx0.empty((B, 3, 4), torch.int64))
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        a, b = rnd & 1, (rnd + 1) & 1
+        codec.encode_begin(ctx0, xs[a], plan, *out0)
+        with torch.cuda.stream(s1):
+            codec.encode_begin(ctx1, xs[b], plan, *out1)
+        with pytest.raises(AejError):
+            codec.encode_begin(ctx0, xs[a], plan, *out0)            # one call in flight per context
+        codec.encode_end(ctx0)
+        with torch.cuda.stream(s1):
+            codec.encode_end(ctx1)
+        torch.cuda.synchronize()
+        _assert_same_encoding(torch, plan, out0, want[a], B, f"round {rnd}, context 0")
+        _assert_same_encoding(torch, plan, out1, want[b], B, f"round {rnd}, context 1")
+    with pytest.raises(AejError):
+        codec.encode_end(ctx0)                                      # nothing in flight
+    ref = oracle.encode_image(xs[0][0].cpu().numpy(), space, qr, br)
+    from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+    check_image(EncodedBatch(plan, *want[0]), 0, ref, "blocking call")
