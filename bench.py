@@ -11,6 +11,12 @@ weak scaling).  Inputs are in HBM before the timed region; outputs stay in HBM.
         bench.py --gpus N --steps K --warmup W
 
 What the timed region does and does not contain:
+* the K steps rotate over `--pipeline` (default 2) contexts, each on its own stream with its own output buffers and workspace:
+  step i is enqueued with aej_encode_batch_begin on context i % n after the step that used that context before has been ended
+  (aej_encode_batch_end: waited for, device counters checked, a speculation miss repaired).  Two calls in flight let the HBM-bound
+  stages of one (colour planes, DCT) run beside the issue-bound stages of the other (blur, Sobel / NMS, quadtree); the library
+  keeps them one stage apart.  All K steps are complete inside the timed region (sync() ends every call in flight before the
+  clock stops).  `pipeline.serial_ms_per_step` is the same K steps as blocking aej_encode_batch calls on one context.
 * TWO different device-resident batches (different seeds) alternate across the steps, so the data-dependent speculation of the
   hysteresis stage (pass count learnt from the previous call) is exercised on changing inputs; `hysteresis` in the JSON line
   reports how many timed calls were speculative and how many missed, and `verified_mode_ms_per_step` is the same loop with the
@@ -52,8 +58,9 @@ ALGO_BYTES_PER_PX = {
 }
 WHOLE_PATH_BYTES_PER_PX = 18.0                   # 12 B f32 RGB in + 4 B x 1.5 coefficients out
 KERNEL_OF_STAGE = {"color_planes": "k_color_planes", "clahe_blur": "k_clahe_blur", "sobel_nms": "k_sobel_nms", "hysteresis": "k_hyst_pass",
-                   "quadtree": "k_qt_", "dct4": "k_dct4", "dct8": "k_dct_small<8", "dct16": "k_dct_small<16", "dct32": "k_dct_mfma<32",
-                   "dct64": "k_dct_mfma<64", "dct128": "k_dct_mfma<128", "dct2": "k_dct_small<2", "dct256": "k_dct_big"}
+                   "quadtree": "k_qt_", "dct4": "k_dct4", "dct8": "k_dct_small<8", "dct16": "k_dct16_mfma", "dct32": "k_dct_mfma<32",
+                   "dct64": "k_dct_mfma<64", "dct128": "k_dct_mfma<128", "dct2": "k_dct_small<2", "dct256": "k_dct_big<256", "dct512": "k_dct_big<512",
+                   "dct1024": "k_dct_big<1024"}
 
 
 def synth_batch(torch, B, H, W, seed, device):
@@ -289,7 +296,8 @@ def main():
 
     # ---- the measurement: W warm-up steps, then exactly K timed steps on alternating inputs, profiling off ----
     ctx.set_profiling(False)
-    for i in range(max(args.warmup, 2 * n_pipe)):       # every context has seen both inputs
+    n_warm = max(args.warmup, 2 * n_pipe)               # every context has seen both inputs
+    for i in range(n_warm):
         step(i)
     sync()
     h0 = hyst_stats()
@@ -303,7 +311,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch", "value": round(value, 1), "unit": "MP/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-                              "encode_calls": args.steps + args.warmup, "hysteresis_misses": h1["misses"] - h0["misses"], "timed_only": True}), flush=True)
+                              "encode_calls": args.steps + n_warm, "hysteresis_misses": h1["misses"] - h0["misses"], "timed_only": True}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """PMC summaries of the bench workload per kernel (GPU box).  Each counter group is its own rocprofv3 pass with --kernel-trace
-only (never combined with other trace domains), of `python3 bench.py --timed-only`, where every kernel is launched a known
-number of times; values are divided by the number of aej_encode_batch calls.
+only (never combined with other trace domains), of `python3 bench.py --timed-only --pipeline 1 --sub-batches 1` (blocking calls on
+one context, no sub-batches: counters are per kernel, and every kernel is launched a known number of times); values are divided by
+the number of aej_encode_batch calls.
 
     python3 tools/profiling/pmc.py traffic [bench args]   -> gpurun_out/hbm_traffic.json   (FETCH_SIZE pass + WRITE_SIZE pass)
     python3 tools/profiling/pmc.py valu    [bench args]   -> gpurun_out/pmc_valu.json      (SQ instruction / LDS / busy counters)
@@ -39,7 +40,7 @@ def one_pass(counters, bench_args, tag):
     shutil.rmtree(out_dir, ignore_errors=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out_dir, "--", "python3", os.path.join(ROOT, "bench.py"),
-                                                "--timed-only", "--steps", "2", "--warmup", "1"] + bench_args
+                                                "--timed-only", "--steps", "2", "--warmup", "1", "--pipeline", "1", "--sub-batches", "1"] + bench_args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not line:
