@@ -678,14 +678,18 @@ __device__ __forceinline__ bool locate_strip(const Geom &g, int strip, int t, in
 constexpr int kNW4 = (kBlurTW + 8) / 4;      // 18 dwords per staged row: columns c <-> gx = x0 - 4 + c
 constexpr int kNUH = kBlurTH + 4;            // u8 rows  [y0-2, y0+TH+2)
 constexpr int kNMH = kBlurTH + 2;            // mag rows [y0-1, y0+TH+1)
-constexpr int kNMW = kBlurTW + 8 + 1;        // mag row stride (ints), odd to skew banks
+constexpr int kNMW = kBlurTW + 8;            // mag row stride (ints): a multiple of 4, so that the four values of an item are ONE aligned 16-byte
+                                             // LDS write (as 4-byte writes at a 16-byte lane stride they ran into 4-way bank conflicts); every reader walks rows
 constexpr int kNRaw = (kNUH * kNW4 + 255) / 256;
+constexpr int kS1Rows = 3;                   // output rows per stage-1 thread: 256 / 18 = 14 row groups x 3 rows >= 34
+static_assert((256 / kNW4) * kS1Rows >= kNMH, "stage-1 thread -> row mapping must cover the magnitude rows");
 
-struct NmsLds {
-    unsigned int U[kNUH * kNW4];
+struct __attribute__((aligned(16))) NmsLds {
     int M[kNMH * kNMW];
     int G[kNMH * kNMW];        // dx (low 16 bits) | dy << 16
+    unsigned int U[kNUH * kNW4];
 };
+static_assert((kNMW % 4) == 0 && (kNMH * kNMW) % 4 == 0, "16-byte aligned item writes");
 
 __device__ __forceinline__ void nms_prefetch(const unsigned char *src, int w, int x0, int y0, unsigned int (&raw)[kNRaw])
 {
@@ -750,56 +754,72 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
         __syncthreads();
         if (tx + 1 < tx_end && is_aligned(tx + 1)) nms_prefetch(src, w, (tx + 1) * kBlurTW, y0, raw);
 
-        // ---- stage 1: 4 pixels per item; rows gy = y0-1+jm, columns gx = x0-4+4*i4 .. +3
-#pragma unroll
-        for (int k = 0; k < (kNMH * kNW4 + 255) / 256; k++) {
-            const int idx = tid + k * 256;
-            if (idx < kNMH * kNW4) {
-                const int jm = idx / kNW4, i4 = idx - jm * kNW4;
+        // ---- stage 1: gradients and magnitudes, 4 pixels (one column dword) x kS1Rows output rows per thread; rows gy = y0-1+jm,
+        // columns gx = x0-4+4*i4 .. +3.  The thread slides down its column: the horizontal parts of a source row are formed once
+        // and used by the three output rows that see it (the first version recomputed them per output row: 15.5 -> 11 instructions
+        // per pixel in this stage, 9 -> 5 LDS reads per item).
+        {
+            int tq = tid;
+            asm volatile("" : "+v"(tq));           // (keeps the per-thread LDS addresses from being hoisted out of the tile loop into scratch)
+            const int i4 = tq % kNW4, grp = tq / kNW4;
+            const int jm0 = grp * kS1Rows;
+            if (jm0 < kNMH) {
                 const int il = i4 > 0 ? i4 - 1 : 0, ir = i4 < kNW4 - 1 ? i4 + 1 : kNW4 - 1;   // edge dwords feed unused columns only
                 // Per source row, four words of two 16-bit fields each, made by byte permutes (selector 0x0C = zero byte) from the
                 // 6 bytes at columns -1 .. 4:  LE = (-1, 1), A = (0, 2), B = (1, 3), RO = (2, 4).  Outputs 0 and 2 have
                 // (left, mid, right) = (LE, A, B), outputs 1 and 3 have (A, B, RO).
-                unsigned int he[3], ho[3], vle = 0, vlo = 0, vre = 0, vro = 0;
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const unsigned int *row = L.U + (jm + r) * kNW4;
-                    const unsigned int m = row[i4], lf = row[il], rt = row[ir];
-                    const unsigned int LE = __builtin_amdgcn_perm(m, lf, 0x0C050C03u);
-                    const unsigned int A = m & 0x00FF00FFu;
-                    const unsigned int B = __builtin_amdgcn_perm(m, m, 0x0C030C01u);
-                    const unsigned int RO = __builtin_amdgcn_perm(rt, m, 0x0C040C02u);
-                    he[r] = LE + 2u * A + B;                  // horizontal [1 2 1] at columns 0, 2
-                    ho[r] = A + 2u * B + RO;                  // columns 1, 3
-                    const unsigned int wgt = r == 1 ? 2u : 1u;    // vertical [1 2 1]
-                    vle += wgt * LE;  vre += wgt * B;         // left / right columns of outputs 0, 2
-                    vlo += wgt * A;   vro += wgt * RO;        // of outputs 1, 3
-                }
-                // the 16-bit fields are pixel pairs (0, 2) and (1, 3): gradients as packed int16 subtractions, then one
-                // (dx | dy << 16) word per pixel -- the format stage 2 reads -- whose dot product with itself is the magnitude
+                unsigned int LEv[3], Av[3], Bv[3], ROv[3], he[3], ho[3];      // the last three source rows (index = source row % 3)
                 typedef short s16x2 __attribute__((ext_vector_type(2)));
                 auto sub2 = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); };
-                const unsigned dxe = sub2(vre, vle), dxo = sub2(vro, vlo);             // dx of pixels (0, 2), (1, 3)
-                const unsigned dye = sub2(he[2], he[0]), dyo = sub2(ho[2], ho[0]);     // dy
-                unsigned gv[4];
-                gv[0] = __builtin_amdgcn_perm(dye, dxe, 0x05040100u);                  // low halves:  dx0 | dy0 << 16
-                gv[2] = __builtin_amdgcn_perm(dye, dxe, 0x07060302u);                  // high halves: dx2 | dy2 << 16
-                gv[1] = __builtin_amdgcn_perm(dyo, dxo, 0x05040100u);
-                gv[3] = __builtin_amdgcn_perm(dyo, dxo, 0x07060302u);
-                const int gy = y0 - 1 + jm;
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int gx = x0 - 4 + 4 * i4 + p;
-                    int m;
-                    if (L2) {
-                        m = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, gv[p]), __builtin_bit_cast(s16x2, gv[p]), 0, false);   // dx^2 + dy^2
-                    } else {                                                                                                  // |dx| + |dy|
-                        const int dxv = (int)(short)(gv[p] & 0xffffu), dyv = (int)gv[p] >> 16;
-                        m = (dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv);
+                for (int r = 0; r < kS1Rows + 2; r++) {
+                    const int ju = jm0 + r;              // source (U) row; output row jm = ju - 2 uses U rows jm .. jm + 2
+                    if (ju < kNUH) {
+                        const unsigned int *row = L.U + ju * kNW4;
+                        const unsigned int m = row[i4], lf = row[il], rt = row[ir];
+                        const int c = r % 3;
+                        LEv[c] = __builtin_amdgcn_perm(m, lf, 0x0C050C03u);
+                        Av[c] = m & 0x00FF00FFu;
+                        Bv[c] = __builtin_amdgcn_perm(m, m, 0x0C030C01u);
+                        ROv[c] = __builtin_amdgcn_perm(rt, m, 0x0C040C02u);
+                        he[c] = LEv[c] + 2u * Av[c] + Bv[c];          // horizontal [1 2 1] at columns 0, 2
+                        ho[c] = Av[c] + 2u * Bv[c] + ROv[c];          // columns 1, 3
                     }
-                    if (!aligned && (gx < 0 || gx >= w || gy < 0 || gy >= h)) m = 0;      // magnitude outside the image is 0
-                    L.M[jm * kNMW + 4 * i4 + p] = m;
-                    L.G[jm * kNMW + 4 * i4 + p] = (int)gv[p];
+                    if (r >= 2) {
+                        const int jm = ju - 2;
+                        if (jm < kNMH) {
+                            const int c0 = (r - 2) % 3, c1 = (r - 1) % 3, c2 = r % 3;     // top, middle, bottom source row
+                            // vertical [1 2 1] of the left / right columns of outputs (0, 2) and (1, 3)
+                            const unsigned vle = LEv[c0] + 2u * LEv[c1] + LEv[c2], vre = Bv[c0] + 2u * Bv[c1] + Bv[c2];
+                            const unsigned vlo = Av[c0] + 2u * Av[c1] + Av[c2], vro = ROv[c0] + 2u * ROv[c1] + ROv[c2];
+                            // the 16-bit fields are pixel pairs (0, 2) and (1, 3): gradients as packed int16 subtractions, then one
+                            // (dx | dy << 16) word per pixel -- the format stage 2 reads -- whose dot product with itself is the magnitude
+                            const unsigned dxe = sub2(vre, vle), dxo = sub2(vro, vlo);             // dx of pixels (0, 2), (1, 3)
+                            const unsigned dye = sub2(he[c2], he[c0]), dyo = sub2(ho[c2], ho[c0]); // dy
+                            unsigned gv[4];
+                            gv[0] = __builtin_amdgcn_perm(dye, dxe, 0x05040100u);                  // low halves:  dx0 | dy0 << 16
+                            gv[2] = __builtin_amdgcn_perm(dye, dxe, 0x07060302u);                  // high halves: dx2 | dy2 << 16
+                            gv[1] = __builtin_amdgcn_perm(dyo, dxo, 0x05040100u);
+                            gv[3] = __builtin_amdgcn_perm(dyo, dxo, 0x07060302u);
+                            const int gy = y0 - 1 + jm;
+                            int mv[4];
+#pragma unroll
+                            for (int p = 0; p < 4; p++) {
+                                const int gx = x0 - 4 + 4 * i4 + p;
+                                int m;
+                                if (L2) {
+                                    m = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, gv[p]), __builtin_bit_cast(s16x2, gv[p]), 0, false);   // dx^2 + dy^2
+                                } else {                                                                                                  // |dx| + |dy|
+                                    const int dxv = (int)(short)(gv[p] & 0xffffu), dyv = (int)gv[p] >> 16;
+                                    m = (dxv < 0 ? -dxv : dxv) + (dyv < 0 ? -dyv : dyv);
+                                }
+                                if (!aligned && (gx < 0 || gx >= w || gy < 0 || gy >= h)) m = 0;      // magnitude outside the image is 0
+                                mv[p] = m;
+                            }
+                            *reinterpret_cast<int4 *>(&L.M[jm * kNMW + 4 * i4]) = make_int4(mv[0], mv[1], mv[2], mv[3]);
+                            *reinterpret_cast<int4 *>(&L.G[jm * kNMW + 4 * i4]) = make_int4((int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3]);
+                        }
+                    }
                 }
             }
         }

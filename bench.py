@@ -397,7 +397,7 @@ def main():
         if hit:
             traffic = sum(hit)
             traffic_src = {"file": "profiles/r02_hbm_traffic.json", "profiled_commit": tj.get("head"), "this_commit": head,
-                           "stale": tj.get("head") != head}
+                           "stale": (tj.get("head") != head) if (head and tj.get("head")) else "unknown (no git on this box)"}
     roofline = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom].rstrip("<_") if dom != "quadtree" else "k_qt_upper+count+scan+emit",
                 "stage": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -417,7 +417,7 @@ def main():
             valu = {"kernel": roofline["kernel"], "wave_instructions_per_launch": insts, "instructions_per_plane_px": round(insts * 64 / plane_px, 1),
                     "frac_of_issue_peak": round(t_issue / (kernels[dom] * 1e-3), 3),
                     "issue_ns_per_simd_instruction": 1.1, "source": {"file": "profiles/r02_pmc_valu.json", "profiled_commit": vj.get("head"),
-                                                                       "this_commit": head, "stale": vj.get("head") != head}}
+                                                                       "this_commit": head, "stale": (vj.get("head") != head) if (head and vj.get("head")) else "unknown (no git on this box)"}}
     whole_bpp = WHOLE_PATH_BYTES_PER_PX - (9.0 if args.ingest == "u8" else 0.0)
     whole = whole_bpp * local_px / (ms_per_step * 1e-3) / 1e9
     per_stage = {k: {"ms": round(v, 4), "GBps": round(algo[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None} for k, v in kernels.items()}

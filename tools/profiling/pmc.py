@@ -67,7 +67,7 @@ def one_pass(counters, bench_args, tag):
 def main():
     mode = sys.argv[1]
     bench_args = sys.argv[2:]
-    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("AEJ_HEAD") or None
     kernels = collections.defaultdict(dict)
     info = None
     for i, counters in enumerate(GROUPS[mode]):
