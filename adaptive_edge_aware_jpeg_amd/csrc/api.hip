@@ -396,6 +396,7 @@ extern "C" const char *aej_last_error(aej_ctx *ctx)
 extern "C" int aej_synchronize(aej_ctx *ctx)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -1186,6 +1187,7 @@ extern "C" int aej_encode_batch_u8(aej_ctx *ctx, const uint8_t *rgb_u8, int batc
 extern "C" int aej_color_convert(aej_ctx *ctx, int space, const float *rgb, float *out, int64_t n)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (n < 0 || (n > 0 && (!rgb || !out))) return fail(ctx, AEJ_ERR_ARG, "bad buffer");
     if (n == 0) return 0;
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1199,6 +1201,7 @@ extern "C" int aej_color_planes(aej_ctx *ctx, const float *rgb, int batch, int H
 {
     int rc = check_encode_args(ctx, batch, H, W);
     if (rc) return rc;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
     Geom g;
     if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
@@ -1226,6 +1229,7 @@ extern "C" int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t
                          void *workspace, uint64_t workspace_bytes)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "Input array must be a 2D.");
     if (!plane || !edge || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
     if (workspace_bytes < aej_canny_workspace_bytes(H, W)) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
@@ -1294,6 +1298,7 @@ extern "C" int aej_quadtree(aej_ctx *ctx, const uint8_t *edge, int H, int W, int
                             uint8_t *states, int64_t *counts, void *workspace, uint64_t workspace_bytes)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "Input array must be a 2D with a single channel.");
     if (!edge || !leaves || !states || !counts || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1321,6 +1326,7 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
                                     int32_t *coeffs, float *dct_f32)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (!ctx->has_settings) return fail(ctx, AEJ_ERR_STATE, "aej_set_settings has not been called");
     if (H < 1 || W < 1 || layer < 0 || layer > 2 || n_leaves < 0) return fail(ctx, AEJ_ERR_ARG, "bad argument");
     if (n_leaves == 0) return 0;
@@ -1396,6 +1402,7 @@ extern "C" int64_t aej_leaf_positions_host(const int32_t *sizes_host, int64_t n,
 extern "C" int aej_color_convert_inverse(aej_ctx *ctx, int space, const float *in, float *out_rgb, int64_t n)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (n < 0 || (n > 0 && (!in || !out_rgb))) return fail(ctx, AEJ_ERR_ARG, "bad buffer");
     if (n == 0) return 0;
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1443,6 +1450,7 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
 {
     int rc = check_encode_args(ctx, batch, H, W);
     if (rc) return rc;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (!coeffs || !leaves || !counts || !rgb_out || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
     Geom g;
@@ -1520,6 +1528,7 @@ extern "C" int aej_metrics_batch(aej_ctx *ctx, const float *img_a, const float *
                                  void *workspace, uint64_t workspace_bytes)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (!img_a || !img_b || !out || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
     if (batch < 1 || H < 1 || W < 1) return fail(ctx, AEJ_ERR_ARG, "bad shape %d x %d x %d", batch, H, W);
     if ((which & ~7) || !(which & 7)) return fail(ctx, AEJ_ERR_ARG, "which must be a combination of AEJ_METRIC_PSNR | AEJ_METRIC_SSIM | AEJ_METRIC_MS_SSIM");
@@ -1581,6 +1590,7 @@ extern "C" int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin)
 extern "C" int aej_set_hysteresis_speculation(aej_ctx *ctx, int enable)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     ctx->hyst_speculate = enable != 0;
     return 0;
 }
@@ -1598,6 +1608,7 @@ extern "C" int aej_get_hysteresis_stats(aej_ctx *ctx, int64_t *out_host)
 extern "C" int aej_set_graph_mode(aej_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     ctx->graph_mode = mode;
     if (mode == 0) drop_graphs(ctx);
     return 0;
@@ -1624,6 +1635,7 @@ extern "C" int aej_get_graph_stats(aej_ctx *ctx, int64_t *out_host)
 extern "C" int aej_set_stream(aej_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if (s == ctx->stream) return 0;
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1635,6 +1647,7 @@ extern "C" int aej_set_stream(aej_ctx *ctx, void *hip_stream)
 extern "C" int aej_set_profiling(aej_ctx *ctx, int enable)
 {
     if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     ctx->profiling = enable != 0;
     return 0;
 }

@@ -280,7 +280,8 @@ def main():
         pipes[i % n_pipe].begin(input_of(i))
 
     def serial_step(i):                # one blocking call at a time on context 0
-        jpeg.encode_into(ctx, batches[i & 1], plan, coeffs, leaves, states, counts)
+        with torch.cuda.stream(pipes[0].stream):
+            jpeg.encode_into(ctx, batches[i & 1], plan, coeffs, leaves, states, counts)
 
     def sync():
         for p in pipes:

@@ -317,6 +317,8 @@ def test_begin_end_on_two_contexts(env, oracle):
             codec.encode_begin(ctx1, xs[b], plan, *out1)
         with pytest.raises(AejError):
             codec.encode_begin(ctx0, xs[a], plan, *out0)            # one call in flight per context
+        with pytest.raises(AejError):
+            ctx0.set_profiling(True)                                # nor any other entry point that uses the context's stream
         codec.encode_end(ctx0)
         with torch.cuda.stream(s1):
             codec.encode_end(ctx1)
