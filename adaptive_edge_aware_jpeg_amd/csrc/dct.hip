@@ -318,6 +318,138 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8 x 8 blocks: eight LANES per leaf, registers and wavefront shuffles only -- no LDS transpose, no workgroup barrier.
+// Lane j of a leaf's group loads column j of X (eight rows of 32 contiguous bytes per leaf), so the column transform
+// T[.][j] = D.X[.][j] is lane-local (64 fma, D in registers).  An 8 x 8 transpose inside the 8-lane group -- three butterfly
+// stages: partners lane ^ 1 and lane ^ 2 by DPP quad_perm, lane ^ 4 by DPP row_shl / row_shr under bank masks -- hands lane i
+// the row T[i][.], so Y[i][.] = T[i][.].D^T is lane-local again.  Same k-ordered fma chains as every other kernel.  The leaf's
+// 256 bytes of coefficients pass through a wave-private LDS slab at their zigzag positions (LDS operations of one wave execute
+// in order) and leave as two 16-byte stores per lane: a wave writes 2 KiB contiguously.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float v)
+{
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(v), CTRL, 0xf, BANK_MASK, false));
+}
+// value of lane ^ S (S = 1, 2, 4) within the lane's group of 8
+template <int S>
+__device__ __forceinline__ float lane_xor(float v)
+{
+    if (S == 1) return dpp_f<0xB1>(v, v);                    // quad_perm [1, 0, 3, 2]
+    if (S == 2) return dpp_f<0x4E>(v, v);                    // quad_perm [2, 3, 0, 1]
+    float r = dpp_f<0x104, 0x5>(v, v);                       // row_shl:4 -> lanes 0-3, 8-11 of each row take lane + 4
+    return dpp_f<0x114, 0xA>(r, v);                          // row_shr:4 -> lanes 4-7, 12-15 take lane - 4
+}
+// a[r] of lane l  <->  a[l] of lane r  (l, r = 0..7 inside the group)
+template <int S>
+__device__ __forceinline__ void transpose8_stage(float (&a)[8], bool upper)      // upper = (lane & S) != 0
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        if ((r & S) == 0) {
+            const float send = upper ? a[r] : a[r | S];
+            const float recv = lane_xor<S>(send);
+            if (upper) a[r] = recv; else a[r | S] = recv;
+        }
+}
+
+template <bool WANT_DCT>
+__global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, long long max_items)
+{
+    constexpr int S = 8, SS = 64, LPB = 32;
+    __shared__ float sQf[3 * SS];
+    __shared__ int sOut[4][8 * SS];          // per wave: 8 leaves x 64 coefficients
+    __shared__ LayerTab lt;
+    extern __shared__ int s_pref[];
+    const int tid = threadIdx.x;
+    if (tid < 3 * SS) sQf[tid] = (float)(a.qm[tid / SS] ? a.qm[tid / SS][tid % SS] : 1);
+    dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
+    long long count = s_pref[a.nplanes];
+    if (count > max_items) count = max_items;
+    const long long wstride = q.work_stride[a.k];
+    const int lane = tid & 63, wv = tid >> 6, j = tid & 7, slot = tid >> 3;      // slot: leaf of this block iteration (0..31)
+    float D[8][8];
+#pragma unroll
+    for (int i = 0; i < 64; i++) D[i >> 3][i & 7] = a.D[i];
+    int zz[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) zz[c] = zigzag_pos<S>(j, c);                     // after the transpose this lane owns row j
+    int *slab = sOut[wv] + ((lane >> 3) * SS);
+    const long long step = (long long)gridDim.x * LPB;
+    long long base = (long long)blockIdx.x * LPB;
+    int4 wk = make_int4(0, 0, 0, 0);
+    if (base + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + slot);
+    for (; base < count; base += step) {
+        const bool active = base + slot < count;
+        const int4 cur = wk;
+        float x[8];
+        int layer = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = 0.f;
+        if (active) {
+            b = cur.x / 3;
+            layer = cur.x - b * 3;
+            const int w = lt.w[layer], h = lt.h[layer];
+            const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+            const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
+            const float *colp = src + cur.y + reflect_pad_idx(j, wc);
+            if (hc == S) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = colp[(long long)(cur.z + k) * w];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = colp[(long long)(cur.z + reflect_pad_idx(k, hc)) * w];
+            }
+            if (base + step + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + step + slot);
+        }
+        // T[i][j] = sum_k D[i][k] X[k][j]: this lane's column
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = __builtin_fmaf(D[i][k], x[k], acc);
+            t[i] = acc;
+        }
+        // (all 64 lanes take part in the shuffles; the groups of inactive leaves carry zeros)
+        transpose8_stage<1>(t, (lane & 1) != 0);
+        transpose8_stage<2>(t, (lane & 2) != 0);
+        transpose8_stage<4>(t, (lane & 4) != 0);
+        // now t[k] = T[j][k]: Y[j][c] = sum_k T[j][k] D[c][k]
+        float y[8], ymax = 0.f, qmax = 0.f, qf[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = __builtin_fmaf(t[k], D[c][k], acc);
+            y[c] = acc;
+            qf[c] = sQf[layer * SS + j * S + c];
+            ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
+            qmax = __builtin_fmaxf(qmax, qf[c]);
+        }
+        const long long out_base = active ? (long long)b * q.coeff_stride + lt.coff[layer] + cur.w : 0;
+        if (WANT_DCT && active) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) a.dct_f32[out_base + j * S + c] = y[c];
+        }
+        // one range test per wave for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
+        if (!__any(qmax > 4194304.0f || !(ymax < 131072.0f))) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) slab[zz[c]] = quantise_f32(y[c], qf[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) slab[zz[c]] = quantise_f64(y[c], (int)qf[c]);
+        }
+        if (active) {
+            const int4 o0 = reinterpret_cast<const int4 *>(slab)[2 * j], o1 = reinterpret_cast<const int4 *>(slab)[2 * j + 1];
+            int4 *dst = reinterpret_cast<int4 *>(a.coeffs + out_base);      // coefficient offsets are multiples of 4
+            dst[2 * j] = o0;
+            dst[2 * j + 1] = o1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 16 x 16 blocks on the matrix pipe: one WAVE per leaf, v_mfma_f32_16x16x4_f32, no LDS and no barrier between the products.
 // The instruction accumulates its four k values as the k-ascending fma chain (checked bit for bit on hardware,
 // tools/ubench/mfma16_order.hip), so four of them in a row are exactly the contract's chain over k = 0..15.
@@ -868,7 +1000,10 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
         if (wd) hipLaunchKernelGGL((k_dct4<true>), dim3(cap(256, 8192)), dim3(256), pref, st, g, q, a, max_items);
         else hipLaunchKernelGGL((k_dct4<false>), dim3(cap(256, 8192)), dim3(256), pref, st, g, q, a, max_items);
         break;
-    case 8: AEJ_SMALL(8, 32, 4096); break;
+    case 8:
+        if (wd) hipLaunchKernelGGL((k_dct8_shfl<true>), dim3(cap(32, 4096)), dim3(256), pref, st, g, q, a, max_items);
+        else hipLaunchKernelGGL((k_dct8_shfl<false>), dim3(cap(32, 4096)), dim3(256), pref, st, g, q, a, max_items);
+        break;
     case 16:
         if (wd) hipLaunchKernelGGL((k_dct16_mfma<true>), dim3(cap(4, 2048)), dim3(256), pref, st, g, q, a, max_items);
         else hipLaunchKernelGGL((k_dct16_mfma<false>), dim3(cap(4, 2048)), dim3(256), pref, st, g, q, a, max_items);
