@@ -429,9 +429,9 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic ('mixed' images generated on the GPU, SURVEY.md 8d recipe); two batches of different seeds alternate across steps",
         "config": {"workload": f"{B} x {W}x{H} {'uint8' if args.ingest == 'u8' else 'float32'} RGB per GPU, {space}, blocks {brange[0]}-{brange[1]}, quality {qrange[0]}-{qrange[1]} "
-                               f"(BASELINE config 4: 512 4K images / 8 GPUs)",
+                               + ("(BASELINE config 4: 512 4K images / 8 GPUs)" if (B, H, W, space, tuple(brange)) == (64, H4K, W4K, "YCbCr", (4, 64)) else "(not the headline workload)"),
                    "images_per_gpu": B, "height": H, "width": W, "color_space": space,
-                   "block_size_range": list(brange), "quality_range": list(qrange)},
+                   "block_size_range": list(brange), "quality_range": list(qrange), "steps_in_flight": n_pipe},
         "roofline": roofline,
         "valu": valu,
         "verified": verified,
