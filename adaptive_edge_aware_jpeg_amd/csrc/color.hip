@@ -132,10 +132,13 @@ __global__ __launch_bounds__(256) void k_color_convert(const float *__restrict__
 // ------------------------------------------------------------------------------------------------
 struct NormConst { float mid[3]; float scale[3]; };
 
-__device__ __forceinline__ void hist_add(int *lds_hist, int *__restrict__ ghist, int layer, int tx0, int ty0, int tx, int ty, int v)
+// The LDS histogram is addressed through an explicit address-space-3 pointer: through a generic `int *` the compiler emits FLAT
+// atomics (flat_atomic_add: both memory pipes, both wait counters) instead of ds_add_u32.
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ void hist_add(lds_int *lds_hist, int *__restrict__ ghist, int layer, int tx0, int ty0, int tx, int ty, int v)
 {
     int dx = tx - tx0, dy = ty - ty0;
-    if ((unsigned)dx < 2u && (unsigned)dy < 2u) atomicAdd(&lds_hist[((layer * 4) + dy * 2 + dx) * 256 + v], 1);
+    if ((unsigned)dx < 2u && (unsigned)dy < 2u) __hip_atomic_fetch_add(&lds_hist[((layer * 4) + dy * 2 + dx) * 256 + v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicAdd(&ghist[((layer * 16) + ty * 4 + tx) * 256 + v], 1);
 }
 
@@ -244,10 +247,10 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
             if (planes_u8) *reinterpret_cast<uchar4 *>(planes_u8 + o) = u;
             if (do_hist) {
                 int ty = tile_ly(py + r);
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 0), ty, u.x);
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 1), ty, u.y);
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 2), ty, u.z);
-                hist_add(s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 3), ty, u.w);
+                hist_add((lds_int *)s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 0), ty, u.x);
+                hist_add((lds_int *)s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 1), ty, u.y);
+                hist_add((lds_int *)s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 2), ty, u.z);
+                hist_add((lds_int *)s_hist, ghist, 0, tx0_l, ty0_l, tile_lx(px + 3), ty, u.w);
             }
         }
         // ---- layers 1, 2 (chroma): INTER_AREA box mean
@@ -276,8 +279,8 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
                 if (planes_u8) *reinterpret_cast<uchar2 *>(planes_u8 + o) = u;
                 if (do_hist) {
                     const int tyc = tile_cy(cy[0]);          // layers 1 and 2 share their geometry
-                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx), tyc, u.x);
-                    hist_add(s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx + 1), tyc, u.y);
+                    hist_add((lds_int *)s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx), tyc, u.x);
+                    hist_add((lds_int *)s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx + 1), tyc, u.y);
                 }
             } else {
 #pragma unroll
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
                     if (planes_raw) planes_raw[o] = v[q];
                     unsigned char u = scale_u8(v[q]);
                     if (planes_u8) planes_u8[o] = u;
-                    if (do_hist) hist_add(s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx), tile_cy(y), u);
+                    if (do_hist) hist_add((lds_int *)s_hist, ghist, ch, tx0_c, ty0_c, tile_cx(cx), tile_cy(y), u);
                 }
             }
         }
