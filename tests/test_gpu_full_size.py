@@ -274,6 +274,11 @@ def test_sub_batch_pipelining_is_invisible(env, oracle):
             got = _encode_raw(torch, ctx, codec, x, plan)
             assert ctx.split_calls() == c0 + 1
             _assert_same_encoding(torch, plan, got, want, B, f"{n} sub-batches")
+        # 8-bit ingest through the split path (the GPU forms float32(v) / 255 exactly as the float batch was made)
+        ctx.set_sub_batches(3)
+        x8 = (x * 255.0).round().to(torch.uint8)
+        got = _encode_raw(torch, ctx, codec, x8, plan)
+        _assert_same_encoding(torch, plan, got, want, B, "3 sub-batches, uint8 ingest")
         # a speculative pass count that is too small inside the sub-batches: detected per sub-batch and repaired
         ctx.set_sub_batches(2)
         s0 = ctx.hysteresis_stats()
