@@ -138,8 +138,11 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 //     once and used for both pixels: 76 instead of 96 table gathers per 8 pixels.
 // Every float operation per pixel is the same single IEEE operation in the same order as before (and as the CPU oracle).
 // ------------------------------------------------------------------------------------------------
-constexpr int kBT = 512;                  // threads per workgroup
+constexpr int kBT = 512;                  // threads per workgroup (a 384-thread / 128 x 48 / 168-VGPR variant without the spills measured 3.8 ms: uneven waves per SIMD)
 constexpr int kBTW = 128, kBTH = 64;      // output tile
+constexpr int kBMinWaves = 4;             // waves per SIMD the register budget is sized for (128 VGPRs; about 40 dwords per lane spill to scratch in stage C)
+constexpr int kBPairsPerPass = kBT / 32;  // stage C: row pairs one pass of the workgroup covers
+static_assert(kBTH % (2 * kBPairsPerPass) == 0, "stage C passes must tile the rows");
 constexpr int kBAW = kBTW + 8;            // staged columns: c <-> gx = x0 - 4 + c (bytes per CLAHE row, dwords per Gaussian row)
 constexpr int kBAW4 = kBAW / 4;           // 34 dwords per CLAHE row
 constexpr int kBAH = kBTH + 6;            // CLAHE rows  [y0-3, y0+TH+3)
@@ -240,7 +243,7 @@ __device__ __forceinline__ bool locate_blur_strip(const Geom &g, int strip, int 
     return false;
 }
 
-__global__ __launch_bounds__(kBT, 4) void k_clahe_blur(Geom g, CannyBuffers cb, int strip)
+__global__ __launch_bounds__(kBT, kBMinWaves) void k_clahe_blur(Geom g, CannyBuffers cb, int strip)
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;
@@ -340,16 +343,18 @@ __global__ __launch_bounds__(kBT, 4) void k_clahe_blur(Geom g, CannyBuffers cb, 
             const bool need1 = nchg_c + nchg_r == 1;
             const bool build0 = L.pkey[0] != key_s0, build1 = need1 && L.pkey[1] != key_s1;
             if (build0 || build1) {              // uniform: everything above comes from LDS words every thread reads alike
-                const int v = tid & 255, slot = tid >> 8;
-                const int key = slot ? key_s1 : key_s0;
-                if (slot ? build1 : build0) {
-                    const int ckey = key >> 4, rkey = key & 15;
-                    const int tx1 = ckey >> 2, tx2 = ckey & 3, ty1 = rkey >> 2, ty2 = rkey & 3;
-                    L.P[slot][v] = make_float4((float)glut[(ty1 * 4 + tx1) * 256 + v], (float)glut[(ty1 * 4 + tx2) * 256 + v],
-                                               (float)glut[(ty2 * 4 + tx1) * 256 + v], (float)glut[(ty2 * 4 + tx2) * 256 + v]);
+                for (int e = tid; e < 512; e += kBT) {       // entries 0..255 slot 0, 256..511 slot 1
+                    const int v = e & 255, slot = e >> 8;
+                    const int key = slot ? key_s1 : key_s0;
+                    if (slot ? build1 : build0) {
+                        const int ckey = key >> 4, rkey = key & 15;
+                        const int tx1 = ckey >> 2, tx2 = ckey & 3, ty1 = rkey >> 2, ty2 = rkey & 3;
+                        L.P[slot][v] = make_float4((float)glut[(ty1 * 4 + tx1) * 256 + v], (float)glut[(ty1 * 4 + tx2) * 256 + v],
+                                                   (float)glut[(ty2 * 4 + tx1) * 256 + v], (float)glut[(ty2 * 4 + tx2) * 256 + v]);
+                    }
                 }
                 __syncthreads();                   // every thread has compared the old keys; the new entries are visible
-                if (v == 0 && (slot ? build1 : build0)) L.pkey[slot] = key;
+                if (tid < 2 && (tid ? build1 : build0)) L.pkey[tid] = tid ? key_s1 : key_s0;
             }
         }
         // Thread -> work mappings are re-derived per tile from a copy of the thread id the compiler cannot see through: otherwise
@@ -463,8 +468,8 @@ __global__ __launch_bounds__(kBT, 4) void k_clahe_blur(Geom g, CannyBuffers cb, 
         const int c4 = tc & 31;
         unsigned int *hcopy = L.hist + (tc % kHistCopies) * kHistStride;
 #pragma unroll 1
-        for (int pass = 0; pass < kBTH / 32; pass++) {
-            const int yy = 2 * ((tc >> 5) + 16 * pass);
+        for (int pass = 0; pass < kBTH / (2 * kBPairsPerPass); pass++) {
+            const int yy = 2 * ((tc >> 5) + kBPairsPerPass * pass);
             unsigned int W[6][8];
             {
                 // twelve aligned 16-byte reads (512 contiguous bytes per 32 lanes: conflict-free), issued as written: left to itself
