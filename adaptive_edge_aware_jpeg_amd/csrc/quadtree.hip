@@ -98,11 +98,26 @@ __device__ __forceinline__ ChunkEdges chunk_edges(const Geom &g, const QtGeom &q
     return E;
 }
 
+// The chunk kernels run on a grid of (sum over layers of ceil(nchunk / 4), batch): the layers have different chunk counts (a 4:2:0
+// chroma plane has a quarter of the luma's), and a grid sized for the largest layer launched twice as many waves as it needed.
+__device__ __forceinline__ bool locate_chunk_block(const QtGeom &q, int nl, int bx, int &l, unsigned &chunk0)
+{
+    for (l = 0; l < nl; l++) {
+        const int nb = (q.nchunk[l] + 3) >> 2;
+        if (bx < nb) { chunk0 = (unsigned)bx * 4u; return true; }
+        bx -= nb;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void k_qt_upper(Geom g, QtGeom q, const unsigned long long *__restrict__ edge_bits, unsigned char *__restrict__ pyr_all)
 {
-    const int l = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.y;
+    int l;
+    unsigned chunk;
+    if (!locate_chunk_block(q, g.nl, (int)blockIdx.x, l, chunk)) return;
     const int lane = threadIdx.x & 63;
-    const unsigned chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    chunk += threadIdx.x >> 6;
     const int ncell = q.ncell[l], ltot = q.ltot[l], cell = q.cell;
     if ((long long)chunk >= q.nchunk[l] || ltot <= 4) return;
     int ccx, ccy;
@@ -273,9 +288,12 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
                                                   const unsigned char *__restrict__ pyr_all, int *__restrict__ chunk_cnt,
                                                   unsigned short *__restrict__ lane_code)
 {
-    const int l = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.y;
+    int l;
+    unsigned chunk;
+    if (!locate_chunk_block(q, g.nl, (int)blockIdx.x, l, chunk)) return;
     const int lane = threadIdx.x & 63;
-    const unsigned chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    chunk += threadIdx.x >> 6;
     if ((long long)chunk >= q.nchunk[l]) return;
     const long long ncell2 = (long long)q.ncell[l] * q.ncell[l];
     const unsigned char *pyr = pyr_all + (long long)b * q.pyr_stride + q.pyr_off[l];
@@ -420,9 +438,12 @@ __global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restr
 // scans (deterministic, Morton-ordered lists, no global atomics).
 __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
 {
-    const int l = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.y;
+    int l;
+    unsigned chunk;
+    if (!locate_chunk_block(q, g.nl, (int)blockIdx.x, l, chunk)) return;
     const int lane = threadIdx.x & 63;
-    const unsigned chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    chunk += threadIdx.x >> 6;
     if ((long long)chunk >= q.nchunk[l]) return;
     const int *coff = qb.chunk_cnt + ((long long)b * q.chunk_stride + q.chunk_off[l] + chunk) * kChunkInts;
     CellNodes c[4];
@@ -493,11 +514,11 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static int max_chunks(const Geom &g, const QtGeom &q)
+static int chunk_blocks(const Geom &g, const QtGeom &q)      // workgroups of 4 chunks (one wave each), all layers of one image
 {
-    int m = 1;
-    for (int l = 0; l < g.nl; l++) if (q.nchunk[l] > m) m = q.nchunk[l];
-    return m;
+    int n = 0;
+    for (int l = 0; l < g.nl; l++) n += (q.nchunk[l] + 3) / 4;
+    return n;
 }
 
 void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsigned long long *edge_bits, const QtBuffers &qb)
@@ -505,11 +526,11 @@ void launch_qt_cells(hipStream_t st, const Geom &g, const QtGeom &q, const unsig
     // only the levels above a chunk (>= 5) live in global memory, and only when a node of that size can still be a leaf
     bool need = false;
     for (int l = 0; l < g.nl; l++) if (q.ltot[l] > 4 && (q.cell << 5) <= q.bmax) need = true;
-    if (need) hipLaunchKernelGGL(k_qt_upper, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, edge_bits, qb.pyr);
+    if (need) hipLaunchKernelGGL(k_qt_upper, dim3(chunk_blocks(g, q), g.B), dim3(256), 0, st, g, q, edge_bits, qb.pyr);
 }
 void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_count, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, qb.edge_bits, qb.pyr, qb.chunk_cnt, qb.lane_code);
+    hipLaunchKernelGGL(k_qt_count, dim3(chunk_blocks(g, q), g.B), dim3(256), 0, st, g, q, qb.edge_bits, qb.pyr, qb.chunk_cnt, qb.lane_code);
 }
 void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
@@ -517,7 +538,7 @@ void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuff
 }
 void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_emit, dim3((max_chunks(g, q) + 3) / 4, g.nl, g.B), dim3(256), 0, st, g, q, qb);
+    hipLaunchKernelGGL(k_qt_emit, dim3(chunk_blocks(g, q), g.B), dim3(256), 0, st, g, q, qb);
 }
 
 }  // namespace aej
