@@ -38,8 +38,9 @@ def check_image(enc, b, ref, tag):
         assert np.array_equal(got["coeffs"], ref[l]["coeffs"]), f"{tag} L{l} coeffs"
 
 
-@pytest.mark.parametrize("H,W,space,br", [(2160, 3840, "YCbCr", (4, 64)), (4320, 7680, "OKLAB", (4, 128))],
-                         ids=["4K-YCbCr-4-64", "8K-OKLAB-4-128"])
+@pytest.mark.parametrize("H,W,space,br", [(2160, 3840, "YCbCr", (4, 64)), (4320, 7680, "OKLAB", (4, 128)), (2160, 3840, "ICtCp", (4, 64)),
+                                          (2160, 3840, "JzAzBz", (8, 128)), (2160, 3840, "ICaCb", (4, 32)), (2160, 3840, "YCoCg-R", (2, 64))],
+                         ids=["4K-YCbCr-4-64", "8K-OKLAB-4-128", "4K-ICtCp-4-64", "4K-JzAzBz-8-128", "4K-ICaCb-4-32", "4K-YCoCg-R-2-64"])
 def test_single_full_size_image_matches_oracle(env, oracle, H, W, space, br):
     torch, A, bench = env
     x = bench.synth_batch(torch, 1, H, W, 20250718, torch.device("cuda", 0))
@@ -335,3 +336,31 @@ def test_begin_end_on_two_contexts(env, oracle):
     ref = oracle.encode_image(xs[0][0].cpu().numpy(), space, qr, br)
     from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
     check_image(EncodedBatch(plan, *want[0]), 0, ref, "blocking call")
+
+
+def test_randomised_parity_sweep(env, oracle):
+    """A bounded, seeded slice of tools/profiling/fuzz_gpu.py inside the suite: random sizes (ragged and aligned), colour spaces,
+    block ranges, quality ranges and image kinds (8-bit levels and arbitrary floats) -- whole encode and decode against the oracle."""
+    torch, A, bench = env
+    rng = np.random.default_rng(20250718)
+    spaces = ["YCbCr", "YCoCg", "YCoCg-R", "OKLAB", "ICtCp", "ICaCb", "JzAzBz"]
+    for case in range(24):
+        space = spaces[case % len(spaces)]
+        H, W = int(rng.integers(5, 420)), int(rng.integers(5, 560))
+        if rng.random() < 0.3:
+            H, W = (H // 4 + 1) * 4, (W // 4 + 1) * 4
+        lo = int(2 ** rng.integers(1, 5))
+        hi = min(int(lo * 2 ** rng.integers(0, 5)), 256)
+        q = tuple(sorted(int(v) for v in rng.integers(5, 96, size=2)))
+        kind = ["mixed", "noise", "flat", "mixed"][rng.integers(4)]
+        img = oracle.synth_image(H, W, int(rng.integers(1 << 30)), kind).astype(np.float32) / np.float32(255.0)
+        if rng.random() < 0.3:            # arbitrary floats beside 8-bit levels
+            img = np.where(rng.random((H, W, 1)) < 0.5, img, rng.random((H, W, 3), dtype=np.float32)).astype(np.float32)
+        tag = f"case {case}: {space} {H}x{W} blocks ({lo},{hi}) q {q} {kind}"
+        codec = A.Jpeg(A.JpegCompressionSettings(space, q, (lo, hi)))
+        enc = codec.compress_batch(img[None])
+        ref = oracle.encode_image(img, space, q, (lo, hi))
+        check_image(enc, 0, ref, tag)
+        dec = codec.decompress_batch(enc).cpu().numpy()[0]
+        want = oracle.decode_image(oracle.write_ajpg(ref, H, W, space, q, (lo, hi), ".png"))
+        assert np.array_equal(dec, want, equal_nan=True), tag + " decode"
