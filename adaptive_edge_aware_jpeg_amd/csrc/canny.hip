@@ -727,6 +727,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
     const long long pbase = (long long)b * g.pstride + g.poff[l];
     const unsigned char *src = cb.u8b + pbase;
     const int low = cb.thr[((long long)b * 3 + l) * 2], high = cb.thr[((long long)b * 3 + l) * 2 + 1];
+    const int wpr = g.wpr[l];            // (once: indexing the kernel-argument array with `l` inside the row loop was a kernarg load + wait per row)
     unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
     unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
     auto is_aligned = [&](int tx) {
@@ -859,8 +860,8 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
             }
             unsigned long long wmask = __ballot(res == 0), smask = __ballot(res == 2);
             if (i == 0 && gy < h) {
-                wk[bp_index(gy, tx, g.wpr[l])] = wmask;
-                sg[bp_index(gy, tx, g.wpr[l])] = smask;
+                wk[bp_index(gy, tx, wpr)] = wmask;
+                sg[bp_index(gy, tx, wpr)] = smask;
             }
         }
         __syncthreads();       // M / G are rewritten by the next tile's stage 1
