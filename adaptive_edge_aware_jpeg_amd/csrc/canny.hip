@@ -833,6 +833,8 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
 
         // ---- stage 2: NMS, one wave per 64-pixel row segment
         const int i = tid & 63;
+        static_assert(64 % kBlurTH == 0, "a tile's rows must stay inside one 64-row band of the bit-plane");
+        const long long bp_tile = bp_index(y0, tx, wpr);
 #pragma unroll 2
         for (int j = tid >> 6; j < kBlurTH; j += 4) {
             const int gx = x0 + i, gy = y0 + j;
@@ -860,8 +862,8 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
             }
             unsigned long long wmask = __ballot(res == 0), smask = __ballot(res == 2);
             if (i == 0 && gy < h) {
-                wk[bp_index(gy, tx, wpr)] = wmask;
-                sg[bp_index(gy, tx, wpr)] = smask;
+                wk[bp_tile + j] = wmask;           // the 32 rows of a tile lie in one 64-row band of the tile-major bit-plane
+                sg[bp_tile + j] = smask;
             }
         }
         __syncthreads();       // M / G are rewritten by the next tile's stage 1
