@@ -57,6 +57,7 @@ struct aej_ctx {
     // each one stage behind the previous, so that HBM-bound stages (colour planes, DCT) of one run beside the issue-bound stages
     // (blur, Sobel / NMS, quadtree) of another
     int sub_mode = 0;                  // 0 automatic, 1 never split, n > 1 split into n (when the batch allows)
+    int hw_queues = 4;                 // GPU_MAX_HW_QUEUES as the process environment has it (HIP's default 4): streams beyond it share hardware queues
     static constexpr int kMaxSub = 8;
     hipStream_t sub_stream[kMaxSub] = {};
     hipEvent_t sub_color_done[kMaxSub] = {}, sub_in = nullptr;
@@ -352,7 +353,8 @@ extern "C" aej_ctx *aej_create(int device, void *hip_stream)
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
-    if (const char *e = getenv("AEJ_SUB_CHAIN")) ctx->sub_chain = atoi(e);      // tuning knob of the sub-batch pipelining (tools/profiling)
+    if (const char *e = getenv("AEJ_SUB_CHAIN")) ctx->sub_chain = atoi(e);
+    if (const char *e = getenv("GPU_MAX_HW_QUEUES")) { const int v = atoi(e); if (v > 0) ctx->hw_queues = v; }      // tuning knob of the sub-batch pipelining (tools/profiling)
     return ctx;
 }
 
@@ -921,8 +923,8 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
 }
 
 // ---- sub-batch pipelining ------------------------------------------------------------------------------------
-// How many sub-batches a call is cut into.  Automatic: 2 for calls of at least 64 Mpx and 8 images (measured on 64 x 4K: 8.6 ->
-// 8.1 ms; 4 sub-batches 8.4 ms; smaller calls have too few workgroups per kernel to share the chip).  Never for profiled calls (the
+// How many sub-batches a call is cut into (automatic mode: by call size and by how many hardware queues the process has, below;
+// smaller calls have too few workgroups per kernel to share the chip).  Never for profiled calls (the
 // stage timings describe the serial chain), graph replay, the verified (host-synchronising) hysteresis loop, or shapes that need the
 // host-built INTER_AREA tables.
 static int sub_batches(const aej_ctx *ctx, const Geom &g)
@@ -930,11 +932,19 @@ static int sub_batches(const aej_ctx *ctx, const Geom &g)
     if (ctx->sub_mode == 1 || ctx->profiling || ctx->graph_mode == 2 || !planes_fast_ok(g) || !ctx->hyst_speculate) return 1;
     int n = ctx->sub_mode;
     if (n == 0) {
-        // automatic: two sub-batches for a large call that has the device to itself; a caller that keeps calls in flight on other
-        // contexts (aej_encode_batch_begin / _end) already fills the gaps, and more than two chains side by side measured slower
-        bool alone;
-        { std::lock_guard<std::mutex> lock(g_chain_mutex); alone = ctx->device >= 64 || g_calls_in_flight[ctx->device] == 0; }
-        n = (alone && (long long)g.B * g.H * g.W >= (64LL << 20) && g.B >= 8) ? 2 : 1;
+        const long long px = (long long)g.B * g.H * g.W;
+        if (ctx->hw_queues >= 8) {
+            // every stream has a hardware queue of its own: four chains for a 64 x 4K call, two for a 64 x 1080p or 8 x 8K one, also
+            // beside a call in flight on another context (64 x 4K, two contexts: 7.45 ms with 4 sub-batches each, 7.5 with 2, 7.75 with
+            // none, 8.2 with 8; 64 x 1080p: 2.11 ms with 2, 2.26 with 4)
+            n = (px >= (384LL << 20) && g.B >= 16) ? 4 : (px >= (64LL << 20) && g.B >= 8) ? 2 : 1;
+        } else {
+            // HIP's default of 4 hardware queues: streams start to share queues (two streams on one queue run one after the other), so
+            // two sub-batches, and only for a call that has the device to itself (with 4 queues: 4 sub-batches 8.4 ms, 2: 8.1 ms)
+            bool alone;
+            { std::lock_guard<std::mutex> lock(g_chain_mutex); alone = ctx->device >= 64 || g_calls_in_flight[ctx->device] == 0; }
+            n = (alone && px >= (64LL << 20) && g.B >= 8) ? 2 : 1;
+        }
     }
     if (n > aej_ctx::kMaxSub) n = aej_ctx::kMaxSub;
     if (n > g.B) n = g.B;

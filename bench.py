@@ -211,6 +211,10 @@ def main():
     if args.rehearse_control_flow:
         return rehearse(args)
 
+    # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue run one after the other;
+    # this process uses one stream per context plus the library's sub-batch streams, so give every stream a queue of its own
+    # (must be set before the HIP runtime initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     rank, local_rank, world = rank_env()
     # rehearsal switches (not used by the driver): AEJ_BENCH_BACKEND=gloo + AEJ_BENCH_ONE_DEVICE=1 run the multi-rank control flow
@@ -266,7 +270,9 @@ def main():
                 jpeg.encode_begin(self.ctx, batches[which], self.plan, *self.out)
             self.pending, self.input = True, which
 
-    pipes = [Pipe(torch.cuda.current_stream(dev))] + [Pipe(torch.cuda.Stream(device=dev)) for _ in range(args.pipeline - 1)]
+    # every context on a stream of its own, none on the legacy null stream: once other streams exist, launches on the null stream shift
+    # the HIP-event stage attribution (colour planes +0.25 ms, blur -0.09 ms, profiles/r02_null_stream_stage_attribution.txt)
+    pipes = [Pipe(torch.cuda.Stream(device=dev)) for _ in range(args.pipeline)]
     torch.cuda.synchronize()
     ctx, plan = pipes[0].ctx, pipes[0].plan
     coeffs, leaves, states, counts = pipes[0].out

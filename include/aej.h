@@ -104,8 +104,9 @@ AEJ_API int aej_set_graph_mode(aej_ctx *ctx, int mode);
 /* Throughput path: aej_encode_batch cuts a large call into sub-batches (contiguous image ranges, the unit the reference's sweep
  * hands to one worker, metrics_computation.py:253) that run the whole chain on private streams, each one stage behind the previous,
  * so that the HBM-bound stages of one sub-batch (colour planes, DCT) run beside the issue-bound stages of another (blur, Sobel / NMS,
- * quadtree).  n = 0: automatic (the default: 2 sub-batches for calls of at least 64 Mpx and 8 images while no other context has a call
- * in flight on the device), 1: never, 2..8: that many.
+ * quadtree).  n = 0: automatic (the default: by call size -- 4 sub-batches from 384 Mpx / 16 images, 2 from 64 Mpx / 8 images -- when the
+ * process runs with GPU_MAX_HW_QUEUES >= 8, so that every stream has a hardware queue of its own; with HIP's default of 4 queues: 2
+ * sub-batches, and only while no other context has a call in flight), 1: never, 2..8: that many.
  * Outputs are identical; the call still returns with everything complete.  aej_encode_plan's workspace_bytes covers every split. */
 AEJ_API int aej_set_sub_batches(aej_ctx *ctx, int n);
 /* The two halves of aej_encode_batch / aej_encode_batch_u8 (same arguments; rgb_is_u8 selects the ingest): _begin enqueues the whole
