@@ -121,11 +121,11 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 //
 // This kernel is bound by the LDS pipe, not by VALU issue or HBM (PMC: the LDS array is busy > 70 % of the kernel's time,
 // profiles/r02_blur_pmc.txt), so its structure minimises LDS cycles per pixel:
-//   * 512-thread workgroups on 128 x 64 output tiles (2 workgroups per CU): the staged halo is 16 % / 13 % of the tile for the
+//   * 256-thread workgroups on 128 x 32 output tiles (3 workgroups per CU; shape and why below): the staged halo is 27 % / 20 % of the tile for the
 //     CLAHE / Gaussian images instead of 34 % / 27 % with 64 x 32 tiles;
 //   * stage A (CLAHE): the four tile LUTs a pixel blends are pre-packed, per workgroup, into one float4 per input value
 //     ("packed LUT": { L[ty1][tx1][v], L[ty1][tx2][v], L[ty2][tx1][v], L[ty2][tx2][v] } as floats), so a pixel costs ONE
-//     16-byte LDS gather and no int -> float conversions instead of four byte gathers + four conversions.  A 136 x 70 window
+//     16-byte LDS gather and no int -> float conversions instead of four byte gathers + four conversions.  A 136 x 38 window
 //     rarely crosses a tile-centre line, and almost never one per axis: two packed LUTs are kept (windows that would need
 //     more -- tiny planes, the 0.5 % of tiles on a crossing of both axes -- take the general path that reads LUT bytes from
 //     global memory); a thread keeps its column for the whole tile, so the column weights live in registers;
@@ -138,9 +138,13 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 //     once and used for both pixels: 76 instead of 96 table gathers per 8 pixels.
 // Every float operation per pixel is the same single IEEE operation in the same order as before (and as the CPU oracle).
 // ------------------------------------------------------------------------------------------------
-constexpr int kBT = 512;                  // threads per workgroup (a 384-thread / 128 x 48 / 168-VGPR variant without the spills measured 3.8 ms: uneven waves per SIMD)
-constexpr int kBTW = 128, kBTH = 64;      // output tile
-constexpr int kBMinWaves = 4;             // waves per SIMD the register budget is sized for (128 VGPRs; about 40 dwords per lane spill to scratch in stage C)
+// Workgroup shape.  Alone, 512 threads on 128 x 64 tiles (two workgroups per CU, 128 VGPRs with ~40 dwords of spills, 9 % halo) is the
+// fastest: 2.19 ms against 2.32 ms for 256 threads on 128 x 32 tiles (three workgroups per CU, 168 VGPRs, 16 % halo).  But this kernel
+// never runs alone in the throughput path -- it shares the chip with the HBM-bound stages of other sub-batches -- and
+// there the smaller footprint wins: resources change hands in units of 51 KiB LDS / one wave per SIMD instead of 77 KiB / two, and the
+// 64 x 4K step goes from 7.50 to 7.33 ms (256 threads on 128 x 64 tiles, 235 VGPRs: 7.44; 384 threads on 128 x 48: 3.8 ms alone).
+constexpr int kBT = 256;                  // threads per workgroup
+constexpr int kBTW = 128, kBTH = 32;      // output tile
 constexpr int kBPairsPerPass = kBT / 32;  // stage C: row pairs one pass of the workgroup covers
 static_assert(kBTH % (2 * kBPairsPerPass) == 0, "stage C passes must tile the rows");
 constexpr int kBAW = kBTW + 8;            // staged columns: c <-> gx = x0 - 4 + c (bytes per CLAHE row, dwords per Gaussian row)
@@ -151,11 +155,11 @@ constexpr int kBGW = kBAW + 4;            // Gaussian row stride in dwords; stag
                                           // a bilateral thread (columns 4 c4 + 2 .. 4 c4 + 9) is two ALIGNED 16-byte reads (conflict-free)
 constexpr int kBStripMax = 8;             // tiles of one tile-row handled by one workgroup (tables / histogram stay in LDS); fewer when
                                           // the batch is small, so that a single image still spreads over the whole chip
-constexpr int kASlots = kBT / kBAW4;      // 15 row slots: thread t owns column dword t % 34 and rows t / 34 + 15 k
-constexpr int kAIter = (kBAH + kASlots - 1) / kASlots;   // 5
-constexpr int kBRows = 5;                 // Gaussian output rows per thread: rows 5 * (t / 34) .. + 4
+constexpr int kASlots = kBT / kBAW4;      // 7 row slots: thread t owns column dword t % 34 and rows t / 34 + 7 k
+constexpr int kAIter = (kBAH + kASlots - 1) / kASlots;   // 6
+constexpr int kBRows = (kBGH + kASlots - 1) / kASlots;      // Gaussian output rows per thread: rows kBRows * (t / 34) .. + kBRows - 1
 static_assert(kASlots * kBRows >= kBGH && kASlots * kAIter >= kBAH, "thread -> row mapping must cover the tile");
-constexpr int kHistCopies = 12;
+constexpr int kHistCopies = 8;             // (8 copies keep the workgroup under a third of the LDS)
 constexpr int kHistStride = 257;          // dwords per histogram copy: odd, so the same bin of different copies sits in different banks
 
 // Member order matters: DS instructions carry a 16-bit immediate offset, so everything addressed with small compile-time offsets
@@ -177,7 +181,7 @@ struct __attribute__((aligned(16))) BlurLds {
     unsigned int A[kBAH * kBAW4];    // CLAHE image, one byte per pixel
     unsigned int G[kBGH * kBGW];     // Gaussian image, one dword per pixel: bit pattern of the float 2^23 + 4 * value
 };
-static_assert(sizeof(BlurLds) <= 80 * 1024, "two workgroups per CU");
+static_assert(3 * sizeof(BlurLds) <= 160 * 1024, "three workgroups per CU");
 
 // 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2): (dy, dx) =
 // (-2,0) (-1,-1) (-1,0) (-1,1) (0,-2) (0,-1) (0,0) (0,1) (0,2) (1,-1) (1,0) (1,1) (2,0).  The weight of a tap is
@@ -243,7 +247,7 @@ __device__ __forceinline__ bool locate_blur_strip(const Geom &g, int strip, int 
     return false;
 }
 
-__global__ __launch_bounds__(kBT, kBMinWaves) void k_clahe_blur(Geom g, CannyBuffers cb, int strip)
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD: 168 VGPRs
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;
