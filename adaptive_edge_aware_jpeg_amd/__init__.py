@@ -5,13 +5,12 @@ Same Python surface as the reference for this path (fevzibabaoglu/adaptive-edge-
 ``apply_normalization``, ``get_color_spaces``.  The arithmetic runs in hand-written HIP kernels behind the
 C ABI of ``libaejpeg_hip.so`` (include/aej.h); there is no CPU fallback.
 """
-import os as _os
+from ._lib import hw_queues, request_hw_queues as _request_hw_queues, set_hw_queues
 
-# HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); two streams on one queue run one after the other.  The
-# library overlaps sub-batches and calls on several streams (DESIGN.md 4a), so ask for a queue per stream -- effective when this
-# package is imported before the process makes its first HIP call (the runtime reads the variable when it initialises; the library
-# reads the same variable and falls back to a two-stream schedule when it is absent or smaller than 8).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Streams beyond the HIP runtime's hardware queues share queues and serialise; the library's overlap of sub-batches and calls wants a
+# queue per stream.  The policy (and why importing this package after HIP has initialised changes nothing in the environment) is
+# written down in _lib.py; `hw_queues()` reports what the library schedules for and `set_hw_queues(n)` overrides it.
+_request_hw_queues()
 
 from .color import apply_normalization, convert, get_color_spaces  # noqa: E402
 from .edge_detection import EdgeDetection  # noqa: E402
@@ -22,4 +21,4 @@ from .quadtree import QuadNode, QuadTree  # noqa: E402
 from .settings import JpegCompressionSettings  # noqa: E402
 
 __all__ = ["Jpeg", "JpegCompressionSettings", "EncodedBatch", "Image", "EvaluationMetrics", "EdgeDetection", "QuadTree", "QuadNode",
-           "convert", "apply_normalization", "get_color_spaces"]
+           "convert", "apply_normalization", "get_color_spaces", "hw_queues", "set_hw_queues"]

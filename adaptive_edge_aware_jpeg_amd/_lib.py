@@ -39,6 +39,58 @@ class AejPlan(ctypes.Structure):
 _lib = None
 _lib_lock = threading.Lock()
 
+# ---- hardware queues ------------------------------------------------------------------------------------------------
+# HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue run one after the other.
+# The library overlaps sub-batches and calls on several streams and picks its schedule by the number of queues --
+# which only the host can know: the runtime reads the variable once, when it initialises.  Policy:
+#   * package imported BEFORE the process's first HIP call (torch.cuda not initialised): ask for 16 queues unless the variable is
+#     already set (or AEJ_KEEP_HW_QUEUES=1 forbids touching the environment), and trust the variable's value;
+#   * HIP already initialised at import: the environment is left alone and says nothing reliable -> assume HIP's default of 4 (the
+#     conservative two-sub-batch schedule) unless the application states the value with set_hw_queues().
+HIP_DEFAULT_HW_QUEUES = 4
+_hw_queues = HIP_DEFAULT_HW_QUEUES
+_hw_queues_source = "HIP default (assumed)"
+
+
+def _hip_initialised():
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        return True
+
+
+def request_hw_queues(want=16):
+    """Called once at package import (see the policy above)."""
+    global _hw_queues, _hw_queues_source
+    if _hip_initialised():
+        _hw_queues, _hw_queues_source = HIP_DEFAULT_HW_QUEUES, "HIP was initialised before this package was imported: HIP's default assumed"
+        return _hw_queues
+    if "GPU_MAX_HW_QUEUES" not in os.environ and not os.environ.get("AEJ_KEEP_HW_QUEUES"):
+        os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+    try:
+        v = int(os.environ.get("GPU_MAX_HW_QUEUES", HIP_DEFAULT_HW_QUEUES))
+    except ValueError:
+        v = HIP_DEFAULT_HW_QUEUES
+    _hw_queues, _hw_queues_source = (v if v > 0 else HIP_DEFAULT_HW_QUEUES), "GPU_MAX_HW_QUEUES at import, before HIP initialised"
+    return _hw_queues
+
+
+def set_hw_queues(n):
+    """For applications that initialise HIP before importing this package: the value of GPU_MAX_HW_QUEUES their runtime started
+    with.  Applies to contexts created afterwards and to the existing ones."""
+    global _hw_queues, _hw_queues_source
+    _hw_queues, _hw_queues_source = int(n), "stated by the application (set_hw_queues)"
+    for ctx in _contexts.values():
+        ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, _hw_queues))
+
+
+def hw_queues():
+    """-> (queues the library schedules for, where the number comes from)"""
+    return _hw_queues, _hw_queues_source
+
+
 # name -> (restype, argtypes); exactly the symbols declared in include/aej.h
 _P, _I, _I64, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
 class CannyParams(ctypes.Structure):
@@ -58,6 +110,9 @@ SIGNATURES = {
     "aej_get_hysteresis_stats": (_I, [_P, _P]),
     "aej_set_graph_mode": (_I, [_P, _I]),
     "aej_set_sub_batches": (_I, [_P, _I]),
+    "aej_set_hw_queues": (_I, [_P, _I]),
+    "aej_get_schedule_host": (_I, [_P, _I, _I, _I, _P]),
+    "aej_test_fail_after_stage": (_I, [_P, _I]),
     "aej_encode_batch_begin": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _U64]),
     "aej_encode_batch_end": (_I, [_P]),
     "aej_get_split_calls": (ctypes.c_int64, [_P]),
@@ -132,6 +187,7 @@ class Context:
         self.handle = self.lib.aej_create(self.device.index, ctypes.c_void_p(self.stream))
         if not self.handle:
             raise AejError(self.lib.aej_last_error(None).decode())
+        self.check(self.lib.aej_set_hw_queues(self.handle, _hw_queues))
         self.settings_key = None
         self._ws = None
 
@@ -191,6 +247,12 @@ class Context:
     def set_sub_batches(self, n):
         """0 = automatic (default), 1 = never split a call, 2..8 = that many sub-batches on private streams (include/aej.h)"""
         self.check(self.lib.aej_set_sub_batches(self.handle, int(n)))
+
+    def schedule(self, batch, H, W):
+        """-> dict(hw_queues, sub_batches, limited): what the automatic mode would do for this call (aej_get_schedule_host)"""
+        buf = (ctypes.c_int32 * 4)()
+        self.check(self.lib.aej_get_schedule_host(self.handle, int(batch), int(H), int(W), ctypes.cast(buf, ctypes.c_void_p)))
+        return {"hw_queues": int(buf[0]), "sub_batches": int(buf[1]), "limited_by_hw_queues": bool(buf[2]), "hw_queues_source": _hw_queues_source}
 
     def split_calls(self):
         return int(self.lib.aej_get_split_calls(self.handle))

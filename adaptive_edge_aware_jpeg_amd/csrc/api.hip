@@ -57,7 +57,8 @@ struct aej_ctx {
     // each one stage behind the previous, so that HBM-bound stages (colour planes, DCT) of one run beside the issue-bound stages
     // (blur, Sobel / NMS, quadtree) of another
     int sub_mode = 0;                  // 0 automatic, 1 never split, n > 1 split into n (when the batch allows)
-    int hw_queues = 4;                 // GPU_MAX_HW_QUEUES as the process environment has it (HIP's default 4): streams beyond it share hardware queues
+    int hw_queues = 4;                 // hardware queues the runtime maps streams onto, as the host states it (aej_set_hw_queues; HIP's default 4): streams beyond it share queues
+    int fail_after = -1;               // aej_test_fail_after_stage (test instrumentation)
     static constexpr int kMaxSub = 8;
     hipStream_t sub_stream[kMaxSub] = {};
     hipEvent_t sub_color_done[kMaxSub] = {}, sub_in = nullptr;
@@ -102,6 +103,16 @@ static void mark(aej_ctx *ctx, int stage)
     ctx->ev_stage[ctx->n_ev] = stage;   // the stage that ENDS at this event
     (void)hipEventRecord(ctx->ev[ctx->n_ev], ctx->stream);
     ctx->n_ev++;
+}
+
+extern "C" const char *aej_stage_name(int i);
+// test instrumentation (aej_test_fail_after_stage): one-shot failure right after `stage` has been enqueued
+static int injected_failure(aej_ctx *ctx, int stage)
+{
+    if (ctx->fail_after != stage) return 0;
+    ctx->fail_after = -1;
+    ctx->err = std::string("injected failure after stage ") + aej_stage_name(stage);
+    return AEJ_ERR_STATE;
 }
 
 static void collect_marks(aej_ctx *ctx)
@@ -354,7 +365,6 @@ extern "C" aej_ctx *aej_create(int device, void *hip_stream)
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
     if (const char *e = getenv("AEJ_SUB_CHAIN")) ctx->sub_chain = atoi(e);
-    if (const char *e = getenv("GPU_MAX_HW_QUEUES")) { const int v = atoi(e); if (v > 0) ctx->hw_queues = v; }      // tuning knob of the sub-batch pipelining (tools/profiling)
     return ctx;
 }
 
@@ -927,13 +937,13 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
 // smaller calls have too few workgroups per kernel to share the chip).  Never for profiled calls (the
 // stage timings describe the serial chain), graph replay, the verified (host-synchronising) hysteresis loop, or shapes that need the
 // host-built INTER_AREA tables.
-static int sub_batches(const aej_ctx *ctx, const Geom &g)
+static int sub_batches(const aej_ctx *ctx, const Geom &g, int hw_queues)
 {
     if (ctx->sub_mode == 1 || ctx->profiling || ctx->graph_mode == 2 || !planes_fast_ok(g) || !ctx->hyst_speculate) return 1;
     int n = ctx->sub_mode;
     if (n == 0) {
         const long long px = (long long)g.B * g.H * g.W;
-        if (ctx->hw_queues >= 8) {
+        if (hw_queues >= 8) {
             // every stream has a hardware queue of its own: four chains for a 64 x 4K call, two for a 64 x 1080p or 8 x 8K one, also
             // beside a call in flight on another context (64 x 4K, two contexts: 7.45 ms with 4 sub-batches each, 7.5 with 2, 7.75 with
             // none, 8.2 with 8; 64 x 1080p: 2.11 ms with 2, 2.26 with 4)
@@ -1002,6 +1012,7 @@ static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void
     }
     if ((rc = run_color_planes(ctx, rgb, in_u8, p.g, nullptr, p.w.norm, p.w.canny.cb.u8a, p.w.canny.cb.tile_hist, p.w.area_tabs))) return rc;
     mark(ctx, AEJ_STAGE_COLOR_PLANES);
+    if ((rc = injected_failure(ctx, AEJ_STAGE_COLOR_PLANES))) return rc;
     auto publish = [&]() -> int {
         std::lock_guard<std::mutex> lock(g_chain_mutex);
         AEJ_HIP_CHECK(hipEventRecord(done, ctx->stream));
@@ -1009,12 +1020,16 @@ static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void
         return 0;
     };
     if (chain && chain_mode == 1 && (rc = publish())) return rc;
+    // (the hook is cleared on every exit: a later stand-alone aej_canny on this context must not re-record the shared chain event)
+    struct HookGuard { aej_ctx *c; ~HookGuard() { c->chain_hook = 0; } } hook_guard{ ctx };
     ctx->chain_hook = (chain && chain_mode > 1) ? chain_mode : 0;
     ctx->chain_event = done;
     if ((rc = run_canny_chain(ctx, p.g, p.w.canny, true))) return rc;      // first call (no hint yet): verified loop, synchronises this stream
     ctx->chain_hook = 0;
     p.n_spec = ctx->hyst_enqueued;
+    if ((rc = injected_failure(ctx, AEJ_STAGE_HYSTERESIS))) return rc;
     if ((rc = enqueue_back(ctx, p.g, q, p.w, p.coeffs, p.dct))) return rc;
+    if ((rc = injected_failure(ctx, AEJ_STAGE_DCT_64))) return rc;
     return enqueue_readback(ctx, p.w, p.n_spec);      // one read-back for the whole part
 }
 
@@ -1035,7 +1050,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     if ((rc = ensure_canny_tables(ctx))) return rc;
     ctx->n_ev = 0;
     ctx->n_encode_calls++;
-    const int nsub = sub_batches(ctx, g);
+    const int nsub = sub_batches(ctx, g, ctx->hw_queues);
     pd.parts.assign((size_t)nsub, EncodePart());
     pd.complete = false;
     hipStream_t user = ctx->stream;
@@ -1053,15 +1068,20 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         bool graphed = false;
         const bool want_graph = ctx->graph_mode != 0 && !ctx->profiling && (hyst_small(g) || (ctx->hyst_speculate && ctx->hyst_hint > 0)) && planes_fast_ok(g) &&
                                 (ctx->graph_mode == 2 || (long long)batch * H * W <= kGraphAutoPixels);
-        if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, g, q, p.w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) return rc;
+        if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, g, q, p.w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) {
+            if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);       // a replay whose read-back failed may still be running
+            return rc;
+        }
         if (graphed) { p.n_spec = ctx->hyst_enqueued; pd.complete = true; }      // the replay path has synchronised its own stream
         else {
             if (!ctx->sub_color_done[0]) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->sub_color_done[0], hipEventDisableTiming));
-            if ((rc = enqueue_part(ctx, p, q, rgb, in_u8, hyst_small(g) ? nullptr : ctx->sub_color_done[0]))) return rc;      // (latency-sized calls stay out of the chain)
+            rc = enqueue_part(ctx, p, q, rgb, in_u8, hyst_small(g) ? nullptr : ctx->sub_color_done[0]);      // (latency-sized calls stay out of the chain)
         }
+        // also after an error: whatever enqueue_part had already put on the stream is drained by the caller (encode_end_impl), exactly as
+        // on the sub-batch path below
         pd.active = started = true;
         { std::lock_guard<std::mutex> lock(g_chain_mutex); if (ctx->device < 64) g_calls_in_flight[ctx->device]++; }
-        return 0;
+        return rc;
     }
 
     // ---- sub-batches on private streams
@@ -1632,6 +1652,36 @@ extern "C" int aej_set_sub_batches(aej_ctx *ctx, int n)
 }
 
 extern "C" int64_t aej_get_split_calls(aej_ctx *ctx) { return ctx ? (int64_t)ctx->n_split_calls : -1; }
+
+extern "C" int aej_set_hw_queues(aej_ctx *ctx, int n)
+{
+    if (!ctx || n < 1) return AEJ_ERR_ARG;
+    ctx->hw_queues = n;
+    return 0;
+}
+
+extern "C" int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int32_t *out_host)
+{
+    int rc = check_encode_args(ctx, batch, H, W);
+    if (rc) return rc;
+    if (!out_host) return fail(ctx, AEJ_ERR_ARG, "out_host is NULL");
+    Geom g;
+    if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
+    const int n = sub_batches(ctx, g, ctx->hw_queues), n_wide = sub_batches(ctx, g, 16);
+    out_host[0] = ctx->hw_queues;
+    out_host[1] = n;
+    out_host[2] = (ctx->hw_queues < 8 && n_wide > n) ? 1 : 0;
+    out_host[3] = 0;
+    if (out_host[2]) ctx->err = "fewer than 8 hardware queues (GPU_MAX_HW_QUEUES, read by the HIP runtime at its initialisation): the two-sub-batch schedule is used";
+    return 0;
+}
+
+extern "C" int aej_test_fail_after_stage(aej_ctx *ctx, int stage)
+{
+    if (!ctx || stage < -1 || stage >= AEJ_N_STAGES) return AEJ_ERR_ARG;
+    ctx->fail_after = stage;
+    return 0;
+}
 
 extern "C" int aej_get_graph_stats(aej_ctx *ctx, int64_t *out_host)
 {

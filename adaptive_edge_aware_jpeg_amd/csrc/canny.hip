@@ -180,8 +180,19 @@ struct __attribute__((aligned(16))) BlurLds {
     float4 P[2][256];                // packed LUTs: slot 0 = class 0 of both axes, slot 1 = class 1 of the ONE axis that changes
     unsigned int A[kBAH * kBAW4];    // CLAHE image, one byte per pixel
     unsigned int G[kBGH * kBGW];     // Gaussian image, one dword per pixel: bit pattern of the float 2^23 + 4 * value
+#ifdef AEJ_X_BLUR_PAD
+    char pad[AEJ_X_BLUR_PAD];        // experiment (tools/profiling/variants.py): a larger footprint caps the workgroups per CU
+#endif
 };
+#ifndef AEJ_X_BLUR_PAD
 static_assert(3 * sizeof(BlurLds) <= 160 * 1024, "three workgroups per CU");
+#endif
+#ifndef AEJ_X_BLUR_WAVES
+#define AEJ_X_BLUR_WAVES 3
+#endif
+#ifndef AEJ_X_BLUR_ATTR
+#define AEJ_X_BLUR_ATTR __attribute__((amdgpu_waves_per_eu(AEJ_X_BLUR_WAVES, AEJ_X_BLUR_WAVES)))
+#endif
 
 // 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2): (dy, dx) =
 // (-2,0) (-1,-1) (-1,0) (-1,1) (0,-2) (0,-1) (0,0) (0,1) (0,2) (1,-1) (1,0) (1,1) (2,0).  The weight of a tap is
@@ -247,7 +258,7 @@ __device__ __forceinline__ bool locate_blur_strip(const Geom &g, int strip, int 
     return false;
 }
 
-__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD: 168 VGPRs
+__global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD: 168 VGPRs
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;

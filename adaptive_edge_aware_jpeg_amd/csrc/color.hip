@@ -10,6 +10,7 @@
 #include "aej_common.h"
 #include "aej_launch.h"
 #include "aej_devmath.h"
+#include <stdlib.h>
 
 namespace aej {
 
@@ -310,6 +311,242 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
 }
 
 // ------------------------------------------------------------------------------------------------
+// Strip version of the fused plane kernel (round 3): the shapes every BASELINE configuration has (W % 16 == 0, H % 8 == 0, so the
+// CLAHE tiles are W/4 x H/4 without padding and a 4 x 2 patch never straddles a tile edge in any layer).  A workgroup owns a
+// 128-pixel-wide column (128-aligned, so every row segment it writes is whole 128-byte lines) and walks down `rows` rows of ONE
+// CLAHE tile row, 16 rows per iteration, so that
+//   * the histogram is zeroed and flushed once per strip instead of once per 2048 pixels (the 128 x 16 kernel above spends 24 LDS
+//     accesses and up to 12 global atomics per thread on that), and needs two slots of 3 x 256 counters only: a 128-pixel column
+//     meets at most one vertical tile edge, a thread's columns lie on one side of it for the whole strip, so its slot is a constant
+//     LDS base -- no tile test per update; columns that meet no edge use the two slots as lane-striped copies (odd stride: equal
+//     values of neighbouring pixels land in different banks);
+//   * the kernel's footprint is small on purpose -- 6 KiB of LDS, at most 56 VGPRs -- so that one of its workgroups fits on a CU
+//     beside three resident workgroups of the blur kernel (3 x 152 VGPRs per SIMD, 3 x 50.5 KiB): the HBM-bound stage of one chain
+//     then really shares SIMDs with the issue-bound stage of another.
+// Per-pixel arithmetic is the same sequence of single IEEE operations as k_color_planes.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStripSlots = 2;
+constexpr int kStripHistStride = 257;
+
+// PROD: the whole-path call (normalised + uint8 planes and the histograms wanted, no raw planes): the per-output null tests, which
+// otherwise are a scalar compare + branch per store, fold away.
+//
+// Thread -> pixels: lanes 0..31 of a 32-lane half-wave own the 4-pixel columns of the 128-pixel strip, the 8 half-waves own 8 bands
+// of rows / 8 consecutive rows; a thread walks down its band TWO rows per step and keeps the next row's 48 bytes in flight while it
+// converts the current one (row B is requested before row A is touched, the next row A as soon as row A's registers are free), so
+// a wave always has loads outstanding -- the kernel is meant to stream at few waves per CU.
+template <typename IN> struct RowRaw;
+template <> struct RowRaw<float> { float4 a, b, c; };
+template <> struct RowRaw<unsigned char> { unsigned int d[3]; };
+
+template <typename IN>
+__device__ __forceinline__ RowRaw<IN> strip_load_row(const IN *img, unsigned byte_off)
+{
+    RowRaw<IN> r;
+    if constexpr (sizeof(IN) == 1) {
+        const unsigned int *p = reinterpret_cast<const unsigned int *>(reinterpret_cast<const char *>(img) + byte_off);
+        r.d[0] = p[0]; r.d[1] = p[1]; r.d[2] = p[2];
+    } else {
+        const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(img) + byte_off);
+        r.a = p[0]; r.b = p[1]; r.c = p[2];
+    }
+    return r;
+}
+
+template <int SPACE, int RH, int RW, typename IN, bool PROD>
+__global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict__ rgb, Geom g, NormConst nc, float *__restrict__ planes_raw,
+                                                            float *__restrict__ planes_norm, unsigned char *__restrict__ planes_u8,
+                                                            int *__restrict__ tile_hist, int nxb, int nys, int rows, int nstrips)
+{
+    __shared__ int s_hist[3 * kStripSlots * kStripHistStride];
+    const int tid = threadIdx.x;
+    constexpr bool kU8 = sizeof(IN) == 1;
+    constexpr bool kLin = SPACE >= 3;
+    __shared__ float s_u8f[(kU8 || kLin) ? 256 : 1];
+    __shared__ float s_lin[kLin ? 256 : 1];
+    __shared__ double s_pow[kLin ? 192 : 1];
+    PowTabs pt = pow_tabs_global();
+    if constexpr (kLin) {
+        if (tid < 192) s_pow[tid] = tid < 64 ? POW_INVC[tid] : tid < 128 ? POW_LOGC[tid - 64] : POW_EXP2T[tid - 128];
+        __syncthreads();
+        pt = PowTabs{ s_pow, s_pow + 64, s_pow + 128 };
+    }
+    if (kU8 || kLin) s_u8f[tid] = (float)tid / 255.0f;
+    if (kLin) s_lin[tid] = srgb_to_linear((float)tid / 255.0f, pt);
+    const bool do_hist = PROD || tile_hist != nullptr;
+    const bool has_norm = PROD || planes_norm != nullptr, has_raw = !PROD && planes_raw != nullptr, has_u8 = PROD || planes_u8 != nullptr;
+    if (kU8 || kLin) __syncthreads();
+    constexpr int kLayerInts = kStripSlots * kStripHistStride;
+    const long long poff1 = g.poff[1], poff2 = g.poff[2];
+    const unsigned in_row_bytes = (unsigned)g.W * 3u * (unsigned)sizeof(IN);
+
+    // one row of four pixels: colour transform, luma outputs, histogram; the chroma values come back to the caller
+    // (RH = RW = 2: the horizontal pair sums (c[0] + c[1], c[2] + c[3]) of both chroma channels; RH = 1, RW = 4: the row's finished
+    // means in h1[0] / h2[0])
+    auto do_row = [&](const RowRaw<IN> &raw, float (&h1)[2], float (&h2)[2], float *norm0, float *raw0, unsigned char *u80, unsigned o, lds_int *hcopy) {
+        float in[12];
+        if constexpr (kU8) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) in[k] = (kLin ? s_lin : s_u8f)[(raw.d[k >> 2] >> (8 * (k & 3))) & 0xffu];
+        } else {
+            in[0] = raw.a.x; in[1] = raw.a.y; in[2] = raw.a.z; in[3] = raw.a.w; in[4] = raw.b.x; in[5] = raw.b.y; in[6] = raw.b.z; in[7] = raw.b.w;
+            in[8] = raw.c.x; in[9] = raw.c.y; in[10] = raw.c.z; in[11] = raw.c.w;
+        }
+        if constexpr (kLin && !kU8) {
+            float lin[12];
+            bool hit = true;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                int idx = __float2int_rn(in[k] * 255.0f);
+                idx = idx < 0 ? 0 : idx > 255 ? 255 : idx;
+                hit = hit && (s_u8f[idx] == in[k]);
+                lin[k] = s_lin[idx];
+            }
+            if (!__all(hit)) {        // some value of this wave's rows is not k / 255.0f: those lanes take the float64 pow
+                if (!hit) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) lin[k] = srgb_to_linear(in[k], pt);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) in[k] = lin[k];
+        }
+        float c0[4], c1[4], c2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) color_px_lin<SPACE>(in[3 * k], in[3 * k + 1], in[3 * k + 2], c0[k], c1[k], c2[k], pt);
+        if constexpr (RH == 2 && RW == 2) {
+            h1[0] = c1[0] + c1[1]; h1[1] = c1[2] + c1[3];
+            h2[0] = c2[0] + c2[1]; h2[1] = c2[2] + c2[3];
+        } else {
+            h1[0] = (((c1[0] + c1[1]) + c1[2]) + c1[3]) * 0.25f; h1[1] = 0.f;
+            h2[0] = (((c2[0] + c2[1]) + c2[2]) + c2[3]) * 0.25f; h2[1] = 0.f;
+        }
+        if (has_norm)
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(norm0) + 4u * o) =
+                make_float4((c0[0] - nc.mid[0]) * nc.scale[0], (c0[1] - nc.mid[0]) * nc.scale[0], (c0[2] - nc.mid[0]) * nc.scale[0], (c0[3] - nc.mid[0]) * nc.scale[0]);
+        if (has_raw) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(raw0) + 4u * o) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+        uchar4 u;
+        u.x = scale_u8(c0[0]); u.y = scale_u8(c0[1]); u.z = scale_u8(c0[2]); u.w = scale_u8(c0[3]);
+        if (has_u8) *reinterpret_cast<uchar4 *>(u80 + o) = u;
+        if (do_hist) {
+            __hip_atomic_fetch_add(&hcopy[u.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hcopy[u.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hcopy[u.z], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hcopy[u.w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+
+    // Persistent over strips: the launch holds as many workgroups as the caller wants resident (one or two per CU when the kernel is
+    // to run in the gaps beside another chain's issue-bound kernels), each takes strips blockIdx.x, + gridDim.x, ... .  Strips are
+    // numbered x fastest, then tile row / strip row, then image, so that the workgroups in flight sweep the input linearly.
+    const int per_img = nxb * nys * 4;
+    for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int b = strip / per_img;
+        const int rem = strip - b * per_img;
+        const int yb_i = rem / nxb, xb_i = rem - yb_i * nxb;
+        if (do_hist) {
+            if (strip != (int)blockIdx.x) __syncthreads();          // the previous strip's flush has read the counters
+            // (fixed trip count from one address register: the kernel has to stay within 56 VGPRs)
+            constexpr int kHistInts = 3 * kStripSlots * kStripHistStride;
+#pragma unroll
+            for (int k = 0; k < kHistInts / 256; k++) s_hist[k * 256 + tid] = 0;
+            if (tid < kHistInts % 256) s_hist[(kHistInts / 256) * 256 + tid] = 0;
+            __syncthreads();
+        }
+        // the strip's rectangle: columns [x0, x0 + 128), rows [y0, yend) inside CLAHE tile row ty (the same tile indices hold in
+        // the chroma layers: their tiles are the luma tiles divided by the down-sampling ratios)
+        const int ty = yb_i / nys, ys = yb_i - ty * nys;
+        const int x0 = xb_i * 128;
+        const int y0 = ty * g.cth[0] + ys * rows, yend = min(y0 + rows, (ty + 1) * g.cth[0]);
+        const int tx0 = x0 / g.ctw[0];                 // CLAHE tile column of the strip's first pixel
+        const int xedge = (tx0 + 1) * g.ctw[0];        // the one vertical tile edge the strip can meet
+        const bool straddle = xedge < x0 + 128 && xedge < g.W;
+        const IN *img = rgb + (long long)b * g.H * g.W * 3;
+        const long long ibase = (long long)b * g.pstride;
+        {
+            // (per-thread values are re-derived per strip from a copy of the thread id the compiler cannot see through: hoisted out of
+            // the strip loop they cost ten registers, and the kernel has to stay within 56)
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const int px = x0 + 4 * (tq & 31);
+            const int band = rows >> 3;                 // rows per half-wave: even (rows is a multiple of 16)
+            const int ya = y0 + (tq >> 5) * band, yb = min(ya + band, yend);
+            const int slot = straddle ? (px >= xedge ? 1 : 0) : (tq & 1);
+            lds_int *hcopy = (lds_int *)s_hist + slot * kStripHistStride;
+            if (px < g.W && ya < yb) {
+                float *norm0 = planes_norm + ibase + g.poff[0], *raw0 = planes_raw + ibase + g.poff[0];
+                unsigned char *u80 = planes_u8 + ibase + g.poff[0];
+                float *normc[2] = { planes_norm + ibase + poff1, planes_norm + ibase + poff2 }, *rawc[2] = { planes_raw + ibase + poff1, planes_raw + ibase + poff2 };
+                unsigned char *u8c[2] = { planes_u8 + ibase + poff1, planes_u8 + ibase + poff2 };
+                unsigned ioff = (unsigned)(ya * g.W + px) * (3u * (unsigned)sizeof(IN));      // byte offset inside the image: < 2^32
+                unsigned o_l = (unsigned)(ya * g.w[0] + px);
+                unsigned o_c = RH == 2 ? (unsigned)((ya >> 1) * g.w[1] + (px >> 1)) : (unsigned)(ya * g.w[1] + (px >> 2));
+                RowRaw<IN> rowA = strip_load_row<IN>(img, ioff);
+                for (int y = ya; y < yb; y += 2) {
+                    const RowRaw<IN> rowB = strip_load_row<IN>(img, ioff + in_row_bytes);
+                    float a1[2], a2[2], b1[2], b2[2];
+                    do_row(rowA, a1, a2, norm0, raw0, u80, o_l, hcopy);
+                    // the next row A (the band's last step re-reads row B instead: an unconditional load keeps the registers of
+                    // rowA out of a copy at the loop's back edge)
+                    rowA = strip_load_row<IN>(img, ioff + (y + 2 < yb ? 2u : 1u) * in_row_bytes);
+                    do_row(rowB, b1, b2, norm0, raw0, u80, o_l + (unsigned)g.w[0], hcopy);
+                    // ---- layers 1, 2 (chroma): INTER_AREA box mean
+#pragma unroll
+                    for (int ch = 1; ch < 3; ch++) {
+                        const float *ca = ch == 1 ? a1 : a2, *cb = ch == 1 ? b1 : b2;
+                        float v[2];
+                        if constexpr (RH == 2 && RW == 2) {      // ((r0e+r0o)+(r1e+r1o))*0.25f
+                            v[0] = (ca[0] + cb[0]) * 0.25f;
+                            v[1] = (ca[1] + cb[1]) * 0.25f;
+                            if (has_norm)
+                                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * o_c) =
+                                    make_float2((v[0] - nc.mid[ch]) * nc.scale[ch], (v[1] - nc.mid[ch]) * nc.scale[ch]);
+                            if (has_raw) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(rawc[ch - 1]) + 4u * o_c) = make_float2(v[0], v[1]);
+                            uchar2 u;
+                            u.x = scale_u8(v[0]); u.y = scale_u8(v[1]);
+                            if (has_u8) *reinterpret_cast<uchar2 *>(u8c[ch - 1] + o_c) = u;
+                            if (do_hist) {
+                                __hip_atomic_fetch_add(&hcopy[ch * kLayerInts + u.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(&hcopy[ch * kLayerInts + u.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        } else {                                  // RH == 1, RW == 4: sequential sum * (1/4)
+                            v[0] = ca[0];
+                            v[1] = cb[0];
+#pragma unroll
+                            for (int q = 0; q < 2; q++) {
+                                const unsigned o = o_c + (unsigned)(q * g.w[ch]);
+                                if (has_norm) *reinterpret_cast<float *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * o) = (v[q] - nc.mid[ch]) * nc.scale[ch];
+                                if (has_raw) *reinterpret_cast<float *>(reinterpret_cast<char *>(rawc[ch - 1]) + 4u * o) = v[q];
+                                const unsigned char u = scale_u8(v[q]);
+                                if (has_u8) u8c[ch - 1][o] = u;
+                                if (do_hist) __hip_atomic_fetch_add(&hcopy[ch * kLayerInts + u], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                    ioff += 2u * in_row_bytes;
+                    o_l += 2u * (unsigned)g.w[0];
+                    o_c += RH == 2 ? (unsigned)g.w[1] : 2u * (unsigned)g.w[1];
+                }
+            }
+        }
+        if (do_hist) {
+            __syncthreads();
+            int *ghist = tile_hist + (long long)b * 3 * 16 * 256 + (ty * 4 + tx0) * 256;
+#pragma unroll
+            for (int layer = 0; layer < 3; layer++) {
+                const int c0 = s_hist[(layer * kStripSlots + 0) * kStripHistStride + tid], c1 = s_hist[(layer * kStripSlots + 1) * kStripHistStride + tid];
+                if (straddle) {
+                    if (c0) atomicAdd(&ghist[layer * 16 * 256 + tid], c0);
+                    if (c1) atomicAdd(&ghist[layer * 16 * 256 + 256 + tid], c1);
+                } else if (c0 + c1) {
+                    atomicAdd(&ghist[layer * 16 * 256 + tid], c0 + c1);
+                }
+            }
+        }
+    }       // strips
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic (slow-path) version of the fused plane kernel for shapes the 4x2-patch kernel cannot take: widths that are
 // not a multiple of 4, odd heights, and sizes that do not divide by the down-sampling ratios, where cv.resize(INTER_AREA)
 // is the general area-weighted resize (OpenCV resize.cpp computeResizeAreaTab + ResizeArea_Invoker):
@@ -410,6 +647,32 @@ template <int SPACE, int RH, int RW>
 static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const Geom &g, const NormConst &nc, float *raw, float *norm,
                             unsigned char *u8, int *hist)
 {
+    // strip kernel: CLAHE tiles without padding whose edges no 4 x 2 patch straddles, in every layer
+    if ((g.W % 16) == 0 && (g.H % 8) == 0 && g.ctw[0] * 4 == g.W && g.cth[0] * 4 == g.H && g.ctw[0] >= 128 && !getenv("AEJ_COLOR_NO_STRIP")) {
+        const int nxb = (g.W + 127) / 128;
+        // rows per workgroup: as long as the launch still has a few thousand workgroups (one image spreads over the chip), at most 64
+        int rows = 64;
+        while (rows > 16 && (long long)nxb * ((g.cth[0] + rows - 1) / rows) * 4 * g.B < 4096) rows >>= 1;
+        if (const char *e = getenv("AEJ_COLOR_STRIP_ROWS")) rows = atoi(e) > 0 ? (atoi(e) + 15) / 16 * 16 : rows;
+        const int nys = (g.cth[0] + rows - 1) / rows;
+        const long long nstrips = (long long)nxb * nys * 4 * g.B;
+        // workgroups in the launch: enough to fill the chip when the kernel runs alone (8 per CU); AEJ_COLOR_WGS_PER_CU sets another
+        // residency (tuning knob of the co-residency experiments)
+        int per_cu = 8;
+        if (const char *e = getenv("AEJ_COLOR_WGS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+        const long long want = 256LL * per_cu;
+        dim3 sgrid((unsigned)(nstrips < want ? nstrips : want));
+        const bool prod = norm && u8 && hist && !raw;
+        auto go = [&](auto kern, auto *in) { hipLaunchKernelGGL(kern, sgrid, dim3(256), 0, st, in, g, nc, raw, norm, u8, hist, nxb, nys, rows, (int)nstrips); };
+        if (in_u8) {
+            if (prod) go(k_color_planes_strip<SPACE, RH, RW, unsigned char, true>, static_cast<const unsigned char *>(rgb));
+            else go(k_color_planes_strip<SPACE, RH, RW, unsigned char, false>, static_cast<const unsigned char *>(rgb));
+        } else {
+            if (prod) go(k_color_planes_strip<SPACE, RH, RW, float, true>, static_cast<const float *>(rgb));
+            else go(k_color_planes_strip<SPACE, RH, RW, float, false>, static_cast<const float *>(rgb));
+        }
+        return;
+    }
     dim3 grid((g.W + 127) / 128, (g.H + 15) / 16, g.B);
     if (in_u8)
         hipLaunchKernelGGL((k_color_planes<SPACE, RH, RW, unsigned char>), grid, dim3(256), 0, st, static_cast<const unsigned char *>(rgb), g, nc,

@@ -21,8 +21,8 @@ namespace aej {
 // ------------------------------------------------------------------------------------------------
 struct WorkPtrsD { LeafWork *w[kMaxSizes]; };
 
-// A leaf table that does not fit the plan (more leaves than the layer can hold, a size outside the settings' block range, more
-// leaves of one size than its work list holds) sets *bad instead of writing out of bounds; aej_decode_batch reports it.
+// A leaf table that does not fit the plan (more leaves than the layer can hold, a size outside the settings' block range, an origin
+// outside the layer, a coefficient offset outside the layer's span, more leaves of one size than its work list holds) sets *bad instead of writing out of bounds; aej_decode_batch reports it.
 __global__ __launch_bounds__(256) void k_work_from_tables(Geom g, QtGeom q, const int *__restrict__ leaves, const long long *__restrict__ counts,
                                                           WorkPtrsD wp, int *__restrict__ work_count, int bmin_log2, int *__restrict__ bad)
 {
@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256) void k_work_from_tables(Geom g, QtGeom q, cons
         int4 lf = tab[i];
         int k = (31 - __clz(lf.z)) - bmin_log2;
         if (k < 0 || k >= q.nsizes || !wp.w[k] || lf.z != (q.bmin << k)) { k = -1; *bad = 1; }
+        // the IDCT kernels clip a leaf at the layer's right / bottom edge only: its origin has to lie inside the layer, and its
+        // coefficients inside the layer's span of `coeffs`
+        else if (lf.x < 0 || lf.y < 0 || lf.x >= g.w[l] || lf.y >= g.h[l] || lf.w < 0 || (long long)lf.w + (long long)lf.z * lf.z > q.coeff_cap[l]) { k = -1; *bad = 1; }
         // one atomic per wave and block size instead of one per leaf (all lanes of a wave work on the same plane): a few
         // counters shared by 10^5 leaves per image serialise otherwise.  List order is irrelevant to the decode.
         const int lane = threadIdx.x & 63;

@@ -95,6 +95,29 @@ def synth_batch(torch, B, H, W, seed, device):
     return out
 
 
+def natural_batch(torch, B, H, W, seed, device):
+    """Labelled variant (--data natural): the reference's own natural test images (tests/golden/natural/*.png = its test_images/,
+    metrics_computation.py:307-324) mirror-tiled to H x W -- reflected copies side by side, so the seams add no artificial edges --
+    each batch image from another source image / tile offset; uint8 levels -> float32 by the exact division of image.py:80."""
+    from PIL import Image as PILImage
+    d = os.path.join(ROOT, "tests", "golden", "natural")
+    names = sorted(f for f in os.listdir(d) if f.endswith(".png"))
+    srcs = [np.asarray(PILImage.open(os.path.join(d, f)).convert("RGB")) for f in names]
+    lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(device)
+    out = torch.empty((B, H, W, 3), dtype=torch.float32, device=device)
+    for b in range(B):
+        k = seed + b
+        src = srcs[k % len(srcs)]
+        period = np.concatenate([np.concatenate([src, src[:, ::-1]], 1), np.concatenate([src[::-1], src[::-1, ::-1]], 1)], 0)   # 2h x 2w, tiles seamlessly
+        ph, pw = period.shape[:2]
+        oy, ox = (k * 37) % ph, (k * 53) % pw
+        ys = (np.arange(H) + oy) % ph
+        xs = (np.arange(W) + ox) % pw
+        img = torch.from_numpy(np.ascontiguousarray(period[ys][:, xs])).to(device)
+        out[b] = lut[img.to(torch.int64)]
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +133,9 @@ def parse_args(argv=None):
     ap.add_argument("--quality", type=int, nargs=2, default=[40, 80])
     ap.add_argument("--ingest", choices=["f32", "u8"], default="f32",
                     help="f32 = the BASELINE metric's float32 RGB input; u8 = 8-bit ingest (aej_encode_batch_u8, 3 B/px in), reported as a variant")
+    ap.add_argument("--data", choices=["synthetic", "natural"], default="synthetic",
+                    help="synthetic = SURVEY 8d's 'mixed' generator (the headline); natural = the reference's own test images mirror-tiled to "
+                         "the image size (a labelled variant: textures change the leaf mix and the hysteresis pass count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle comparison")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for cpu_baseline; 0 = min(available cores, 16)")
@@ -120,6 +146,9 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", type=int, choices=[1, 2, 3, 4], default=2,
                     help="contexts (each on its own stream, with its own output buffers and workspace) the timed steps rotate over: step i is "
                          "enqueued with aej_encode_batch_begin on context i %% n after the step that used it before has been ended; 1 = blocking calls")
+    ap.add_argument("--strict-speculation", action="store_true",
+                    help="exit non-zero when any rank's hysteresis speculation missed inside the timed region (the miss is repaired and the "
+                         "output correct either way; the line always reports the misses per rank)")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiler runs (tools/profiling/*.sh): only the W warm-up and K timed steps, so every kernel is launched a known "
                          "number of times; prints value / ms_per_step only")
@@ -167,6 +196,7 @@ def timed_loop(torch, dist, step, steps, sync):
     for i in range(steps):
         step(i)
     sync()
+    timed_loop.own_seconds = time.perf_counter() - t0      # this rank's own K steps, before it waits for the others (per-rank report)
     if dist is not None:
         dist.barrier()
     return time.perf_counter() - t0
@@ -177,6 +207,19 @@ def git_head():
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
     except Exception:
         return None
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and headers the library is built from: what a PMC profile is valid for.
+    tools/profiling/pmc.py stores the same figure in the profile it writes, so staleness needs no git on the GPU box."""
+    import hashlib
+    d = os.path.join(ROOT, "adaptive_edge_aware_jpeg_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_profile_json(name):
@@ -194,16 +237,21 @@ def rehearse(args):
     import torch
     rank, local_rank, world = rank_env()
     dist = init_distributed(torch, os.environ.get("AEJ_BENCH_BACKEND", "gloo"), rank, local_rank, world)
-    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput
+    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput, gather_rank_report
     B, seed_a, seed_b, scaling = local_batch_and_seed(args, rank, world)
     dt = timed_loop(torch, dist, lambda i: time.sleep(0.002 * (1 + rank)), args.steps, lambda: None)
+    dt_local = timed_loop.own_seconds
     px, dt = aggregate_throughput(dist, B * args.height * args.width * args.steps, dt, None)
+    fake_bad = os.environ.get("AEJ_REHEARSE_BAD_RANK")            # the CPU test makes one rank report a failed oracle check
+    ranks = gather_rank_report(dist, local_rank, dt_local / args.steps * 1e3, 0, not (fake_bad is not None and int(fake_bad) == rank), None)
     if rank == 0:
         print(json.dumps({"metric": "REHEARSAL of bench.py's multi-rank control flow (no GPU work, not a measurement)", "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "pixels_total": px,
-                          "seconds_max": round(dt, 4), "rank0_images": B, "rank0_seeds": [seed_a, seed_b]}), flush=True)
+                          "seconds_max": round(dt, 4), "rank0_images": B, "rank0_seeds": [seed_a, seed_b], "ranks": ranks}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if not ranks["all_verified"]:
+        raise SystemExit(3)                                       # every rank exits non-zero, as in the real run
 
 
 def main():
@@ -216,6 +264,9 @@ def main():
     # (must be set before the HIP runtime initialises)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
+    # imported BEFORE anything initialises HIP: the package then knows that the queue count in the environment is the one the runtime
+    # will start with and tells the library (aej_set_hw_queues); imported later it would have to assume HIP's default of 4
+    import adaptive_edge_aware_jpeg_amd as A
     rank, local_rank, world = rank_env()
     # rehearsal switches (not used by the driver): AEJ_BENCH_BACKEND=gloo + AEJ_BENCH_ONE_DEVICE=1 run the multi-rank control flow
     # with every rank on GPU 0 of a one-GPU box; RCCL needs one GPU per rank
@@ -230,8 +281,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
 
-    import adaptive_edge_aware_jpeg_amd as A
-    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput
+    from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput, gather_rank_report
 
     H, W = args.height, args.width
     B, seed_a, seed_b, scaling = local_batch_and_seed(args, rank, world)
@@ -239,7 +289,8 @@ def main():
         raise SystemExit("no images for this rank")
     space, qrange, brange = args.space, tuple(args.quality), tuple(args.blocks)
     dev = torch.device("cuda", local_rank)
-    batches_f32 = [synth_batch(torch, B, H, W, seed_a, dev), synth_batch(torch, B, H, W, seed_b, dev)]
+    make_batch = synth_batch if args.data == "synthetic" else natural_batch
+    batches_f32 = [make_batch(torch, B, H, W, seed_a, dev), make_batch(torch, B, H, W, seed_b, dev)]
     batches = batches_f32 if args.ingest == "f32" else [(x * 255.0).round().to(torch.uint8) for x in batches_f32]
 
     jpeg = A.Jpeg(A.JpegCompressionSettings(space, qrange, brange), device=local_rank)
@@ -309,6 +360,7 @@ def main():
     sync()
     h0 = hyst_stats()
     dt_local = timed_loop(torch, dist, step, args.steps, sync)
+    own_ms_per_step = timed_loop.own_seconds / args.steps * 1e3
     h1 = hyst_stats()
     px_total, dt = aggregate_throughput(dist, B * H * W * args.steps, dt_local, dev if backend == "nccl" else None)   # SUM of pixels, MAX of seconds
     value = px_total / dt / 1e6
@@ -325,7 +377,7 @@ def main():
 
     # ---- tie the number to correct output: first and last image of the LAST timed step's batch against the CPU oracle ----
     verified = None
-    if rank == 0 and not args.no_verify:
+    if not args.no_verify:                   # every rank checks its own outputs (rank 0's result goes into the line, all of them into `ranks`)
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
         O.build()
@@ -341,6 +393,10 @@ def main():
                 ok = ok and got["root_size"] == ref[l]["root_size"] and all(np.array_equal(got[k], ref[l][k]) for k in ("states", "leaves", "coeffs"))
         verified = {"ok": bool(ok), "images": picks, "of_batch": "A" if last_batch == 0 else "B",
                     "what": "quadtree states, leaf table and quantised zigzag coefficients of all 3 layers, bit-exact vs the CPU oracle"}
+
+    # ---- first-contact evidence for N > 1: which ranks the collective saw, their own step times, misses and oracle checks ----
+    ranks = gather_rank_report(dist, local_rank, own_ms_per_step, h1["misses"] - h0["misses"], None if verified is None else verified["ok"],
+                               dev if backend == "nccl" else None)
 
     # ---- the same loop with the speculation off (verified hysteresis loop) ----
     # ---- strictly serial figure: blocking calls on one context, nothing in flight between them ----
@@ -394,15 +450,26 @@ def main():
     head = git_head()
     # HBM bytes and VALU instruction counts come from rocprofv3 PMC passes of this same command (profiles/, tools/profiling/pmc.py);
     # they cannot be collected inside a normal run, so the line says which profile they are from and for which commit
-    tj = load_profile_json("r02_hbm_traffic.json")
-    vj = load_profile_json("r02_pmc_valu.json")
+    traffic_file = "r03_hbm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")) else "r02_hbm_traffic.json"
+    valu_file = "r03_pmc_valu.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_valu.json")) else "r02_pmc_valu.json"
+    tj = load_profile_json(traffic_file)
+    vj = load_profile_json(valu_file)
+    src_hash = source_hash()
 
     def same_shape(j):
         return bool(j) and (j.get("batch"), j.get("height"), j.get("width")) == (B, H, W) and j.get("space", "YCbCr") == space and \
             tuple(j.get("blocks", (4, 64))) == brange
 
     def stale(j):
-        return (j.get("head") != head) if (head and j.get("head")) else "unknown (no git on this box)"
+        # a profile is valid for the kernel sources it was taken with (source_hash, stored by tools/profiling/pmc.py); older
+        # profiles only carry the git commit
+        if j.get("src_hash"):
+            return j["src_hash"] != src_hash
+        return (j.get("head") != head) if (head and j.get("head")) else "unknown (profile predates source hashes and there is no git on this box)"
+
+    def src_of(j, fname):
+        return {"file": "profiles/" + fname, "profiled_commit": j.get("head"), "profiled_src_hash": j.get("src_hash"), "this_commit": head,
+                "this_src_hash": src_hash, "stale": stale(j)}
 
     def roofline_of(stage):
         achieved = algo[stage] / (kernels[stage] * 1e-3) / 1e9 if kernels[stage] > 0 else 0.0
@@ -411,7 +478,7 @@ def main():
             hit = [v["hbm_bytes"] for k, v in tj["kernels"].items() if KERNEL_OF_STAGE[stage] in k]
             if hit:
                 traffic = sum(hit)
-                traffic_src = {"file": "profiles/r02_hbm_traffic.json", "profiled_commit": tj.get("head"), "this_commit": head, "stale": stale(tj)}
+                traffic_src = src_of(tj, traffic_file)
         r = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[stage].rstrip("<_") if stage != "quadtree" else "k_qt_upper+count+scan+emit",
              "stage": stage, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -428,7 +495,7 @@ def main():
                 t_issue = insts / N_SIMD * 1.1e-9
                 v = {"kernel": r["kernel"], "wave_instructions_per_launch": insts, "instructions_per_plane_px": round(insts * 64 / plane_px, 1),
                      "frac_of_issue_peak": round(t_issue / (kernels[stage] * 1e-3), 3), "issue_ns_per_simd_instruction": 1.1,
-                     "source": {"file": "profiles/r02_pmc_valu.json", "profiled_commit": vj.get("head"), "this_commit": head, "stale": stale(vj)}}
+                     "source": src_of(vj, valu_file)}
         return r, v
 
     ranked = sorted(kernels, key=kernels.get, reverse=True)
@@ -448,15 +515,20 @@ def main():
         "metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic ('mixed' images generated on the GPU, SURVEY.md 8d recipe); two batches of different seeds alternate across steps",
+        "dtype": "f32",
+        "data": ("synthetic ('mixed' images generated on the GPU, SURVEY.md 8d recipe); two batches of different seeds alternate across steps"
+                 if args.data == "synthetic" else
+                 "natural: the reference's own test images (baboon, peppers, house, jelly_beans, LIVE bikes / buildings) mirror-tiled to the image "
+                 "size, uint8 levels / 255; two batches alternate across steps -- a labelled variant, not the headline recipe"),
         "config": {"workload": f"{B} x {W}x{H} {'uint8' if args.ingest == 'u8' else 'float32'} RGB per GPU, {space}, blocks {brange[0]}-{brange[1]}, quality {qrange[0]}-{qrange[1]} "
-                               + ("(BASELINE config 4: 512 4K images / 8 GPUs)" if (B, H, W, space, tuple(brange)) == (64, H4K, W4K, "YCbCr", (4, 64)) else "(not the headline workload)"),
+                               + ("(BASELINE config 4: 512 4K images / 8 GPUs)" if (B, H, W, space, tuple(brange), args.data) == (64, H4K, W4K, "YCbCr", (4, 64), "synthetic") else "(not the headline workload)"),
                    "images_per_gpu": B, "height": H, "width": W, "color_space": space,
                    "block_size_range": list(brange), "quality_range": list(qrange), "steps_in_flight": n_pipe},
         "roofline": roofline,
         "valu": valu,
         "runner_up": runner_up,
         "verified": verified,
+        "ranks": ranks,
         "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "speculative_calls": h1["speculative"] - h0["speculative"],
                        "misses": h1["misses"] - h0["misses"], "passes_enqueued_last_call": h1["enqueued"],
                        "passes_needed_last_call": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle))},
@@ -539,6 +611,15 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    # a rank whose outputs differ from the oracle's makes the whole run fail (every rank has the same `ranks` dict); a speculation
+    # miss inside the timed region is correct output at a slower step -- it is reported per rank (`speculation_misses_by_rank`) and
+    # fails the run only under --strict-speculation
+    if not ranks["all_verified"]:
+        sys.stderr.write(f"bench.py: oracle check failed on rank(s) {[i for i, v in enumerate(ranks['verified_ok_by_rank']) if v is False]}\n")
+        raise SystemExit(3)
+    if args.strict_speculation and ranks["any_miss"]:
+        sys.stderr.write(f"bench.py: speculation misses in the timed region: {ranks['speculation_misses_by_rank']}\n")
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

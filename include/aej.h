@@ -53,7 +53,8 @@ typedef enum aej_space {
     AEJ_XYZ = 7 /* aej_color_convert / aej_color_convert_inverse only (conversion.py:63-68); not a codec space */
 } aej_space;
 
-#define AEJ_MAX_SIZES 8 /* block sizes 2,4,...,256 (GUI range, src/gui/main_frame.py:41-45) */
+#define AEJ_MAX_SIZES 8 /* a block-size range spans at most 8 powers of two between 2 and 1024 (the GUI offers 2..256, src/gui/main_frame.py:41-45;
+                         Jpeg itself takes any power of two, jpeg.py:216-219) */
 
 /* Shapes and capacities for one (batch, H, W) under the current settings.  Layer l of image b lives at
  * element offset  b*<x>_stride + <x>_off[l]  of the corresponding output array. */
@@ -109,6 +110,17 @@ AEJ_API int aej_set_graph_mode(aej_ctx *ctx, int mode);
  * sub-batches, and only while no other context has a call in flight), 1: never, 2..8: that many.
  * Outputs are identical; the call still returns with everything complete.  aej_encode_plan's workspace_bytes covers every split. */
 AEJ_API int aej_set_sub_batches(aej_ctx *ctx, int n);
+/* How many hardware queues the HIP runtime of this process maps its streams onto (GPU_MAX_HW_QUEUES as it was when the runtime
+ * initialised; HIP's default is 4).  The library cannot see that value -- the environment may have been changed after the runtime
+ * read it -- so the HOST states it: aej_create assumes 4 (the conservative schedule) and the Python package passes what it knows
+ * (adaptive_edge_aware_jpeg_amd/_lib.py: the variable's value when the package was imported before the first HIP call, 4 otherwise).
+ * aej_get_schedule_host: out_host[4] = { hardware queues assumed, sub-batches the automatic mode would use for (batch, H, W) right now,
+ * 1 when fewer than 8 queues force the two-sub-batch schedule for a call the 4-sub-batch one would serve better, reserved }. */
+AEJ_API int aej_set_hw_queues(aej_ctx *ctx, int n);
+AEJ_API int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int32_t *out_host);
+/* TEST INSTRUMENTATION (tests/ only): the next whole-path call fails with AEJ_ERR_STATE right after it has enqueued stage `stage`
+ * (an AEJ_STAGE_* value; -1 disarms) of its first part, i.e. with work in flight -- the error paths must drain it.  One-shot. */
+AEJ_API int aej_test_fail_after_stage(aej_ctx *ctx, int stage);
 /* The two halves of aej_encode_batch / aej_encode_batch_u8 (same arguments; rgb_is_u8 selects the ingest): _begin enqueues the whole
  * call and returns without waiting, _end waits for it, checks the device-side counters and repairs a speculation miss.  One call may
  * be in flight per context; until _end returns, the context's other entry points, the workspace and the output buffers must not be
@@ -207,7 +219,8 @@ AEJ_API int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, 
  * (Jpeg._dequantize, _apply_inverse_dct, _block_merge, _upsample, _convert_color_space_inverse).
  * The leaf tables must tile every layer (aej_encode_batch's output does; Jpeg.decompress checks a parsed stream on the host
  * with aej_leaf_positions_host): a table that does not fit the plan -- n_leaves beyond the layer's capacity, a size outside
- * the settings' block range, more leaves of one size than can exist -- returns AEJ_ERR_ARG instead of touching memory it
+ * the settings' block range, an origin outside the layer, a coefficient offset outside the layer's span, more leaves of one size
+ * than can exist -- returns AEJ_ERR_ARG instead of touching memory it
  * does not own; pixels no leaf covers are left undefined (the reference starts from np.zeros, jpeg.py:421). */
 AEJ_API uint64_t aej_decode_workspace_bytes(aej_ctx *ctx, int batch, int H, int W);
 AEJ_API int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32_t *leaves, const int64_t *counts, int batch, int H,

@@ -25,3 +25,11 @@ def lena():
     import numpy as np
     from PIL import Image as PILImage
     return np.asarray(PILImage.open(os.path.join(GOLDEN, "lena.png")).convert("RGB")).astype(np.float32) / np.float32(255.0)
+
+
+def golden_image(name):
+    """float32 RGB in [0, 1] (uint8 levels / 255, image.py:80) of tests/golden/<name>.png -- "lena" or "natural/<x>" (the reference's
+    own test images, converted by tests/golden/make_natural_fixtures.py)"""
+    import numpy as np
+    from PIL import Image as PILImage
+    return np.asarray(PILImage.open(os.path.join(GOLDEN, name + ".png")).convert("RGB")).astype(np.float32) / np.float32(255.0)

@@ -84,6 +84,16 @@ def main():
         "lena_default_ycocg_4_64": (lena, "YCoCg", (40, 80), (4, 64)),    # reference defaults (jpeg.py:150-155)
         "crop_ycbcr_4_64": (crop, "YCbCr", (40, 80), (4, 64)),
     }
+    # natural images the reference ships (test_images/, converted by make_natural_fixtures.py): textures drive the hysteresis pass
+    # count and the leaf-size mix very differently from lena and from the synthetic generator
+    def natural(name):
+        return np.asarray(PILImage.open(os.path.join(HERE, "natural", name + ".png")).convert("RGB")).astype(np.float32) / 255.0
+    cases.update({
+        "baboon_ycbcr_4_64": (natural("baboon"), "YCbCr", (40, 80), (4, 64)),
+        "peppers_default_ycocg_4_64": (natural("peppers"), "YCoCg", (40, 80), (4, 64)),
+        "house_ycocgr_2_32_q30_90": (natural("house"), "YCoCg-R", (30, 90), (2, 32)),
+        "bikes_ycbcr_4_128": (natural("bikes"), "YCbCr", (40, 80), (4, 128)),
+    })
     meta = {}
     for name, (img, space, qr, br) in cases.items():
         codec = Jpeg(Settings(space, qr, br))
@@ -94,7 +104,8 @@ def main():
         qm = {f"{l}_{s}": codec.quantization_matrix_cache[l][s].tolist() for l in range(3) for s in codec.quantization_matrix_cache[l]}
         meta[name] = {"space": space, "quality_range": qr, "block_size_range": br, "shape": list(img.shape),
                       "sha256": hashlib.sha256(data).hexdigest(), "bytes": len(data), "qm": qm,
-                      "crop": [100, 200, 150, 212] if name.startswith("crop") else None}
+                      "crop": [100, 200, 150, 212] if name.startswith("crop") else None,
+                      "image": "lena" if name.startswith(("lena", "crop")) else "natural/" + name.split("_")[0]}
         print(name, len(data), meta[name]["sha256"][:16])
     json.dump(meta, open(os.path.join(HERE, "compress_cases.json"), "w"), indent=1, sort_keys=True)
 

@@ -364,3 +364,145 @@ def test_randomised_parity_sweep(env, oracle):
         dec = codec.decompress_batch(enc).cpu().numpy()[0]
         want = oracle.decode_image(oracle.write_ajpg(ref, H, W, space, q, (lo, hi), ".png"))
         assert np.array_equal(dec, want, equal_nan=True), tag + " decode"
+
+
+def test_bench_configuration_64x4k_two_contexts(env, oracle):
+    """The exact configuration bench.py times (BASELINE config 4's per-GPU share): B = 64 x 3840x2160, two contexts on two streams
+    with aej_encode_batch_begin / _end, automatic sub-batching, two different input batches; images 0, B/2 and B-1 of BOTH calls in
+    flight are compared with the oracle, and every image's counters are checked for consistency."""
+    torch, A, bench = env
+    from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+    dev = torch.device("cuda", 0)
+    space, qr, br = "YCbCr", (40, 80), (4, 64)
+    B, H, W = 64, 2160, 3840
+    codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
+    xs = [bench.synth_batch(torch, B, H, W, seed, dev) for seed in (20250718, 20250718 + 1_000_000)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    ctxs, outs = [], []
+    for s in streams:
+        with torch.cuda.stream(s):
+            c = codec._bind()
+            c.set_sub_batches(0)
+            plan = c.plan(B, H, W)
+            ctxs.append(c)
+            outs.append((c.empty((B * plan.coeff_stride,), torch.int32), c.empty((B * plan.leaf_stride, 4), torch.int32),
+                         c.empty((B * plan.state_stride,), torch.uint8), c.empty((B, 3, 4), torch.int64)))
+    torch.cuda.synchronize()
+    sched = ctxs[0].schedule(B, H, W)
+    picks = [0, B // 2, B - 1]
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        futs = {(w, b): ex.submit(oracle.encode_image, xs[w][b].cpu().numpy(), space, qr, br) for w in (0, 1) for b in picks}
+        # three rounds as the bench does: step i on context i % 2, inputs alternating on every context
+        split0 = [c.split_calls() for c in ctxs]
+        for i in range(6):
+            k, which = i % 2, (i // 2 + i) & 1
+            if i >= 2:
+                with torch.cuda.stream(streams[k]):
+                    codec.encode_end(ctxs[k])
+            with torch.cuda.stream(streams[k]):
+                codec.encode_begin(ctxs[k], xs[which], plan, *outs[k])
+            last = {**(last if i else {}), k: which}
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                codec.encode_end(ctxs[k])
+        torch.cuda.synchronize()
+        if sched["sub_batches"] > 1:
+            assert all(c.split_calls() - s0 == 3 for c, s0 in zip(ctxs, split0)), "the calls were expected to run as sub-batches"
+        for k in (0, 1):
+            enc = EncodedBatch(plan, *outs[k])
+            for b in picks:
+                check_image(enc, b, futs[(last[k], b)].result(), f"context {k}, batch {last[k]}, image {b} of {B}")
+            cnt = enc.counts_host
+            assert (cnt[:, :, 3] == np.asarray(plan.root_size)[None, :]).all() and (cnt[:, :, 1] > 0).all()
+            assert (cnt[:, :, 0] >= (np.asarray(plan.layer_h) * np.asarray(plan.layer_w))[None, :]).all()
+
+
+def test_failed_begin_drains_what_it_enqueued(env, oracle):
+    """A whole-path call that fails after it has put work in flight (aej_test_fail_after_stage: test instrumentation of the ABI) must
+    return with its streams drained -- unsplit and sub-batch paths alike -- leave the context usable, and leave no stale chain hook."""
+    torch, A, bench = env
+    from adaptive_edge_aware_jpeg_amd._lib import AejError
+    from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+    dev = torch.device("cuda", 0)
+    space, qr, br = "YCbCr", (40, 80), (4, 64)
+    B, H, W = 14, 1080, 1920
+    x = bench.synth_batch(torch, B, H, W, 31, dev)
+    codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        ctx = codec._bind()
+        plan = ctx.plan(B, H, W)
+        try:
+            ctx.set_sub_batches(1)
+            want = _encode_raw(torch, ctx, codec, x, plan)
+            want = _encode_raw(torch, ctx, codec, x, plan)          # (speculative from here on)
+            stages = {"color_planes": 1, "hysteresis": 6, "dct64": 13}
+            for nsub in (1, 2):
+                ctx.set_sub_batches(nsub)
+                for name, stage in stages.items():
+                    out = (ctx.empty((B * plan.coeff_stride,), torch.int32), ctx.empty((B * plan.leaf_stride, 4), torch.int32),
+                           ctx.empty((B * plan.state_stride,), torch.uint8), ctx.empty((B, 3, 4), torch.int64))
+                    ctx.check(ctx.lib.aej_test_fail_after_stage(ctx.handle, stage))
+                    with pytest.raises(AejError, match="injected failure"):
+                        codec.encode_into(ctx, x, plan, *out)
+                    assert s.query(), f"{nsub} sub-batch(es), failure after {name}: the caller's stream still has work in flight"
+                    # nothing of the failed call is in flight on the library's private streams either: the next call's outputs are right
+                    with pytest.raises(AejError):
+                        codec.encode_end(ctx)                      # and no call is left pending
+                    got = _encode_raw(torch, ctx, codec, x, plan)
+                    _assert_same_encoding(torch, plan, got, want, B, f"call after a failure behind {name} ({nsub} sub-batch(es))")
+                    # begin / end flavour: a failing begin returns the error itself and leaves nothing to end
+                    ctx.check(ctx.lib.aej_test_fail_after_stage(ctx.handle, stage))
+                    with pytest.raises(AejError, match="injected failure"):
+                        codec.encode_begin(ctx, x, plan, *out)
+                    ctx._in_flight = None
+                    with pytest.raises(AejError):
+                        codec.encode_end(ctx)
+            # a stand-alone Canny on the same context afterwards still works (no stale chain hook re-recording a shared event)
+            plane = torch.rand((256, 320), device=dev).cpu().numpy().astype(np.float32)
+            e1 = A.EdgeDetection.canny(plane)
+            assert e1.shape == plane.shape
+        finally:
+            ctx.set_sub_batches(0)
+            ctx.check(ctx.lib.aej_test_fail_after_stage(ctx.handle, -1))
+    check_image(EncodedBatch(plan, *want), 0, oracle.encode_image(x[0].cpu().numpy(), space, qr, br), "reference call")
+
+
+def test_decode_refuses_tables_that_leave_the_plan(env):
+    """include/aej.h: aej_decode_batch returns AEJ_ERR_ARG for a leaf table whose entries would make a kernel touch memory the plan
+    does not own -- origin outside the layer, negative or overlong coefficient offset, size outside the block range."""
+    torch, A, bench = env
+    dev = torch.device("cuda", 0)
+    x = bench.synth_batch(torch, 2, 256, 384, 5, dev)
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    enc = codec.compress_batch(x)
+    good = codec.decompress_batch(enc)
+    p = enc.plan
+    row = int(p.leaf_stride) + int(p.leaf_off[1]) + 3                  # a leaf of image 1, layer 1
+    cap1 = int(p.coeff_off[2] - p.coeff_off[1])
+    for col, val in ((0, -4), (0, int(p.layer_w[1])), (1, -8), (1, int(p.layer_h[1]) + 64), (3, -1), (3, cap1), (2, 3), (2, 128)):
+        saved = enc.leaves[row, col].item()
+        enc.leaves[row, col] = val
+        with pytest.raises(ValueError):
+            codec.decompress_batch(enc)
+        enc.leaves[row, col] = saved
+    assert torch.equal(codec.decompress_batch(enc), good)
+
+
+def test_schedule_report_follows_the_stated_hardware_queues(env):
+    """aej_set_hw_queues / aej_get_schedule_host: the library schedules for the queue count the host states and says when fewer than
+    8 queues force the narrower schedule."""
+    torch, A, bench = env
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    ctx = codec._bind()
+    n, src = A.hw_queues()
+    try:
+        ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, 16))
+        s16 = ctx.schedule(64, 2160, 3840)
+        assert s16["hw_queues"] == 16 and s16["sub_batches"] == 4 and not s16["limited_by_hw_queues"]
+        ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, 4))
+        s4 = ctx.schedule(64, 2160, 3840)
+        assert s4["hw_queues"] == 4 and s4["sub_batches"] <= 2 and s4["limited_by_hw_queues"]
+        assert ctx.schedule(1, 1080, 1920)["sub_batches"] == 1
+    finally:
+        ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, n))

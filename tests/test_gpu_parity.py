@@ -304,12 +304,22 @@ CASES = [("lena YCbCr 8-8 q50", "lena", "YCbCr", (50, 50), (8, 8)),
          ("synth 128x256 ICtCp", (128, 256, 12), "ICtCp", (20, 60), (4, 32)),
          ("synth 96x128 ICaCb", (96, 128, 13), "ICaCb", (40, 80), (4, 16)),
          ("synth 120x200 JzAzBz", (120, 200, 14), "JzAzBz", (40, 80), (8, 64)),
-         ("synth 1080p YCbCr", (1080, 1920, 20250718), "YCbCr", (40, 80), (4, 64))]
+         ("synth 1080p YCbCr", (1080, 1920, 20250718), "YCbCr", (40, 80), (4, 64)),
+         # the reference's own natural test images (test_images/, metrics_computation.py:307-324): textures, many hysteresis passes
+         ("baboon YCbCr", "natural/baboon", "YCbCr", (40, 80), (4, 64)),
+         ("baboon OKLAB 4-128", "natural/baboon", "OKLAB", (40, 80), (4, 128)),
+         ("peppers YCoCg default", "natural/peppers", "YCoCg", (40, 80), (4, 64)),
+         ("peppers ICtCp", "natural/peppers", "ICtCp", (40, 80), (4, 64)),
+         ("house JzAzBz 2-32", "natural/house", "JzAzBz", (30, 90), (2, 32)),
+         ("jelly_beans ICaCb", "natural/jelly_beans", "ICaCb", (40, 80), (4, 64)),
+         ("bikes YCbCr 4-128", "natural/bikes", "YCbCr", (40, 80), (4, 128)),
+         ("buildings YCoCg-R 8-64", "natural/buildings", "YCoCg-R", (10, 95), (8, 64))]
 
 
 @pytest.mark.parametrize("name,src,space,qr,br", CASES, ids=[c[0] for c in CASES])
 def test_encode_matches_oracle(A, oracle, lena, name, src, space, qr, br):
-    img = lena if src == "lena" else synth(oracle, *src)
+    from conftest import golden_image
+    img = lena if src == "lena" else golden_image(src) if isinstance(src, str) else synth(oracle, *src)
     enc = A.Jpeg(A.JpegCompressionSettings(space, qr, br)).compress_batch(img[None], want_dct=True)
     ref = oracle.encode_image(img, space, qr, br)
     for l in range(3):
@@ -345,11 +355,12 @@ def test_compress_bytes_match_reference_orchestrated_fixture(A, lena):
     """Jpeg.compress(Image) -> .ajpg identical to the files the reference's own compress() wrote (with the oracle
     as its cv2)."""
     meta = json.load(open(os.path.join(GOLDEN, "compress_cases.json")))
+    from conftest import golden_image
     for name, m in meta.items():
-        img = lena
+        img = lena if m["image"] == "lena" else golden_image(m["image"])
         if m["crop"]:
             y, x, h, w = m["crop"]
-            img = np.ascontiguousarray(lena[y:y + h, x:x + w])
+            img = np.ascontiguousarray(img[y:y + h, x:x + w])
         codec = A.Jpeg(A.JpegCompressionSettings(m["space"], tuple(m["quality_range"]), tuple(m["block_size_range"])))
         data = codec.compress(A.Image(img, img.shape, ".png"))
         assert hashlib.sha256(data).hexdigest() == m["sha256"], name

@@ -84,11 +84,13 @@ def test_normalisation_constants(oracle):
 def test_full_compress_matches_reference_orchestration(oracle, lena):
     """tests/golden/*.ajpg were written by the REFERENCE's Jpeg.compress with the oracle standing in for cv2."""
     meta = json.load(open(os.path.join(GOLDEN, "compress_cases.json")))
+    from conftest import golden_image
+    assert len(meta) >= 7 and any(m["image"].startswith("natural/") for m in meta.values())      # lena AND the natural images
     for name, m in meta.items():
-        img = lena
+        img = lena if m["image"] == "lena" else golden_image(m["image"])
         if m["crop"]:
             y, x, h, w = m["crop"]
-            img = np.ascontiguousarray(lena[y:y + h, x:x + w])
+            img = np.ascontiguousarray(img[y:y + h, x:x + w])
         qr, br = tuple(m["quality_range"]), tuple(m["block_size_range"])
         layers = oracle.encode_image(img, m["space"], qr, br)
         data = oracle.write_ajpg(layers, img.shape[0], img.shape[1], m["space"], qr, br, ".png")

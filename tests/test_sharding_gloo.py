@@ -88,3 +88,35 @@ def test_bench_multi_rank_control_flow_rehearsal(extra, scaling, images):
     assert line["pixels_total"] == sum(images) * 100 * 200 * 3       # SUM over ranks
     assert line["seconds_max"] >= 3 * 0.004 * 0.9                      # MAX over ranks: rank 1 sleeps twice as long
     assert line["rank0_images"] == images[0] and line["rank0_seeds"][0] == 20250718
+    # first-contact evidence: the collective saw both ranks, each with its own step time
+    rk = line["ranks"]
+    assert rk["world_size"] == 2 and rk["n_ranks_seen"] == 2 and rk["local_ranks_seen"] == [0, 1]
+    assert rk["ms_per_step_by_rank"][1] > rk["ms_per_step_by_rank"][0] > 0 and rk["all_verified"] and not rk["any_miss"]
+
+
+def test_bench_fails_on_every_rank_when_one_rank_fails_its_oracle_check():
+    """A rank whose outputs differ from the oracle's must fail the whole run: rank 1 reports a failed check (rehearsal switch), the
+    all_gather carries it to rank 0, the JSON line shows it and BOTH processes exit non-zero."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AEJ_BENCH_BACKEND="gloo",
+                   AEJ_REHEARSE_BAD_RANK="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--rehearse-control-flow", "--gpus", "2", "--steps", "2",
+                                       "--warmup", "1", "--batch", "2", "--height", "64", "--width", "64"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], [o[1][-1500:] for o in outs]
+    line = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][0])
+    assert line["ranks"]["verified_ok_by_rank"] == [True, False] and not line["ranks"]["all_verified"]
+
+
+def test_rank_report_single_process():
+    from adaptive_edge_aware_jpeg_amd.sharding import gather_rank_report
+    r = gather_rank_report(None, 0, 7.25, 0, True)
+    assert r["n_ranks_seen"] == 1 and r["ms_per_step_by_rank"] == [7.25] and r["all_verified"] and not r["any_miss"]
+    assert not gather_rank_report(None, 0, 7.25, 2, False)["all_verified"] and gather_rank_report(None, 0, 1.0, 2, None)["any_miss"]

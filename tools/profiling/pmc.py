@@ -64,6 +64,12 @@ def one_pass(counters, bench_args, tag):
     return info, acc, launches
 
 
+def src_hash():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.source_hash()
+
+
 def main():
     mode = sys.argv[1]
     bench_args = sys.argv[2:]
@@ -86,7 +92,7 @@ def main():
         return default
 
     meta = {"batch": int(arg("--batch", 64)), "height": int(arg("--height", 2160)), "width": int(arg("--width", 3840)), "space": arg("--space", "YCbCr"),
-            "blocks": [int(v) for v in arg("--blocks", [4, 64], 2)], "head": head, "bench": info}
+            "blocks": [int(v) for v in arg("--blocks", [4, 64], 2)], "head": head, "src_hash": src_hash(), "bench": info}
     if mode == "traffic":
         for k, d in kernels.items():
             d["read_bytes"] = d.get("FETCH_SIZE_per_encode", 0.0) * 1024 * 2
