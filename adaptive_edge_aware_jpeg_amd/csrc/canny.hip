@@ -6,6 +6,7 @@
 // to the CPU oracle.  OpenCV semantics restated per stage are documented in DESIGN.md ("Canny chain").
 #include "aej_common.h"
 #include "aej_launch.h"
+#include <stdlib.h>
 
 namespace aej {
 
@@ -886,6 +887,190 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// a-8 part 1, register version (round 3): the same Sobel / magnitude / NMS, without LDS and without barriers.
+// One WAVE owns a 64 x 64 tile (= the 64 contiguous words of the tile-major bit-planes): lane (q, j) = (lane >> 4, lane & 15)
+// owns the four pixels x0 + 4 j .. + 3 and walks down the band of 16 rows y0 + 16 q ..; so the 16 lanes of a DPP row are the 64
+// pixels of one image row, and a lane's left / right neighbour dwords are one DPP row shift away (the lanes 0 / 15 of a row read
+// the dword beyond the tile themselves: their `old` operand).  Per source row the horizontal [1 2 1] sums and differences of the
+// SIX pixels -1 .. 4 are formed once as three words of two 16-bit fields (pixel pairs (-1, 2), (0, 3), (1, 4)) and slide down
+// through the three rows a gradient needs; the magnitudes of the six pixels of three rows stay in registers, so the NMS of the
+// four own pixels needs no exchange at all.  The NMS itself is branch-free per pixel column and skipped for a column in which no
+// lane of the wave has a candidate (m > low).  Results leave as 16-bit pieces of the bit-plane words: two DPP OR steps gather the
+// nibbles of four lanes (weak in the low, strong in the high half-word).
+// Every integer operation is the one the LDS kernel above performs (the tests compare both with the oracle).
+// ------------------------------------------------------------------------------------------------
+typedef short nms_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (nms_s16x2)(__builtin_bit_cast(nms_s16x2, a) - __builtin_bit_cast(nms_s16x2, b))); }
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (nms_s16x2)(__builtin_bit_cast(nms_s16x2, a) + __builtin_bit_cast(nms_s16x2, b))); }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_row(unsigned old, unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, 0xf, false); }
+constexpr int kDppRowShl1 = 0x101, kDppRowShr1 = 0x111, kDppRowShr2 = 0x112;
+
+struct NmsRowH { unsigned s[3], d[3]; };        // per source row: [1 2 1] sums and right-minus-left differences of the pixel pairs (-1, 2), (0, 3), (1, 4)
+
+// one 64 x 64 tile; EDGE = the tile touches the plane's border (clamped source coordinates, magnitudes outside the image are 0)
+template <bool L2, bool EDGE>
+__device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__ src, int w, int h, int tx, int ty, int low, int high,
+                                               unsigned short *__restrict__ wk16, unsigned short *__restrict__ sg16, long long bp_tile, int lane)
+{
+    const int j = lane & 15, q = lane >> 4;
+    const int x0 = tx * 64, px = x0 + 4 * j;
+    const int yb0 = ty * 64 + 16 * q;                 // first output row of this lane's band
+    constexpr int kRows = 20;                          // source rows yb0 - 2 .. yb0 + 17
+    unsigned own[kRows], halo[kRows];
+    // the dword beyond the tile's edge is needed by lanes 0 and 15 of a row only (the DPP shifts' `old` operand); the other lanes
+    // re-read their own dword instead of being masked off (same cache lines, no exec juggling)
+    const int halo_col = j == 0 ? x0 - 4 : j == 15 ? x0 + 64 : px;
+    if constexpr (EDGE) {
+        // source dword of column c (a multiple of 4, possibly outside [0, w)) of clamped row y: BORDER_REPLICATE
+        auto load_col = [&](int y, int c) -> unsigned {
+            const int yc = y < 0 ? 0 : y >= h ? h - 1 : y;
+            const int cc = c < 0 ? 0 : c > w - 4 ? w - 4 : c;
+            unsigned d = *reinterpret_cast<const unsigned int *>(src + (long long)yc * w + cc);
+            if (c < 0) d = (d & 0xffu) * 0x01010101u;
+            else if (c > w - 4) d = (d >> 24) * 0x01010101u;
+            return d;
+        };
+#pragma unroll
+        for (int u = 0; u < kRows; u++) {
+            own[u] = load_col(yb0 - 2 + u, px);
+            halo[u] = load_col(yb0 - 2 + u, halo_col);
+        }
+    } else {
+        // interior tile: one wave-uniform row base per source row (scalar arithmetic) plus a per-lane 32-bit offset
+        // (row0 starts four pixels left of the tile, so that every per-lane offset is non-negative)
+        const unsigned own_off = (unsigned)(16 * q * w + 4 * j + 4), halo_off = (unsigned)(16 * q * w + (halo_col - x0) + 4);
+        const unsigned char *row0 = src + (long long)(ty * 64 - 2) * w + (x0 - 4);
+#pragma unroll
+        for (int u = 0; u < kRows; u++) {
+            const unsigned char *row = row0 + (long long)u * w;
+            own[u] = *reinterpret_cast<const unsigned int *>(row + own_off);
+            halo[u] = *reinterpret_cast<const unsigned int *>(row + halo_off);
+        }
+    }
+
+    NmsRowH H[3];                                      // the last three source rows (index = u % 3)
+    int M[3][6];                                       // magnitudes of pixels -1 .. 4 of the last three gradient rows (index = row % 3)
+    unsigned G[3][4];                                  // dx | dy << 16 of the four own pixels, same rows
+#pragma unroll
+    for (int u = 0; u < kRows; u++) {
+        // ---- horizontal pass of source row u: p[-2], p[-1] = left bytes 2, 3; p[0..3] = own; p[4], p[5] = right bytes 0, 1
+        {
+            const unsigned m = own[u];
+            const unsigned lf = dpp_row<kDppRowShr1>(halo[u], m);      // lane j - 1's dword; lane 0 of the row keeps its halo dword
+            const unsigned rt = dpp_row<kDppRowShl1>(halo[u], m);      // lane j + 1's dword; lane 15 keeps its halo dword
+            // E(k) = (p[k], p[k + 3]) as two 16-bit fields, k = -2 .. 2 (selector 0x0C = zero byte)
+            const unsigned Em2 = __builtin_amdgcn_perm(m, lf, 0x0C050C02u);      // (lf.b2, m.b1)
+            const unsigned Em1 = __builtin_amdgcn_perm(m, lf, 0x0C060C03u);      // (lf.b3, m.b2)
+            const unsigned E0 = __builtin_amdgcn_perm(m, m, 0x0C030C00u);        // (m.b0, m.b3)
+            const unsigned E1 = __builtin_amdgcn_perm(rt, m, 0x0C040C01u);       // (m.b1, rt.b0)
+            const unsigned E2 = __builtin_amdgcn_perm(rt, m, 0x0C050C02u);       // (m.b2, rt.b1)
+            NmsRowH &r = H[u % 3];
+            r.s[0] = Em2 + 2u * Em1 + E0;  r.d[0] = pk_sub16(E0, Em2);           // pixels (-1, 2)
+            r.s[1] = Em1 + 2u * E0 + E1;   r.d[1] = pk_sub16(E1, Em1);           // pixels ( 0, 3)
+            r.s[2] = E0 + 2u * E1 + E2;    r.d[2] = pk_sub16(E2, E0);            // pixels ( 1, 4)
+        }
+        if (u < 2) continue;
+        // ---- gradient row: image row gy = yb0 - 3 + u from source rows u - 2 (top), u - 1, u (bottom)
+        const int gr = (u - 1) % 3;                    // slot of this gradient row
+        {
+            const NmsRowH &top = H[(u - 2) % 3], &mid = H[(u - 1) % 3], &bot = H[u % 3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const unsigned dx = pk_add16(pk_add16(top.d[p], bot.d[p]), pk_add16(mid.d[p], mid.d[p]));
+                const unsigned dy = pk_sub16(bot.s[p], top.s[p]);
+                const unsigned glo = __builtin_amdgcn_perm(dy, dx, 0x05040100u);      // pixel p - 1: dx | dy << 16
+                const unsigned ghi = __builtin_amdgcn_perm(dy, dx, 0x07060302u);      // pixel p + 2
+                int mlo, mhi;
+                if (L2) {
+                    mlo = __builtin_amdgcn_sdot2(__builtin_bit_cast(nms_s16x2, glo), __builtin_bit_cast(nms_s16x2, glo), 0, false);
+                    mhi = __builtin_amdgcn_sdot2(__builtin_bit_cast(nms_s16x2, ghi), __builtin_bit_cast(nms_s16x2, ghi), 0, false);
+                } else {
+                    const int xl = (int)(short)(glo & 0xffffu), yl = (int)glo >> 16, xh = (int)(short)(ghi & 0xffffu), yh = (int)ghi >> 16;
+                    mlo = (xl < 0 ? -xl : xl) + (yl < 0 ? -yl : yl);
+                    mhi = (xh < 0 ? -xh : xh) + (yh < 0 ? -yh : yh);
+                }
+                M[gr][p] = mlo;                        // pixels -1, 0, 1
+                M[gr][p + 3] = mhi;                    // pixels  2, 3, 4
+                if (p >= 1) G[gr][p - 1] = glo;        // own pixels 0, 1
+                if (p <= 1) G[gr][p + 2] = ghi;        // own pixels 2, 3
+            }
+            if constexpr (EDGE) {
+                const int gy = yb0 - 3 + u;
+                const bool row_out = gy < 0 || gy >= h;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const int x = px - 1 + i;
+                    if (row_out || x < 0 || x >= w) M[gr][i] = 0;
+                }
+            }
+        }
+        if (u < 4) continue;
+        // ---- NMS of image row y = yb0 + u - 4: previous / current / next gradient rows are the slots of u - 3, u - 2, u - 1.
+        // Written as plain boolean algebra on compare results: the compiler keeps them as lane masks and combines them on the scalar
+        // unit, so a pixel costs its compares plus two selects -- no per-lane neighbour selection, no divergent branch.
+        const int *Mp = M[(u - 3) % 3], *Mc = M[(u - 2) % 3], *Mn = M[(u - 1) % 3];
+        const unsigned *Gc = G[(u - 2) % 3];
+        unsigned v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int m = Mc[k + 1];
+            const bool cand = m > low;
+            if (!__any(cand)) continue;                // no candidate in this pixel column of the wave's four rows
+            const unsigned gd = Gc[k];
+            const unsigned absg = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(nms_s16x2, gd), (nms_s16x2)(-__builtin_bit_cast(nms_s16x2, gd))));   // |dx| | |dy| << 16
+            const int ax = (int)(absg & 0xffffu);
+            const int ay = (int)((absg >> 1) & 0x7fff8000u);          // |dy| << 15
+            const int t22 = ax * 13573;
+            const int t67 = t22 + (int)(absg << 16);                  // + (|dx| << 16)
+            const bool c_h = ay < t22, c_v = ay > t67;
+            const bool neg = (int)(gd ^ (gd << 16)) < 0;              // sign(dx) != sign(dy)
+            const bool k_h = (m > Mc[k]) & (m >= Mc[k + 2]);
+            const bool k_v = (m > Mp[k + 1]) & (m >= Mn[k + 1]);
+            const bool k_dp = (m > Mp[k]) & (m > Mn[k + 2]);          // s = +1
+            const bool k_dm = (m > Mp[k + 2]) & (m > Mn[k]);          // s = -1
+            const bool k_d = (neg & k_dm) | (!neg & k_dp);
+            const bool keep = cand & ((c_h & k_h) | (!c_h & ((c_v & k_v) | (!c_v & k_d))));
+            const bool strong = keep & (m > high);
+            v |= strong ? (0x10000u << k) : 0u;
+            v |= (keep & !strong) ? (1u << k) : 0u;
+        }
+        // this lane's nibbles (weak in bits 0..3, strong in bits 16..19), shifted to its place among four lanes; two DPP OR steps
+        // gather the 16-bit pieces in lanes 3, 7, 11, 15 of every row
+        v <<= 4 * (j & 3);
+        v |= dpp_row<kDppRowShr1>(0u, v);
+        v |= dpp_row<kDppRowShr2>(0u, v);
+        const int y = yb0 + u - 4;
+        if ((j & 3) == 3 && (!EDGE || y < h)) {
+            const long long o = (bp_tile + (y & 63)) * 4 + (j >> 2);      // 16-bit piece j / 4 of the row's word
+            wk16[o] = (unsigned short)(v & 0xffffu);
+            sg16[o] = (unsigned short)(v >> 16);
+        }
+    }
+}
+
+template <bool L2>
+__global__ __launch_bounds__(256) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const long long T = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (T >= total_tiles) return;
+    const int b = (int)(T / tiles_per_img);
+    int l, tx, ty, ntx, nty, tbase;
+    if (!locate_tile(g, kHystTile, kHystTile, (int)(T - (long long)b * tiles_per_img), l, tx, ty, ntx, nty, tbase)) return;
+    const int w = g.w[l], h = g.h[l], wpr = g.wpr[l];
+    const unsigned char *src = cb.u8b + (long long)b * g.pstride + g.poff[l];
+    const int low = cb.thr[((long long)b * 3 + l) * 2], high = cb.thr[((long long)b * 3 + l) * 2 + 1];
+    unsigned short *wk16 = reinterpret_cast<unsigned short *>(cb.weak + (long long)b * g.bpstride + g.bpoff[l]);
+    unsigned short *sg16 = reinterpret_cast<unsigned short *>(cb.strong + (long long)b * g.bpstride + g.bpoff[l]);
+    const long long bp_tile = bp_index(ty * 64, tx, wpr);
+    // tiles whose 68 x 68 source window leaves the plane: clamped loads (BORDER_REPLICATE), magnitudes outside the image are 0
+    const bool edge_tile = tx == 0 || tx * 64 + 68 > w || ty == 0 || ty * 64 + 66 > h;
+    if (edge_tile) sobel_nms_tile<L2, true>(src, w, h, tx, ty, low, high, wk16, sg16, bp_tile, lane);
+    else sobel_nms_tile<L2, false>(src, w, h, tx, ty, low, high, wk16, sg16, bp_tile, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // a-8 part 2: hysteresis on the bit-planes.  One WAVE owns a 64x64 tile: lane r holds row r of the
 // strong and weak planes as 64-bit words, the 8-neighbourhood dilation is shifts + two lane shuffles, and
 // horizontal runs are filled in one step with a Kogge-Stone occluded fill; the loop runs in registers until
@@ -1167,6 +1352,16 @@ void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
+    // register kernel: every layer's rows must be whole aligned dwords (w % 4 == 0, w >= 4); other shapes take the LDS kernel
+    bool reg_ok = !getenv("AEJ_SOBEL_LDS");
+    for (int l = 0; l < g.nl; l++) reg_ok = reg_ok && (g.w[l] % 4) == 0 && g.w[l] >= 4;
+    if (reg_ok) {
+        const long long t = hyst_tiles_per_image(g), total = t * g.B;
+        const dim3 rgrid((unsigned)((total + 3) / 4));
+        if (cb.l2) hipLaunchKernelGGL(k_sobel_nms_reg<true>, rgrid, dim3(256), 0, st, g, cb, t, total);
+        else hipLaunchKernelGGL(k_sobel_nms_reg<false>, rgrid, dim3(256), 0, st, g, cb, t, total);
+        return;
+    }
     const int strip = pick_strip(g, kBlurTW, kBlurTH, kStripMax, 2048);
     const dim3 grid((unsigned)(strips_per_image(g, kBlurTW, kBlurTH, strip) * g.B));
     if (cb.l2) hipLaunchKernelGGL(k_sobel_nms<true>, grid, dim3(256), 0, st, g, cb, strip);

@@ -656,11 +656,13 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
         if (const char *e = getenv("AEJ_COLOR_STRIP_ROWS")) rows = atoi(e) > 0 ? (atoi(e) + 15) / 16 * 16 : rows;
         const int nys = (g.cth[0] + rows - 1) / rows;
         const long long nstrips = (long long)nxb * nys * 4 * g.B;
-        // workgroups in the launch: enough to fill the chip when the kernel runs alone (8 per CU); AEJ_COLOR_WGS_PER_CU sets another
-        // residency (tuning knob of the co-residency experiments)
-        int per_cu = 8;
-        if (const char *e = getenv("AEJ_COLOR_WGS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-        const long long want = 256LL * per_cu;
+        // Workgroups in the launch.  The matrix spaces are a pure stream: ONE workgroup per CU (256 in all, each walking ~270 strips)
+        // is the fastest shape alone -- 64 x 4K: 1.95 ms against 2.27 ms with 8 per CU and 2.19 ms for the 128 x 16 kernel; 320
+        // workgroups: 2.5 ms (a quarter of the CUs get two) -- and, being one small workgroup per CU, it runs in the gaps beside the
+        // other chains' kernels (64 x 4K pipelined step 7.4 -> 7.0 ms; with 128 workgroups the kernel takes 3.0 ms alone and the step
+        // is still 7.0: the stage is off the critical path).  The spaces with float64 pows are arithmetic-bound: fill the chip.
+        long long want = SPACE < 3 ? 256 : 256 * 8;
+        if (const char *e = getenv("AEJ_COLOR_WGS")) want = atoi(e) > 0 ? atoi(e) : want;      // tuning knob (tools/profiling)
         dim3 sgrid((unsigned)(nstrips < want ? nstrips : want));
         const bool prod = norm && u8 && hist && !raw;
         auto go = [&](auto kern, auto *in) { hipLaunchKernelGGL(kern, sgrid, dim3(256), 0, st, in, g, nc, raw, norm, u8, hist, nxb, nys, rows, (int)nstrips); };

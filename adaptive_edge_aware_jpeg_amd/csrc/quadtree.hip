@@ -386,12 +386,16 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
     }
 }
 
-// pass 3: exclusive scan of the chunk records per (image, layer); totals -> counts and per-plane work counts
-__global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restrict__ chunk_cnt, long long *__restrict__ counts,
+// pass 3: exclusive scan of the chunk records per (image, layer); totals -> counts and per-plane work counts.
+// 256 threads (round 3; was 1024): a workgroup of 16 waves needs four free wave slots with 56 registers on EVERY SIMD of one CU, which
+// in the pipelined path it waited for behind the other chains' resident workgroups (211 us per launch under overlap against 45 us alone);
+// four waves fit into the gaps.
+constexpr int kScanThreads = 256;
+__global__ __launch_bounds__(kScanThreads) void k_qt_scan(Geom g, QtGeom q, int *__restrict__ chunk_cnt, long long *__restrict__ counts,
                                                   int *__restrict__ work_count)
 {
     constexpr int NQ = 3 + kMaxSizes;
-    __shared__ int s_w[NQ][16];
+    __shared__ int s_w[NQ][kScanThreads / 64];
     __shared__ int carry[NQ];
     const int tid = threadIdx.x, l = blockIdx.x, b = blockIdx.y;
     const int lane = tid & 63, wv = tid >> 6;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restr
     const int nq = 3 + q.nsizes;
     if (tid < NQ) carry[tid] = 0;
     __syncthreads();
-    for (int start = 0; start < n; start += 1024) {
+    for (int start = 0; start < n; start += kScanThreads) {
         const int i = start + tid;
         int v[NQ], inc[NQ];
 #pragma unroll
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_qt_scan(Geom g, QtGeom q, int *__restr
         __syncthreads();
         if (tid < NQ) {
             int t = 0;
-            for (int k = 0; k < 16; k++) t += s_w[tid][k];
+            for (int k = 0; k < kScanThreads / 64; k++) t += s_w[tid][k];
             carry[tid] += t;
         }
         __syncthreads();
@@ -534,7 +538,7 @@ void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuf
 }
 void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_scan, dim3(g.nl, g.B), dim3(1024), 0, st, g, q, qb.chunk_cnt, qb.counts, qb.work_count);
+    hipLaunchKernelGGL(k_qt_scan, dim3(g.nl, g.B), dim3(kScanThreads), 0, st, g, q, qb.chunk_cnt, qb.counts, qb.work_count);
 }
 void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
