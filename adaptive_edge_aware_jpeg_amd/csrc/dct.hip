@@ -12,6 +12,7 @@
 #include "aej_launch.h"
 #include "aej_bigblock.h"
 #include "aej_mfma.h"
+#include <stdlib.h>
 
 namespace aej {
 
@@ -983,8 +984,10 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
     if (max_items <= 0) return 0;                  // an empty work list is not an error
     if (a.nplanes > kMaxPlanes) return -1;         // the per-plane prefix table would not fit the launch's LDS
     const size_t pref = (size_t)(a.nplanes + 1) * sizeof(int);
+    static const int small_wgs = getenv("AEJ_DCT_SMALL_WGS") ? atoi(getenv("AEJ_DCT_SMALL_WGS")) : 0;      // tuning knob (tools/profiling): residency of the grid-stride kernels
     auto cap = [&](long long per_block, int hi) {
         long long b = (max_items + per_block - 1) / per_block;
+        if (small_wgs > 0 && size <= 16) hi = small_wgs;
         return (int)(b < 1 ? 1 : b > hi ? hi : b);
     };
     const bool wd = a.dct_f32 != nullptr;
