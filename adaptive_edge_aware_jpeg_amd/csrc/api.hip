@@ -70,6 +70,12 @@ struct aej_ctx {
                                        // 8.0 / 7.8 / 7.9 / 8.4).  AEJ_SUB_CHAIN overrides (tuning knob).
     int chain_hook = 0;                // run_canny_chain publishes chain_event after the blur (2) / Sobel (3) stage of the part being enqueued
     hipEvent_t chain_event = nullptr;
+    // per-stage serialisation across parts (stage_mask, AEJ_STAGE_CHAIN): bit 0 blur, bit 1 Sobel / NMS, bit 2 DCT -- a part's kernel of such a
+    // stage waits for the same stage of the part enqueued before it (any context): two issue-bound kernels of one kind gain nothing from
+    // sharing the chip, they only dilate each other
+    int stage_mask = 0;
+    hipEvent_t stage_ev[kMaxSub][3] = {};
+    hipEvent_t *cur_stage_ev = nullptr;     // the three events of the part being enqueued (null: not chained)
     struct aej_pending *pending = nullptr;     // the call between aej_encode_batch_begin and aej_encode_batch_end
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;
@@ -132,6 +138,21 @@ static void collect_marks(aej_ctx *ctx)
 #include <mutex>
 static std::mutex g_chain_mutex;
 static hipEvent_t g_last_color_done[64] = {};      // per device; owned by the context that recorded it
+static hipEvent_t g_last_stage_done[64][3] = {};   // per device and chained stage (blur, Sobel, DCT), same ownership rule
+
+// wait for the previous part's kernel of chained stage `k` / publish this part's (no-ops unless the part is chained on that stage)
+static void stage_wait(aej_ctx *ctx, int k)
+{
+    if (!ctx->cur_stage_ev || !(ctx->stage_mask & (1 << k)) || ctx->device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_chain_mutex);
+    if (hipEvent_t after = g_last_stage_done[ctx->device][k]) (void)hipStreamWaitEvent(ctx->stream, after, 0);
+}
+static void stage_publish(aej_ctx *ctx, int k)
+{
+    if (!ctx->cur_stage_ev || !(ctx->stage_mask & (1 << k)) || ctx->device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_chain_mutex);
+    if (hipEventRecord(ctx->cur_stage_ev[k], ctx->stream) == hipSuccess) g_last_stage_done[ctx->device][k] = ctx->cur_stage_ev[k];
+}
 static int g_calls_in_flight[64] = {};             // per device: calls between aej_encode_batch_begin and _end (guarded by g_chain_mutex)
 
 static void free_pending(aej_ctx *ctx);      // defined with aej_pending
@@ -365,6 +386,7 @@ extern "C" aej_ctx *aej_create(int device, void *hip_stream)
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
     if (const char *e = getenv("AEJ_SUB_CHAIN")) ctx->sub_chain = atoi(e);
+    if (const char *e = getenv("AEJ_STAGE_CHAIN")) ctx->stage_mask = atoi(e) & 7;      // tuning knob (tools/profiling/sched_sweep.sh)
     return ctx;
 }
 
@@ -382,6 +404,9 @@ extern "C" void aej_destroy(aej_ctx *ctx)
         std::lock_guard<std::mutex> lock(g_chain_mutex);
         for (int i = 0; i < aej_ctx::kMaxSub; i++)
             if (ctx->sub_color_done[i] && ctx->device < 64 && g_last_color_done[ctx->device] == ctx->sub_color_done[i]) g_last_color_done[ctx->device] = nullptr;
+        for (int i = 0; i < aej_ctx::kMaxSub; i++)
+            for (int k = 0; k < 3; k++)
+                if (ctx->stage_ev[i][k] && ctx->device < 64 && g_last_stage_done[ctx->device][k] == ctx->stage_ev[i][k]) g_last_stage_done[ctx->device][k] = nullptr;
     }
     drop_graphs(ctx);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
@@ -391,6 +416,7 @@ extern "C" void aej_destroy(aej_ctx *ctx)
     for (int i = 0; i < aej_ctx::kMaxSub; i++) {
         if (ctx->sub_stream[i]) (void)hipStreamDestroy(ctx->sub_stream[i]);
         if (ctx->sub_color_done[i]) (void)hipEventDestroy(ctx->sub_color_done[i]);
+        for (int k = 0; k < 3; k++) if (ctx->stage_ev[i][k]) (void)hipEventDestroy(ctx->stage_ev[i][k]);
         if (ctx->sub_flag[i]) (void)hipHostFree(ctx->sub_flag[i]);
     }
     if (ctx->sub_in) (void)hipEventDestroy(ctx->sub_in);
@@ -599,13 +625,17 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool specula
         std::lock_guard<std::mutex> lock(g_chain_mutex);
         if (hipEventRecord(ctx->chain_event, st) == hipSuccess && ctx->device < 64) g_last_color_done[ctx->device] = ctx->chain_event;
     };
+    stage_wait(ctx, 0);
     launch_clahe_blur(st, g, w.cb);
     mark(ctx, AEJ_STAGE_CLAHE_BLUR);
+    stage_publish(ctx, 0);
     if (ctx->chain_hook == 2) publish();
     launch_thresholds(st, g, w.cb);
     mark(ctx, AEJ_STAGE_THRESHOLDS);
+    stage_wait(ctx, 1);
     launch_sobel_nms(st, g, w.cb);
     mark(ctx, AEJ_STAGE_SOBEL_NMS);
+    stage_publish(ctx, 1);
     if (ctx->chain_hook == 3) publish();
     int rc = run_hysteresis(ctx, g, w, speculate);
     if (rc) return rc;
@@ -791,6 +821,7 @@ static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &
     if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
     mark(ctx, AEJ_STAGE_QUADTREE);
     int k = 0;
+    stage_wait(ctx, 2);
     for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
         DctArgs a;
         a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
@@ -801,6 +832,7 @@ static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &
         if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k])) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
         mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
     }
+    stage_publish(ctx, 2);
     AEJ_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1038,7 +1070,14 @@ static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void
     };
     if (chain && chain_mode == 1 && (rc = publish())) return rc;
     // (the hook is cleared on every exit: a later stand-alone aej_canny on this context must not re-record the shared chain event)
-    struct HookGuard { aej_ctx *c; ~HookGuard() { c->chain_hook = 0; } } hook_guard{ ctx };
+    struct HookGuard { aej_ctx *c; ~HookGuard() { c->chain_hook = 0; c->cur_stage_ev = nullptr; } } hook_guard{ ctx };
+    if (chain && ctx->stage_mask) {
+        int idx = 0;
+        for (int i = 0; i < aej_ctx::kMaxSub; i++) if (ctx->sub_color_done[i] == done) idx = i;
+        for (int k3 = 0; k3 < 3; k3++)
+            if (!ctx->stage_ev[idx][k3]) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_ev[idx][k3], hipEventDisableTiming));
+        ctx->cur_stage_ev = ctx->stage_ev[idx];
+    }
     ctx->chain_hook = (chain && chain_mode > 1) ? chain_mode : 0;
     ctx->chain_event = done;
     if ((rc = run_canny_chain(ctx, p.g, p.w.canny, true))) return rc;      // first call (no hint yet): verified loop, synchronises this stream

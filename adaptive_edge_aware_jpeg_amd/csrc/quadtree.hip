@@ -389,8 +389,9 @@ __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsign
 // pass 3: exclusive scan of the chunk records per (image, layer); totals -> counts and per-plane work counts.
 // 256 threads (round 3; was 1024): a workgroup of 16 waves needs four free wave slots with 56 registers on EVERY SIMD of one CU, which
 // in the pipelined path it waited for behind the other chains' resident workgroups (211 us per launch under overlap against 45 us alone);
-// four waves fit into the gaps.
-constexpr int kScanThreads = 256;
+// four waves fit into the gaps.  A call of a few images has nothing to wait behind and keeps the 1024-thread shape (fewer serial
+// rounds: it is latency there).
+template <int kScanThreads>
 __global__ __launch_bounds__(kScanThreads) void k_qt_scan(Geom g, QtGeom q, int *__restrict__ chunk_cnt, long long *__restrict__ counts,
                                                   int *__restrict__ work_count)
 {
@@ -538,7 +539,8 @@ void launch_qt_count(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuf
 }
 void launch_qt_scan(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {
-    hipLaunchKernelGGL(k_qt_scan, dim3(g.nl, g.B), dim3(kScanThreads), 0, st, g, q, qb.chunk_cnt, qb.counts, qb.work_count);
+    if (g.B <= 4) hipLaunchKernelGGL(k_qt_scan<1024>, dim3(g.nl, g.B), dim3(1024), 0, st, g, q, qb.chunk_cnt, qb.counts, qb.work_count);
+    else hipLaunchKernelGGL(k_qt_scan<256>, dim3(g.nl, g.B), dim3(256), 0, st, g, q, qb.chunk_cnt, qb.counts, qb.work_count);
 }
 void launch_qt_emit(hipStream_t st, const Geom &g, const QtGeom &q, const QtBuffers &qb)
 {

@@ -11,7 +11,8 @@ weak scaling).  Inputs are in HBM before the timed region; outputs stay in HBM.
         bench.py --gpus N --steps K --warmup W
 
 What the timed region does and does not contain:
-* the K steps rotate over `--pipeline` (default 2) contexts, each on its own stream with its own output buffers and workspace:
+* the K steps rotate over `--pipeline` (default 3; round 2 used 2 -- with the colour stage off the critical path a third call in flight
+  fills what the other two leave idle: 64 x 4K 6.7 -> 6.45 ms, four: 6.85) contexts, each on its own stream with its own output buffers and workspace:
   step i is enqueued with aej_encode_batch_begin on context i % n after the step that used that context before has been ended
   (aej_encode_batch_end: waited for, device counters checked, a speculation miss repaired).  Two calls in flight let the HBM-bound
   stages of one (colour planes, DCT) run beside the issue-bound stages of the other (blur, Sobel / NMS, quadtree); the library
@@ -143,7 +144,7 @@ def parse_args(argv=None):
                     help="aej_set_graph_mode: 0 never replay a captured hipGraph (the library default), 1 automatic (calls of at most 8 Mpx), 2 whenever possible")
     ap.add_argument("--sub-batches", type=int, default=0,
                     help="aej_set_sub_batches: 0 automatic (the library default: 4 sub-batches on private streams for calls of at least 64 Mpx), 1 never, 2..8")
-    ap.add_argument("--pipeline", type=int, choices=[1, 2, 3, 4], default=2,
+    ap.add_argument("--pipeline", type=int, choices=[1, 2, 3, 4], default=3,
                     help="contexts (each on its own stream, with its own output buffers and workspace) the timed steps rotate over: step i is "
                          "enqueued with aej_encode_batch_begin on context i %% n after the step that used it before has been ended; 1 = blocking calls")
     ap.add_argument("--strict-speculation", action="store_true",
