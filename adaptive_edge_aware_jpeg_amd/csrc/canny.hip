@@ -1049,8 +1049,11 @@ __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__
     }
 }
 
+#ifndef AEJ_X_SOBEL_MINW
+#define AEJ_X_SOBEL_MINW 4
+#endif
 template <bool L2>
-__global__ __launch_bounds__(256) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles)
+__global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles)
 {
     const int lane = threadIdx.x & 63;
     const long long T = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
