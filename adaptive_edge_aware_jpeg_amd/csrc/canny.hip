@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms(Geom g, CannyBuffers cb, int 
 // four own pixels needs no exchange at all.  The NMS itself is branch-free per pixel column and skipped for a column in which no
 // lane of the wave has a candidate (m > low).  Results leave as 16-bit pieces of the bit-plane words: two DPP OR steps gather the
 // nibbles of four lanes (weak in the low, strong in the high half-word).
-// Every integer operation is the one the LDS kernel above performs (the tests compare both with the oracle).
+// Every integer operation is the one the LDS kernel above performs (the tests compare both with the CPU oracle).
 // ------------------------------------------------------------------------------------------------
 typedef short nms_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (nms_s16x2)(__builtin_bit_cast(nms_s16x2, a) - __builtin_bit_cast(nms_s16x2, b))); }
