@@ -95,20 +95,6 @@ struct DctArgs {
     const int *qm[3];         // [s*s] per layer
 };
 int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items);   // 0, or -1 when no kernel serves the request
-// the 4 x 4, 8 x 8 and 16 x 16 leaves of the whole batch in ONE launch, region by region (min block 4 only): the three sizes of a group of
-// 64 x 64 chunks are transformed by three workgroups on the same XCD, so the 128-byte lines they share are fetched from HBM once
-struct DctFusedArgs {
-    const float *norm;
-    int *coeffs;
-    float *dct_f32;
-    const LeafWork *work[3];          // work lists of sizes 4, 8, 16
-    const int *work_count;            // [nplanes][kMaxSizes]
-    const int *chunk_cnt;             // [B][chunk_stride][kChunkInts] after the scan: [4 + k] = first leaf of size index k of the chunk in its plane's list
-    const float *D[3];
-    const int *qm[3][3];              // [layer][size index]
-};
-bool dct_fused_ok(const QtGeom &q);
-void launch_dct_small_fused(hipStream_t st, const Geom &g, const QtGeom &q, const DctFusedArgs &a);
 // builds a work list from a leaf table (stand-alone aej_dct_quant_zigzag)
 void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int bmin, int plane, LeafWork *const *work, int *work_count);
 

@@ -12,7 +12,6 @@
 #include "aej_launch.h"
 #include "aej_bigblock.h"
 #include "aej_mfma.h"
-#include <string.h>
 #include <stdlib.h>
 
 namespace aej {
@@ -569,294 +568,6 @@ __global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a,
 #pragma unroll
         for (int s = 0; s < 4; s++) x_cur[s] = x_nxt[s];
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused launch of the small blocks (round 3): the 4 x 4, 8 x 8 and 16 x 16 leaves, region by region.
-// As three launches over the whole batch, one after the other, the small sizes read 2.5 GB for 1.19 GB of pixels: a 128-byte line
-// of a plane row is shared by leaves of different sizes, and by the time the next size's launch reaches it the line has long left
-// the L2.  Here ONE launch holds, for every group of kFuseChunks consecutive 64 x 64 chunks of a plane (a Morton-contiguous region;
-// the quadtree scan leaves each chunk's first leaf per size in chunk_cnt, so a group's leaves of one size are a contiguous range of
-// that size's list), three workgroups -- one per size -- placed so that they run on the SAME XCD in consecutive dispatch rounds:
-// workgroup i goes to XCD i % 8, so (i / 8) % 3 selects the size and (i / 24) * 8 + i % 8 the group.  The second and third reader of
-// a line find it in that XCD's L2 (the groups in flight on an XCD cover ~ 1-2 MB of its 4 MiB).  The per-leaf arithmetic is that of
-// k_dct16_mfma / k_dct8_shfl / k_dct4, instruction for instruction; a workgroup works inside one plane, so the quantisers of its
-// lanes are loaded once and the work-list walk needs no search.  Register budget: the three bodies share one kernel, so each keeps
-// its operands small -- the 8 x 8 basis is read row by row from LDS (as 64 scalar registers it pushed the other bodies' values into
-// vector registers: 212 VGPRs), the 4 x 4 quantisers stay in LDS.
-// ------------------------------------------------------------------------------------------------
-constexpr int kFuseChunks = 8;
-
-// everything the fused kernel needs to know about the batch, per layer (a compact copy of Geom / QtGeom)
-struct FusedGeom {
-    int w[3], h[3], nchunk[3], ngroup[3];
-    long long poff[3], coff[3], chunk_off[3], work_off[3][3];
-    long long pstride, coeff_stride, chunk_stride, work_stride[3];
-    int groups_per_image;
-    long long n_groups;
-};
-
-template <bool WANT_DCT>
-__global__ __launch_bounds__(256) void k_dct_small_fused(FusedGeom fg, DctFusedArgs a)
-{
-    __shared__ int sOut[4][8 * 64];           // per wave: 8 leaves x 64 coefficients (8 x 8) or one 16 x 16 leaf (first 256 words)
-    __shared__ __attribute__((aligned(16))) float sTab[64 + 16];       // 8 x 8: the basis; 4 x 4: 16 quantisers
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int xcd = blockIdx.x & 7, round = blockIdx.x >> 3;
-    const int type = round % 3;                                     // 0: 16 x 16, 1: 8 x 8, 2: 4 x 4
-    const long long gidx = (long long)(round / 3) * 8 + xcd;
-    if (gidx >= fg.n_groups) return;
-    const int b = (int)(gidx / fg.groups_per_image);
-    int grp = (int)(gidx - (long long)b * fg.groups_per_image);
-    int layer = 0;
-    if (grp >= fg.ngroup[0]) { grp -= fg.ngroup[0]; layer = 1; if (grp >= fg.ngroup[1]) { grp -= fg.ngroup[1]; layer = 2; } }
-    const int nchunk = fg.nchunk[layer];
-    const int chunk0 = grp * kFuseChunks;
-    if (chunk0 >= nchunk) return;
-    const int plane = b * 3 + layer;
-    const int k = 2 - type;                                         // size index: 4 -> 0, 8 -> 1, 16 -> 2
-    const long long crec = (long long)b * fg.chunk_stride + fg.chunk_off[layer] + chunk0;
-    const int first = a.chunk_cnt[crec * kChunkInts + 4 + k];
-    const int last = chunk0 + kFuseChunks < nchunk ? a.chunk_cnt[(crec + kFuseChunks) * kChunkInts + 4 + k] : a.work_count[(long long)plane * kMaxSizes + k];
-    if (first >= last) return;
-    const int w = fg.w[layer], h = fg.h[layer];
-    const float *src = a.norm + (long long)b * fg.pstride + fg.poff[layer];
-    const long long out_plane = (long long)b * fg.coeff_stride + fg.coff[layer];
-    const int4 *work = reinterpret_cast<const int4 *>(a.work[k]) + (long long)b * fg.work_stride[k] + fg.work_off[layer][k];
-    const int *qm = a.qm[layer][k];
-    const float *tabD = a.D[k];              // (one dynamic look-up each: the branches below hold no other argument live)
-    int *const coeffs = a.coeffs;
-    float *const dct_f32 = a.dct_f32;
-    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-
-    if (type == 0) {
-        // ---- 16 x 16: one wave per leaf (k_dct16_mfma's body)
-        const int gq = lane >> 4, i16 = lane & 15;
-        float dB[4], qf[4];
-        int zz16[4];
-        float qmax = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; s++) dB[s] = tabD[i16 * 16 + 4 * s + gq];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            zz16[r] = zigzag_pos<16>(4 * gq + r, i16);
-            qf[r] = (float)(qm ? qm[(4 * gq + r) * 16 + i16] : 1);
-            qmax = __builtin_fmaxf(qmax, qf[r]);
-        }
-        const bool q_slow = __any(qmax > 4194304.0f);
-        int *out_slab = sOut[wv];
-        for (int it = first + wv; it < last; it += 4) {
-            const int4 dv = work[it];
-            const int dy = rfl(dv.z), dx = rfl(dv.y), dcoef = rfl(dv.w);
-            const float *leaf = src + (long long)dy * w + dx;
-            float x[4];
-            if (dy + 16 <= h && dx + 16 <= w) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) x[s] = leaf[(4 * s + gq) * w + i16];
-            } else {
-                const int hc = min(16, h - dy), wc = min(16, w - dx);
-                const int col = reflect_pad_idx(i16, wc);
-#pragma unroll
-                for (int s = 0; s < 4; s++) x[s] = leaf[(long long)reflect_pad_idx(4 * s + gq, hc) * w + col];
-            }
-            floatx4 p = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-            for (int s = 0; s < 4; s++) p = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], dB[s], p, 0, 0, 0);
-            const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[0]), __float_as_uint(p[2]), false, false);
-            const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[1]), __float_as_uint(p[3]), false, false);
-            const unsigned p02a = p02[0], p02b = p02[1], p13a = p13[0], p13b = p13[1];
-            const auto q01 = __builtin_amdgcn_permlane16_swap(p02a, p13a, false, false);
-            const auto q23 = __builtin_amdgcn_permlane16_swap(p02b, p13b, false, false);
-            const unsigned t0 = q01[0], t1 = q01[1], t2 = q23[0], t3 = q23[1];
-            const float t[4] = { __uint_as_float(t0), __uint_as_float(t1), __uint_as_float(t2), __uint_as_float(t3) };
-            floatx4 y = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-            for (int s = 0; s < 4; s++) y = __builtin_amdgcn_mfma_f32_16x16x4f32(t[s], dB[s], y, 0, 0, 0);
-            const long long out_base = out_plane + dcoef;
-            float ymax = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (WANT_DCT) dct_f32[out_base + (4 * gq + r) * 16 + i16] = y[r];
-                ymax = __builtin_fmaxf(ymax, __builtin_fabsf(y[r]));
-            }
-            if (!(q_slow || __any(!(ymax < 131072.0f)))) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) out_slab[zz16[r]] = quantise_f32(y[r], qf[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) out_slab[zz16[r]] = quantise_f64(y[r], (int)qf[r]);
-            }
-            const int4 o = reinterpret_cast<const int4 *>(out_slab)[lane];
-            reinterpret_cast<int4 *>(coeffs + out_base)[lane] = o;
-        }
-    } else if (type == 1) {
-        // ---- 8 x 8: eight lanes per leaf, eight leaves per wave and step (k_dct8_shfl's body; the basis from LDS, a row at a time)
-        const int j8 = lane & 7;
-        if (tid < 64) sTab[tid] = tabD[tid];
-        int zz8[8];
-        float qf[8], qmax = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            zz8[c] = zigzag_pos<8>(j8, c);
-            qf[c] = (float)(qm ? qm[j8 * 8 + c] : 1);
-            qmax = __builtin_fmaxf(qmax, qf[c]);
-        }
-        const bool q_slow = __any(qmax > 4194304.0f);
-        __syncthreads();
-        int *slab = sOut[wv] + ((lane >> 3) * 64);
-        const float4 *D8 = reinterpret_cast<const float4 *>(sTab);
-        for (int base8 = first + wv * 8; base8 < last; base8 += 32) {
-            const int it = base8 + (lane >> 3);
-            const bool active = it < last;
-            float x[8];
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) x[kk] = 0.f;
-            int4 cur = make_int4(0, 0, 0, 0);
-            if (active) {
-                cur = work[it];
-                const int hc = min(8, h - cur.z), wc = min(8, w - cur.y);
-                const float *colp = src + cur.y + reflect_pad_idx(j8, wc);
-                if (hc == 8) {
-#pragma unroll
-                    for (int kk = 0; kk < 8; kk++) x[kk] = colp[(long long)(cur.z + kk) * w];
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < 8; kk++) x[kk] = colp[(long long)(cur.z + reflect_pad_idx(kk, hc)) * w];
-                }
-            }
-            float t[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float4 da = D8[2 * i], db = D8[2 * i + 1];          // row i of the basis: the same address in every lane (broadcast)
-                float acc = 0.f;
-                acc = __builtin_fmaf(da.x, x[0], acc); acc = __builtin_fmaf(da.y, x[1], acc); acc = __builtin_fmaf(da.z, x[2], acc); acc = __builtin_fmaf(da.w, x[3], acc);
-                acc = __builtin_fmaf(db.x, x[4], acc); acc = __builtin_fmaf(db.y, x[5], acc); acc = __builtin_fmaf(db.z, x[6], acc); acc = __builtin_fmaf(db.w, x[7], acc);
-                t[i] = acc;
-            }
-            transpose8_stage<1>(t, (lane & 1) != 0);
-            transpose8_stage<2>(t, (lane & 2) != 0);
-            transpose8_stage<4>(t, (lane & 4) != 0);
-            float y[8], ymax = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const float4 da = D8[2 * c], db = D8[2 * c + 1];
-                float acc = 0.f;
-                acc = __builtin_fmaf(t[0], da.x, acc); acc = __builtin_fmaf(t[1], da.y, acc); acc = __builtin_fmaf(t[2], da.z, acc); acc = __builtin_fmaf(t[3], da.w, acc);
-                acc = __builtin_fmaf(t[4], db.x, acc); acc = __builtin_fmaf(t[5], db.y, acc); acc = __builtin_fmaf(t[6], db.z, acc); acc = __builtin_fmaf(t[7], db.w, acc);
-                y[c] = acc;
-                ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
-            }
-            const long long out_base = out_plane + cur.w;
-            if (WANT_DCT && active) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) dct_f32[out_base + j8 * 8 + c] = y[c];
-            }
-            if (!(q_slow || __any(!(ymax < 131072.0f)))) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) slab[zz8[c]] = quantise_f32(y[c], qf[c]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; c++) slab[zz8[c]] = quantise_f64(y[c], (int)qf[c]);
-            }
-            if (active) {
-                const int4 o0 = reinterpret_cast<const int4 *>(slab)[2 * j8], o1 = reinterpret_cast<const int4 *>(slab)[2 * j8 + 1];
-                int4 *dst = reinterpret_cast<int4 *>(coeffs + out_base);
-                dst[2 * j8] = o0;
-                dst[2 * j8 + 1] = o1;
-            }
-        }
-    } else {
-        // ---- 4 x 4: one thread per leaf (k_dct4's body; quantisers in LDS)
-        float D4[4][4];
-#pragma unroll
-        for (int i = 0; i < 16; i++) D4[i >> 2][i & 3] = tabD[i];
-        if (tid < 16) sTab[64 + tid] = (float)(qm ? qm[tid] : 1);
-        __syncthreads();
-        const float *sQ4 = sTab + 64;
-        float qmax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; i++) qmax = __builtin_fmaxf(qmax, sQ4[i]);
-        const bool q_slow = qmax > 4194304.0f;
-        for (int it = first + tid; it < last; it += 256) {
-            const int4 cur = work[it];
-            const int hc = min(4, h - cur.z), wc = min(4, w - cur.y);
-            float x[4][4];
-            if (hc == 4 && wc == 4 && (w & 3) == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src + (long long)(cur.z + r) * w + cur.y);
-                    x[r][0] = v.x; x[r][1] = v.y; x[r][2] = v.z; x[r][3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++)
-                        x[r][c] = src[(long long)(cur.z + reflect_pad_idx(r, hc)) * w + cur.y + reflect_pad_idx(c, wc)];
-            }
-            float T[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) acc = __builtin_fmaf(D4[i][kk], x[kk][j], acc);
-                    T[i][j] = acc;
-                }
-            const long long out_base = out_plane + cur.w;
-            int out[16];
-            float Y[4][4], ymax = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) acc = __builtin_fmaf(T[i][kk], D4[jj][kk], acc);
-                    if (WANT_DCT) dct_f32[out_base + i * 4 + jj] = acc;
-                    Y[i][jj] = acc;
-                    ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
-                }
-            if (!(q_slow || __any(!(ymax < 131072.0f)))) {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) out[zigzag_pos<4>(i, jj)] = quantise_f32(Y[i][jj], sQ4[i * 4 + jj]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) out[zigzag_pos<4>(i, jj)] = quantise_f64(Y[i][jj], (int)sQ4[i * 4 + jj]);
-            }
-            int4 *dst = reinterpret_cast<int4 *>(coeffs + out_base);
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[r] = make_int4(out[4 * r], out[4 * r + 1], out[4 * r + 2], out[4 * r + 3]);
-        }
-    }
-}
-
-bool dct_fused_ok(const QtGeom &q) { return q.bmin == 4 && q.bmax >= 16 && q.cell == 4; }
-
-void launch_dct_small_fused(hipStream_t st, const Geom &g, const QtGeom &q, const DctFusedArgs &a)
-{
-    FusedGeom fg;
-    memset(&fg, 0, sizeof fg);
-    for (int l = 0; l < 3; l++) {
-        const int ll = l < g.nl ? l : 0;
-        fg.w[l] = g.w[ll]; fg.h[l] = g.h[ll]; fg.nchunk[l] = l < g.nl ? q.nchunk[l] : 0;
-        fg.ngroup[l] = (fg.nchunk[l] + kFuseChunks - 1) / kFuseChunks;
-        fg.poff[l] = g.poff[ll]; fg.coff[l] = q.coeff_off[ll]; fg.chunk_off[l] = q.chunk_off[ll];
-        for (int k = 0; k < 3; k++) fg.work_off[l][k] = q.work_off[ll][k];
-        fg.groups_per_image += fg.ngroup[l];
-    }
-    fg.pstride = g.pstride; fg.coeff_stride = q.coeff_stride; fg.chunk_stride = q.chunk_stride;
-    for (int k = 0; k < 3; k++) fg.work_stride[k] = q.work_stride[k];
-    fg.n_groups = (long long)g.B * fg.groups_per_image;
-    if (fg.n_groups < 1) return;
-    const long long blocks = ((fg.n_groups + 7) / 8) * 3 * 8;
-    if (a.dct_f32) hipLaunchKernelGGL(k_dct_small_fused<true>, dim3((unsigned)blocks), dim3(256), 0, st, fg, a);
-    else hipLaunchKernelGGL(k_dct_small_fused<false>, dim3((unsigned)blocks), dim3(256), 0, st, fg, a);
 }
 
 // ------------------------------------------------------------------------------------------------
