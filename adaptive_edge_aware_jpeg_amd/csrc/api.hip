@@ -34,7 +34,8 @@ struct aej_ctx {
     int *h_flag = nullptr;             // pinned host word for counter read-backs
     int last_hyst_passes = 0;
     int hyst_hint = 0;                 // passes the previous encode needed (speculative enqueue, verified at the end of the call)
-    int hyst_margin = 4;               // extra passes enqueued on top of the hint: shrinks to 2 while calls keep converging early, grows after a miss
+    int hyst_margin = 3;               // extra passes enqueued on top of the hint: shrinks to 2 while calls keep converging early, grows by 2 after a miss
+                                       // (round 3: 3 / streak of 4, was 4 / 8 -- every spare pass is a launch in the part's chain: 64 x 4K 6.58 -> 6.49 ms at margin 2)
     int hyst_streak = 0;               // consecutive calls that converged with at least 2 spare passes
     int hyst_enqueued = 0;             // passes enqueued speculatively by the current call (0 = verified path)
     bool capturing = false;            // the stream is being captured into a hipGraph: kernel nodes only (zero-fill by kernel, no copies)
@@ -387,6 +388,7 @@ extern "C" aej_ctx *aej_create(int device, void *hip_stream)
     if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
     if (const char *e = getenv("AEJ_SUB_CHAIN")) ctx->sub_chain = atoi(e);
     if (const char *e = getenv("AEJ_STAGE_CHAIN")) ctx->stage_mask = atoi(e) & 7;      // tuning knob (tools/profiling/sched_sweep.sh)
+    if (const char *e = getenv("AEJ_HYST_MARGIN")) { const int v = atoi(e); if (v >= 0 && v <= 8) ctx->hyst_margin = v; }      // tuning knob
     return ctx;
 }
 
@@ -864,7 +866,7 @@ static void speculation_update(aej_ctx *ctx, int n, int used)
         ctx->hyst_hint = used;
         ctx->last_hyst_passes = used;
         if (n - used >= 2) {
-            if (++ctx->hyst_streak >= 8 && ctx->hyst_margin > 2) { ctx->hyst_margin--; ctx->hyst_streak = 0; }
+            if (++ctx->hyst_streak >= 4 && ctx->hyst_margin > 2) { ctx->hyst_margin--; ctx->hyst_streak = 0; }
         } else {
             ctx->hyst_streak = 0;
         }

@@ -211,15 +211,16 @@ def git_head():
 
 
 def source_hash(root=None):
-    """sha256 (first 16 hex digits) over the CODE of the kernel sources and headers the library is built from -- comments and white
-    space stripped, so that editing a comment does not invalidate a profile: what a PMC profile is valid for.
+    """sha256 (first 16 hex digits) over the CODE of the kernel sources (kernels + their launchers; not the host orchestration in api.hip) and
+    headers the library is built from -- comments and white space stripped, so that editing a comment does not invalidate a profile: what a
+    per-kernel PMC profile is valid for.
     tools/profiling/pmc.py stores the same figure in the profile it writes, so staleness needs no git on the GPU box."""
     import hashlib
     import re
     d = os.path.join(root or ROOT, "adaptive_edge_aware_jpeg_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h")) and f != "api.hip":            # api.hip is host orchestration: no kernel, no launch shape
             text = open(os.path.join(d, f), errors="replace").read()
             text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
             text = re.sub(r"//[^\n]*", " ", text)                        # line comments (no string literal of these sources holds "//")
