@@ -42,38 +42,48 @@ _lib_lock = threading.Lock()
 # ---- hardware queues ------------------------------------------------------------------------------------------------
 # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue run one after the other.
 # The library overlaps sub-batches and calls on several streams and picks its schedule by the number of queues --
-# which only the host can know: the runtime reads the variable once, when it initialises.  Policy:
-#   * package imported BEFORE the process's first HIP call (torch.cuda not initialised): ask for 16 queues unless the variable is
-#     already set (or AEJ_KEEP_HW_QUEUES=1 forbids touching the environment), and trust the variable's value;
-#   * HIP already initialised at import: the environment is left alone and says nothing reliable -> assume HIP's default of 4 (the
-#     conservative two-sub-batch schedule) unless the application states the value with set_hw_queues().
+# which only the host can know: the runtime reads the variable once, when it initialises (any HIP call does that, torch.cuda.is_available()
+# included -- and nothing tells a later importer whether it has happened; torch.cuda.is_initialized() only speaks for torch's own lazy
+# initialisation).  Policy, from sure to unsure:
+#   * the variable is ALREADY in the environment when this package is imported (set by the launcher, or by a script before it imported
+#     torch, as bench.py does): that is what the runtime starts with -- trust its value, change nothing;
+#   * the variable is absent and torch has not even been imported: HIP cannot have initialised through it -- ask for 16 queues (unless
+#     AEJ_KEEP_HW_QUEUES=1 forbids touching the environment) and trust that;
+#   * the variable is absent and torch is imported: HIP may or may not be up.  Setting the variable can still help and cannot hurt
+#     (done unless torch says it is initialised, or AEJ_KEEP_HW_QUEUES=1), but it is NOT trusted: the library is told HIP's default of 4
+#     (its conservative two-sub-batch schedule) unless the application states the value with set_hw_queues().
 HIP_DEFAULT_HW_QUEUES = 4
 _hw_queues = HIP_DEFAULT_HW_QUEUES
 _hw_queues_source = "HIP default (assumed)"
 
 
-def _hip_initialised():
-    import sys
-    torch = sys.modules.get("torch")
-    try:
-        return bool(torch is not None and torch.cuda.is_initialized())
-    except Exception:
-        return True
-
-
 def request_hw_queues(want=16):
     """Called once at package import (see the policy above)."""
     global _hw_queues, _hw_queues_source
-    if _hip_initialised():
-        _hw_queues, _hw_queues_source = HIP_DEFAULT_HW_QUEUES, "HIP was initialised before this package was imported: HIP's default assumed"
+    import sys
+    keep = bool(os.environ.get("AEJ_KEEP_HW_QUEUES"))
+    present = os.environ.get("GPU_MAX_HW_QUEUES")
+    if present is not None:
+        try:
+            v = int(present)
+        except ValueError:
+            v = 0
+        if v > 0:
+            _hw_queues, _hw_queues_source = v, "GPU_MAX_HW_QUEUES was already in the environment when the package was imported"
         return _hw_queues
-    if "GPU_MAX_HW_QUEUES" not in os.environ and not os.environ.get("AEJ_KEEP_HW_QUEUES"):
-        os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+    torch = sys.modules.get("torch")
+    if torch is None:
+        if not keep:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+            _hw_queues, _hw_queues_source = want, "set at import, before torch (and with it HIP) was loaded"
+        return _hw_queues
     try:
-        v = int(os.environ.get("GPU_MAX_HW_QUEUES", HIP_DEFAULT_HW_QUEUES))
-    except ValueError:
-        v = HIP_DEFAULT_HW_QUEUES
-    _hw_queues, _hw_queues_source = (v if v > 0 else HIP_DEFAULT_HW_QUEUES), "GPU_MAX_HW_QUEUES at import, before HIP initialised"
+        torch_up = bool(torch.cuda.is_initialized())
+    except Exception:
+        torch_up = True
+    if not keep and not torch_up:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(want)          # may still take effect; not relied upon
+    _hw_queues, _hw_queues_source = HIP_DEFAULT_HW_QUEUES, "torch was imported before this package and the variable was absent: HIP's default assumed"
     return _hw_queues
 
 

@@ -274,6 +274,7 @@ def main():
     # imported BEFORE anything initialises HIP: the package then knows that the queue count in the environment is the one the runtime
     # will start with and tells the library (aej_set_hw_queues); imported later it would have to assume HIP's default of 4
     import adaptive_edge_aware_jpeg_amd as A
+    assert A.hw_queues()[0] == int(os.environ["GPU_MAX_HW_QUEUES"]), A.hw_queues()      # the variable was in the environment before torch was imported
     rank, local_rank, world = rank_env()
     # rehearsal switches (not used by the driver): AEJ_BENCH_BACKEND=gloo + AEJ_BENCH_ONE_DEVICE=1 run the multi-rank control flow
     # with every rank on GPU 0 of a one-GPU box; RCCL needs one GPU per rank

@@ -180,3 +180,23 @@ def test_compat_alias_packages_expose_the_reference_import_names():
         "print('ok')\n")
     out = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "compat")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_hardware_queue_policy_trusts_only_what_is_certain():
+    """_lib.request_hw_queues: the library is told a queue count only when the package can be sure the HIP runtime
+    starts (or started) with it -- variable already in the environment, or package imported before torch; after torch it assumes 4."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "AEJ_KEEP_HW_QUEUES")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+
+    def run(code, extra=None):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, **(extra or {})), timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return r.stdout.strip().splitlines()[-1]
+
+    probe = "import adaptive_edge_aware_jpeg_amd as A, os; print(A.hw_queues()[0], os.environ.get('GPU_MAX_HW_QUEUES'))"
+    assert run(probe) == "16 16"                                                    # before torch: asked for and trusted
+    assert run("import torch\n" + probe) == "4 16"                                # after torch: asked for, NOT trusted
+    assert run("import torch\n" + probe, {"GPU_MAX_HW_QUEUES": "12"}) == "12 12"   # present at process start: trusted as it is
+    assert run(probe, {"AEJ_KEEP_HW_QUEUES": "1"}) == "4 None"                      # opt-out: environment untouched
+    assert run("import adaptive_edge_aware_jpeg_amd as A; A.set_hw_queues(24); print(A.hw_queues()[0])") == "24"
