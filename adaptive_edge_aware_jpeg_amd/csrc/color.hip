@@ -648,12 +648,17 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
                             unsigned char *u8, int *hist)
 {
     // strip kernel: CLAHE tiles without padding whose edges no 4 x 2 patch straddles, in every layer
-    if ((g.W % 16) == 0 && (g.H % 8) == 0 && g.ctw[0] * 4 == g.W && g.cth[0] * 4 == g.H && g.ctw[0] >= 128 && !getenv("AEJ_COLOR_NO_STRIP")) {
+    // tuning knobs (tools/profiling), read once: AEJ_COLOR_NO_STRIP = the 128 x 16 kernel of rounds 1-2, AEJ_COLOR_STRIP_ROWS / AEJ_COLOR_WGS = strip
+    // height / workgroups in the persistent launch
+    static const bool no_strip = getenv("AEJ_COLOR_NO_STRIP") != nullptr;
+    static const int env_rows = getenv("AEJ_COLOR_STRIP_ROWS") ? atoi(getenv("AEJ_COLOR_STRIP_ROWS")) : 0;
+    static const int env_wgs = getenv("AEJ_COLOR_WGS") ? atoi(getenv("AEJ_COLOR_WGS")) : 0;
+    if ((g.W % 16) == 0 && (g.H % 8) == 0 && g.ctw[0] * 4 == g.W && g.cth[0] * 4 == g.H && g.ctw[0] >= 128 && !no_strip) {
         const int nxb = (g.W + 127) / 128;
         // rows per workgroup: as long as the launch still has a few thousand workgroups (one image spreads over the chip), at most 64
         int rows = 64;
         while (rows > 16 && (long long)nxb * ((g.cth[0] + rows - 1) / rows) * 4 * g.B < 4096) rows >>= 1;
-        if (const char *e = getenv("AEJ_COLOR_STRIP_ROWS")) rows = atoi(e) > 0 ? (atoi(e) + 15) / 16 * 16 : rows;
+        if (env_rows > 0) rows = (env_rows + 15) / 16 * 16;
         const int nys = (g.cth[0] + rows - 1) / rows;
         const long long nstrips = (long long)nxb * nys * 4 * g.B;
         // Workgroups in the launch.  The matrix spaces are a pure stream: ONE workgroup per CU (256 in all, each walking ~270 strips)
@@ -662,7 +667,7 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
         // other chains' kernels (64 x 4K pipelined step 7.4 -> 7.0 ms; with 128 workgroups the kernel takes 3.0 ms alone and the step
         // is still 7.0: the stage is off the critical path).  The spaces with float64 pows are arithmetic-bound: fill the chip.
         long long want = SPACE < 3 ? 256 : 256 * 8;
-        if (const char *e = getenv("AEJ_COLOR_WGS")) want = atoi(e) > 0 ? atoi(e) : want;      // tuning knob (tools/profiling)
+        if (env_wgs > 0) want = env_wgs;
         dim3 sgrid((unsigned)(nstrips < want ? nstrips : want));
         const bool prod = norm && u8 && hist && !raw;
         auto go = [&](auto kern, auto *in) { hipLaunchKernelGGL(kern, sgrid, dim3(256), 0, st, in, g, nc, raw, norm, u8, hist, nxb, nys, rows, (int)nstrips); };
