@@ -130,12 +130,15 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 //     rarely crosses a tile-centre line, and almost never one per axis: two packed LUTs are kept (windows that would need
 //     more -- tiny planes, the 0.5 % of tiles on a crossing of both axes -- take the general path that reads LUT bytes from
 //     global memory); a thread keeps its column for the whole tile, so the column weights live in registers;
-//   * stage B (Gaussian): a thread slides down 5 output rows of one column dword, re-using the horizontal [1 2 1] sums of the
-//     previous two rows: 3 LDS reads per row instead of 9.  The result is stored one dword per pixel as the float 2^23 + 4 g,
-//     whose BIT PATTERN is 0x4B000000 + 4 g: differences of bit patterns are table byte offsets (plain integer subtraction)
-//     and the float minus 2^23 is the tap value x 4 (one float subtraction, exact) -- no conversions in the bilateral stage;
-//   * stage C (bilateral): a thread owns 4 x 2 pixels.  All window reads are 16- or 8-byte reads of whole 512-byte row
-//     segments (conflict-free), and the weight of a pixel PAIR, which depends only on |difference| and distance, is fetched
+//   * stage B (Gaussian): a thread slides down 6 output rows of one column dword, re-using the horizontal [1 2 1] sums of the
+//     previous two rows: 3 LDS reads per row instead of 9.  The result is stored one HALFWORD per pixel: the integer 4 g.  Read as
+//     an integer, differences of two halfwords are table byte offsets (one SDWA subtraction picks the halves); read as a float16,
+//     the same bits are the DENORMAL 4 g * 2^-24, which `v_fma_mix_f32` widens exactly and for free inside the tap's fma.  The
+//     weight tables hold the weights times 2^24, so every product -- and with it every partial sum -- is bit for bit the one the
+//     unscaled filter forms (the weight sum comes out times 2^24, an exact scaling that the final quotient undoes): no conversion
+//     instructions in the bilateral stage, and a window is 24 registers instead of 48;
+//   * stage C (bilateral): a thread owns 4 x 2 pixels.  All window reads are 8-byte reads of whole 256-byte row segments
+//     (conflict-free), and the weight of a pixel PAIR, which depends only on |difference| and distance, is fetched
 //     once and used for both pixels: 76 instead of 96 table gathers per 8 pixels.
 // Every float operation per pixel is the same single IEEE operation in the same order as before (and as the CPU oracle).
 // ------------------------------------------------------------------------------------------------
@@ -152,15 +155,21 @@ constexpr int kBAW = kBTW + 8;            // staged columns: c <-> gx = x0 - 4 +
 constexpr int kBAW4 = kBAW / 4;           // 34 dwords per CLAHE row
 constexpr int kBAH = kBTH + 6;            // CLAHE rows  [y0-3, y0+TH+3)
 constexpr int kBGH = kBTH + 4;            // Gauss rows  [y0-2, y0+TH+2)
-constexpr int kBGW = kBAW + 4;            // Gaussian row stride in dwords; staged column c is stored at c + 2, so that the 8-dword window of
-                                          // a bilateral thread (columns 4 c4 + 2 .. 4 c4 + 9) is two ALIGNED 16-byte reads (conflict-free)
+constexpr int kBGW = kBAW + 4;            // Gaussian row stride in halfwords; staged column c is stored at c + 2, so that the 8-halfword window
+                                          // of a bilateral thread (columns 4 c4 + 2 .. 4 c4 + 9) is two ALIGNED 8-byte reads (conflict-free)
+constexpr int kBGW2 = kBGW / 2;           // ... in dwords
+static_assert(kBGW % 4 == 0, "Gaussian rows keep 8-byte alignment");
 constexpr int kBStripMax = 8;             // tiles of one tile-row handled by one workgroup (tables / histogram stay in LDS); fewer when
                                           // the batch is small, so that a single image still spreads over the whole chip
 constexpr int kASlots = kBT / kBAW4;      // 7 row slots: thread t owns column dword t % 34 and rows t / 34 + 7 k
 constexpr int kAIter = (kBAH + kASlots - 1) / kASlots;   // 6
 constexpr int kBRows = (kBGH + kASlots - 1) / kASlots;      // Gaussian output rows per thread: rows kBRows * (t / 34) .. + kBRows - 1
 static_assert(kASlots * kBRows >= kBGH && kASlots * kAIter >= kBAH, "thread -> row mapping must cover the tile");
-constexpr int kHistCopies = 8;             // (8 copies keep the workgroup under a third of the LDS)
+constexpr float kTwo24 = 16777216.0f, kTwo22 = 4194304.0f;
+#ifndef AEJ_X_BLUR_HIST
+#define AEJ_X_BLUR_HIST 8
+#endif
+constexpr int kHistCopies = AEJ_X_BLUR_HIST;             // (8 copies keep the workgroup under a third of the LDS)
 constexpr int kHistStride = 257;          // dwords per histogram copy: odd, so the same bin of different copies sits in different banks
 
 // Member order matters: DS instructions carry a 16-bit immediate offset, so everything addressed with small compile-time offsets
@@ -180,7 +189,7 @@ struct __attribute__((aligned(16))) BlurLds {
     unsigned int hist[kHistCopies * kHistStride];   // lane-striped copies of the 256 counters of this strip
     float4 P[2][256];                // packed LUTs: slot 0 = class 0 of both axes, slot 1 = class 1 of the ONE axis that changes
     unsigned int A[kBAH * kBAW4];    // CLAHE image, one byte per pixel
-    unsigned int G[kBGH * kBGW];     // Gaussian image, one dword per pixel: bit pattern of the float 2^23 + 4 * value
+    unsigned int G[kBGH * kBGW2];    // Gaussian image, one halfword per pixel: the integer 4 * value = the float16 DENORMAL 4 * value * 2^-24
 #ifdef AEJ_X_BLUR_PAD
     char pad[AEJ_X_BLUR_PAD];        // experiment (tools/profiling/variants.py): a larger footprint caps the workgroups per CU
 #endif
@@ -199,18 +208,39 @@ static_assert(3 * sizeof(BlurLds) <= 160 * 1024, "three workgroups per CU");
 // (-2,0) (-1,-1) (-1,0) (-1,1) (0,-2) (0,-1) (0,0) (0,1) (0,2) (1,-1) (1,0) (1,1) (2,0).  The weight of a tap is
 // space_w[k] * color_w[|delta|]; space_w takes 3 values (radius 1, sqrt 2, 2), so the float32 products are tabulated once per
 // workgroup (same multiplication, same rounding) in cw[0 / 1 / 2].  The centre tap has weight 1.
-// pair_w: weight of the pixel pair (a, b) of radius class T from the bit patterns of their Gaussian words.
-template <int T>
-__device__ __forceinline__ float pair_w(const BlurLds &L, unsigned a, unsigned b)
+// pair_w: weight (times 2^24) of the pixel pair (a, b) of radius class T; a / b = window dwords, ah / bh = which halfword (constants
+// once the loops are unrolled, so one of the four instruction forms survives).
+__device__ __forceinline__ int half_diff(unsigned a, int ah, unsigned b, int bh)       // 4 * (difference of the two Gaussian values): |d| <= 1020
 {
-    const int d = (int)b - (int)a;       // 4 * (difference of the two Gaussian values): |d| <= 1020
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(L.cw[T]) + 1024 + d);
+    int d;
+    if (ah == 0 && bh == 0) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(d) : "v"(b), "v"(a));
+    else if (ah == 0)       asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "=v"(d) : "v"(b), "v"(a));
+    else if (bh == 0)       asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(d) : "v"(b), "v"(a));
+    else                    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(d) : "v"(b), "v"(a));
+    return d;
 }
 
-__device__ __forceinline__ void acc_tap(float &sum, float &wsum, float v, float wgt)
+template <int T>
+__device__ __forceinline__ float pair_w(const BlurLds &L, unsigned a, int ah, unsigned b, int bh)
 {
-    wsum = wsum + wgt;
-    sum = __builtin_fmaf(v, wgt, sum);
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(L.cw[T]) + 1024 + half_diff(a, ah, b, bh));
+}
+
+// one tap: sum = fma(v, wgt, sum) with v = the halfword `h` of p widened inside the instruction
+__device__ __forceinline__ float tap_fma(unsigned p, int h, float wgt, float sum)
+{
+    float r;
+    if (h) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(wgt), "v"(sum));
+    else   asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(wgt), "v"(sum));
+    return r;
+}
+// the first tap of a pixel: fma(v, wgt, +0) = the rounded product (v, wgt >= 0)
+__device__ __forceinline__ float tap_first(unsigned p, int h, float wgt)
+{
+    float r;
+    if (h) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(wgt));
+    else   asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(wgt));
+    return r;
 }
 
 // CLAHE_Interpolation_Body for one pixel from the four LUT values (general path: LUT bytes straight from global memory)
@@ -288,9 +318,9 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
     for (int i = tid; i < 512; i += kBT) {
         const int d = i - 256;
         const float cwv = i == 0 ? 0.f : cb.color_w[d < 0 ? -d : d];     // slot 0 (d = -256) is never addressed
-        L.cw[0][i] = cb.space_w[5] * cwv;       // radius 1
-        L.cw[1][i] = cb.space_w[1] * cwv;       // radius sqrt(2)
-        L.cw[2][i] = cb.space_w[0] * cwv;       // radius 2
+        L.cw[0][i] = (cb.space_w[5] * cwv) * kTwo24;       // radius 1: OpenCV's float32 product, then the exact scaling
+        L.cw[1][i] = (cb.space_w[1] * cwv) * kTwo24;       // radius sqrt(2)
+        L.cw[2][i] = (cb.space_w[0] * cwv) * kTwo24;       // radius 2
     }
     for (int i = tid; i < kHistCopies * kHistStride; i += kBT) L.hist[i] = 0;
     if (tid < 2) L.pkey[tid] = -1;
@@ -461,9 +491,10 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
                         const unsigned int vo = ho2 + 2u * ho1 + ho + 0x00080008u;
                         const unsigned int e4 = (ve >> 2) & 0x03FC03FCu;     // 4 * pixel 0 | 4 * pixel 2 << 16
                         const unsigned int o4 = (vo >> 2) & 0x03FC03FCu;     // 4 * pixel 1 | 4 * pixel 3 << 16
-                        unsigned int *gp = &L.G[(ja - 2) * kBGW + 4 * i4 + 2];
-                        *reinterpret_cast<uint2 *>(gp) = make_uint2((e4 & 0xffffu) | 0x4B000000u, (o4 & 0xffffu) | 0x4B000000u);
-                        *reinterpret_cast<uint2 *>(gp + 2) = make_uint2((e4 >> 16) | 0x4B000000u, (o4 >> 16) | 0x4B000000u);
+                        // halfwords (4 p0, 4 p1), (4 p2, 4 p3) at staged columns 4 i4 + 2 .. + 5
+                        unsigned int *gp = &L.G[(ja - 2) * kBGW2 + 2 * i4 + 1];
+                        gp[0] = __builtin_amdgcn_perm(o4, e4, 0x05040100u);
+                        gp[1] = __builtin_amdgcn_perm(o4, e4, 0x07060302u);
                     }
                     he2 = he1; he1 = he; ho2 = ho1; ho1 = ho;
                 }
@@ -474,7 +505,7 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
             for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
                 int j = idx / kBTW, i = idx - j * kBTW;
                 if (x0 + i < w && y0 + j < h)
-                    cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] = (unsigned char)((L.G[(j + 2) * kBGW + i + 6] & 0xffffu) >> 2);
+                    cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] = (unsigned char)(reinterpret_cast<const unsigned short *>(L.G)[(j + 2) * kBGW + i + 6] >> 2);
             }
         // ---- stage C: bilateral; the thread owns output pixels (x0 + 4 c4 + c, y0 + yy + r), c = 0..3, r = 0..1.
         // Window element W[wr][wc] = Gaussian row yy + wr (wr = 0..5 <-> dy = -2..3 from output row 0), column 4 c4 + 2 + wc
@@ -486,81 +517,87 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
 #pragma unroll 1
         for (int pass = 0; pass < kBTH / (2 * kBPairsPerPass); pass++) {
             const int yy = 2 * ((tc >> 5) + kBPairsPerPass * pass);
-            unsigned int W[6][8];
+            unsigned int W[6][4];          // halfword wc of row wr = half (wc & 1) of W[wr][wc >> 1]
             {
-                // twelve aligned 16-byte reads (512 contiguous bytes per 32 lanes: conflict-free), issued as written: left to itself
-                // the compiler narrows them to the 36 dwords that are used and emits 8-byte / 4-byte reads at a 16-byte lane stride,
-                // which lose 2 - 4 x to bank conflicts (measured: 40 % of this kernel's LDS cycles)
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 m[12];
-                const unsigned int base = (unsigned int)(size_t)(L.G + yy * kBGW + 4 * c4 + 4);       // W[0][0]: 16-byte aligned LDS address
-                constexpr int RS = kBGW * 4;
-                static_assert(5 * RS + 16 < 65536, "DS offset field");
-                asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:16\n\t"
-                             "ds_read_b128 %2, %12 offset:%c13\n\tds_read_b128 %3, %12 offset:%c14\n\t"
-                             "ds_read_b128 %4, %12 offset:%c15\n\tds_read_b128 %5, %12 offset:%c16\n\t"
-                             "ds_read_b128 %6, %12 offset:%c17\n\tds_read_b128 %7, %12 offset:%c18\n\t"
-                             "ds_read_b128 %8, %12 offset:%c19\n\tds_read_b128 %9, %12 offset:%c20\n\t"
-                             "ds_read_b128 %10, %12 offset:%c21\n\tds_read_b128 %11, %12 offset:%c22\n\t"
+                // twelve aligned 8-byte reads (256 contiguous bytes per 32 lanes: conflict-free), issued as written: left to itself
+                // the compiler narrows them to the halfwords that are used and emits reads at a lane stride that collide in the banks
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 m[12];
+                const unsigned int base = (unsigned int)(size_t)(L.G + yy * kBGW2 + 2 * c4 + 2);       // W[0][0]: 8-byte aligned LDS address
+                constexpr int RS = kBGW2 * 4;
+                static_assert(5 * RS + 8 < 65536 && (RS % 8) == 0, "DS offset field, alignment");
+                asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:8\n\t"
+                             "ds_read_b64 %2, %12 offset:%c13\n\tds_read_b64 %3, %12 offset:%c14\n\t"
+                             "ds_read_b64 %4, %12 offset:%c15\n\tds_read_b64 %5, %12 offset:%c16\n\t"
+                             "ds_read_b64 %6, %12 offset:%c17\n\tds_read_b64 %7, %12 offset:%c18\n\t"
+                             "ds_read_b64 %8, %12 offset:%c19\n\tds_read_b64 %9, %12 offset:%c20\n\t"
+                             "ds_read_b64 %10, %12 offset:%c21\n\tds_read_b64 %11, %12 offset:%c22\n\t"
                              "s_waitcnt lgkmcnt(0)"
                              : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6]), "=&v"(m[7]), "=&v"(m[8]),
                                "=&v"(m[9]), "=&v"(m[10]), "=&v"(m[11])
-                             : "v"(base), "i"(RS), "i"(RS + 16), "i"(2 * RS), "i"(2 * RS + 16), "i"(3 * RS), "i"(3 * RS + 16), "i"(4 * RS), "i"(4 * RS + 16),
-                               "i"(5 * RS), "i"(5 * RS + 16)
+                             : "v"(base), "i"(RS), "i"(RS + 8), "i"(2 * RS), "i"(2 * RS + 8), "i"(3 * RS), "i"(3 * RS + 8), "i"(4 * RS), "i"(4 * RS + 8),
+                               "i"(5 * RS), "i"(5 * RS + 8)
                              : "memory");
 #pragma unroll
                 for (int wr = 0; wr < 6; wr++) {
-                    W[wr][0] = m[2 * wr].x; W[wr][1] = m[2 * wr].y; W[wr][2] = m[2 * wr].z; W[wr][3] = m[2 * wr].w;
-                    W[wr][4] = m[2 * wr + 1].x; W[wr][5] = m[2 * wr + 1].y; W[wr][6] = m[2 * wr + 1].z; W[wr][7] = m[2 * wr + 1].w;
+                    W[wr][0] = m[2 * wr].x; W[wr][1] = m[2 * wr].y; W[wr][2] = m[2 * wr + 1].x; W[wr][3] = m[2 * wr + 1].y;
                 }
             }
             // Pair weights: each is fetched once and used by both pixels of the pair when both belong to this thread.  Indexing
             // (window coordinates): H1[r][i] = pair (r+2, 1+i)-(r+2, 2+i); H2[r][i] = (r+2, i)-(r+2, i+2); V1[rr][c] = (1+rr, c+2)-(2+rr, c+2);
             // V2[rr][c] = (rr, c+2)-(rr+2, c+2); D1[rr][i] = (1+rr, 1+i)-(2+rr, 2+i); D2[rr][i] = (1+rr, 2+i)-(2+rr, 1+i).
             // The two output rows are done one after the other (a scheduling barrier keeps the second row's gathers from being
-            // hoisted over the first row's sums: the register budget is 128); the pairs between them (V1[1], D1[1], D2[1]) carry over.
+            // hoisted over the first row's sums); the pairs between them (V1[1], D1[1], D2[1]) carry over.
+            auto PW0 = [&](int ar, int ac, int br, int bc) { return pair_w<0>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
+            auto PW1 = [&](int ar, int ac, int br, int bc) { return pair_w<1>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
+            auto PW2 = [&](int ar, int ac, int br, int bc) { return pair_w<2>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
             float sums[8], wsums[8];
             float V1m[4], D1m[5], D2m[5];
 #pragma unroll
-            for (int c = 0; c < 4; c++) V1m[c] = pair_w<0>(L, W[2][c + 2], W[3][c + 2]);
+            for (int c = 0; c < 4; c++) V1m[c] = PW0(2, c + 2, 3, c + 2);
 #pragma unroll
             for (int i = 0; i < 5; i++) {
-                D1m[i] = pair_w<1>(L, W[2][1 + i], W[3][2 + i]);
-                D2m[i] = pair_w<1>(L, W[2][2 + i], W[3][1 + i]);
+                D1m[i] = PW1(2, 1 + i, 3, 2 + i);
+                D2m[i] = PW1(2, 2 + i, 3, 1 + i);
             }
-            auto val = [&](int wr, int wc) { return __builtin_bit_cast(float, W[wr][wc]) - 8388608.0f; };     // 4 x tap value, exact
+            float two24 = kTwo24;
+            asm volatile("" : "+s"(two24));          // the centre weight lives in a scalar register (VOP3P takes no literal)
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 float H1[5], H2[6], V1o[4], V2a[4], V2b[4], D1o[4], D2o[4];
 #pragma unroll
-                for (int i = 0; i < 5; i++) H1[i] = pair_w<0>(L, W[r + 2][1 + i], W[r + 2][2 + i]);
+                for (int i = 0; i < 5; i++) H1[i] = PW0(r + 2, 1 + i, r + 2, 2 + i);
 #pragma unroll
-                for (int i = 0; i < 6; i++) H2[i] = pair_w<2>(L, W[r + 2][i], W[r + 2][i + 2]);
+                for (int i = 0; i < 6; i++) H2[i] = PW2(r + 2, i, r + 2, i + 2);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    V2a[c] = pair_w<2>(L, W[r][c + 2], W[r + 2][c + 2]);              // (-2, 0)
-                    V2b[c] = pair_w<2>(L, W[r + 2][c + 2], W[r + 4][c + 2]);          // (+2, 0)
+                    V2a[c] = PW2(r, c + 2, r + 2, c + 2);                  // (-2, 0)
+                    V2b[c] = PW2(r + 2, c + 2, r + 4, c + 2);              // (+2, 0)
                     // the vertical / diagonal pairs towards the row that is NOT this thread's other output row
-                    V1o[c] = r == 0 ? pair_w<0>(L, W[1][c + 2], W[2][c + 2]) : pair_w<0>(L, W[3][c + 2], W[4][c + 2]);
-                    D1o[c] = r == 0 ? pair_w<1>(L, W[1][1 + c], W[2][2 + c]) : pair_w<1>(L, W[3][2 + c], W[4][3 + c]);      // r = 0: (-1,-1); r = 1: (+1,+1)
-                    D2o[c] = r == 0 ? pair_w<1>(L, W[1][3 + c], W[2][2 + c]) : pair_w<1>(L, W[3][2 + c], W[4][1 + c]);      // r = 0: (-1,+1); r = 1: (+1,-1)
+                    V1o[c] = r == 0 ? PW0(1, c + 2, 2, c + 2) : PW0(3, c + 2, 4, c + 2);
+                    D1o[c] = r == 0 ? PW1(1, 1 + c, 2, 2 + c) : PW1(3, 2 + c, 4, 3 + c);      // r = 0: (-1,-1); r = 1: (+1,+1)
+                    D2o[c] = r == 0 ? PW1(1, 3 + c, 2, 2 + c) : PW1(3, 2 + c, 4, 1 + c);      // r = 0: (-1,+1); r = 1: (+1,-1)
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    float sum = 0.f, wsum = 0.f;
-                    acc_tap(sum, wsum, val(r, c + 2), V2a[c]);                                  // (-2,  0)
-                    acc_tap(sum, wsum, val(r + 1, c + 1), r == 0 ? D1o[c] : D1m[c]);            // (-1, -1)
-                    acc_tap(sum, wsum, val(r + 1, c + 2), r == 0 ? V1o[c] : V1m[c]);            // (-1,  0)
-                    acc_tap(sum, wsum, val(r + 1, c + 3), r == 0 ? D2o[c] : D2m[c + 1]);        // (-1, +1)
-                    acc_tap(sum, wsum, val(r + 2, c), H2[c]);                                   // ( 0, -2)
-                    acc_tap(sum, wsum, val(r + 2, c + 1), H1[c]);                               // ( 0, -1)
-                    acc_tap(sum, wsum, val(r + 2, c + 2), 1.0f);                                // centre
-                    acc_tap(sum, wsum, val(r + 2, c + 3), H1[c + 1]);                           // ( 0, +1)
-                    acc_tap(sum, wsum, val(r + 2, c + 4), H2[c + 2]);                           // ( 0, +2)
-                    acc_tap(sum, wsum, val(r + 3, c + 1), r == 0 ? D2m[c] : D2o[c]);            // (+1, -1)
-                    acc_tap(sum, wsum, val(r + 3, c + 2), r == 0 ? V1m[c] : V1o[c]);            // (+1,  0)
-                    acc_tap(sum, wsum, val(r + 3, c + 3), r == 0 ? D1m[c + 1] : D1o[c]);        // (+1, +1)
-                    acc_tap(sum, wsum, val(r + 4, c + 2), V2b[c]);                              // (+2,  0)
+                    auto tap = [&](float &sum, float &wsum, int wr, int wc, float wgt) {
+                        wsum = wsum + wgt;
+                        sum = tap_fma(W[wr][wc >> 1], wc & 1, wgt, sum);
+                    };
+                    float wsum = V2a[c];                                                 // (-2,  0): 0 + w = w, fma(v, w, 0) = v * w
+                    float sum = tap_first(W[r][(c + 2) >> 1], (c + 2) & 1, V2a[c]);
+                    tap(sum, wsum, r + 1, c + 1, r == 0 ? D1o[c] : D1m[c]);              // (-1, -1)
+                    tap(sum, wsum, r + 1, c + 2, r == 0 ? V1o[c] : V1m[c]);              // (-1,  0)
+                    tap(sum, wsum, r + 1, c + 3, r == 0 ? D2o[c] : D2m[c + 1]);          // (-1, +1)
+                    tap(sum, wsum, r + 2, c, H2[c]);                                     // ( 0, -2)
+                    tap(sum, wsum, r + 2, c + 1, H1[c]);                                 // ( 0, -1)
+                    tap(sum, wsum, r + 2, c + 2, two24);                                 // centre: weight 1
+                    tap(sum, wsum, r + 2, c + 3, H1[c + 1]);                             // ( 0, +1)
+                    tap(sum, wsum, r + 2, c + 4, H2[c + 2]);                             // ( 0, +2)
+                    tap(sum, wsum, r + 3, c + 1, r == 0 ? D2m[c] : D2o[c]);              // (+1, -1)
+                    tap(sum, wsum, r + 3, c + 2, r == 0 ? V1m[c] : V1o[c]);              // (+1,  0)
+                    tap(sum, wsum, r + 3, c + 3, r == 0 ? D1m[c + 1] : D1o[c]);          // (+1, +1)
+                    tap(sum, wsum, r + 4, c + 2, V2b[c]);                                // (+2,  0)
                     sums[r * 4 + c] = sum; wsums[r * 4 + c] = wsum;
                 }
                 if (r == 0) __builtin_amdgcn_sched_barrier(0);
@@ -576,12 +613,12 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int q = r * 4 + c;
-                    z[q] = (sums[q] * __builtin_amdgcn_rcpf(wsums[q])) * 0.25f;
+                    z[q] = (sums[q] * __builtin_amdgcn_rcpf(wsums[q])) * kTwo22;
                     amb = amb || (__builtin_fabsf(__builtin_amdgcn_fractf(z[q]) - 0.5f) < 1.220703125e-4f);
                 }
                 if (__any(amb)) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) z[r * 4 + c] = (sums[r * 4 + c] / wsums[r * 4 + c]) * 0.25f;
+                    for (int c = 0; c < 4; c++) z[r * 4 + c] = (sums[r * 4 + c] / wsums[r * 4 + c]) * kTwo22;
                 }
             }
 #pragma unroll
