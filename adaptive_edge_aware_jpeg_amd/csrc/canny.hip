@@ -149,8 +149,6 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 // 64 x 4K step goes from 7.50 to 7.33 ms (256 threads on 128 x 64 tiles, 235 VGPRs: 7.44; 384 threads on 128 x 48: 3.8 ms alone).
 constexpr int kBT = 256;                  // threads per workgroup
 constexpr int kBTW = 128, kBTH = 32;      // output tile
-constexpr int kBPairsPerPass = kBT / 32;  // stage C: row pairs one pass of the workgroup covers
-static_assert(kBTH % (2 * kBPairsPerPass) == 0, "stage C passes must tile the rows");
 constexpr int kBAW = kBTW + 8;            // staged columns: c <-> gx = x0 - 4 + c (bytes per CLAHE row, dwords per Gaussian row)
 constexpr int kBAW4 = kBAW / 4;           // 34 dwords per CLAHE row
 constexpr int kBAH = kBTH + 6;            // CLAHE rows  [y0-3, y0+TH+3)
@@ -196,6 +194,9 @@ struct __attribute__((aligned(16))) BlurLds {
 };
 #ifndef AEJ_X_BLUR_PAD
 static_assert(3 * sizeof(BlurLds) <= 160 * 1024, "three workgroups per CU");
+#endif
+#ifndef AEJ_X_BLUR_DYNLDS
+#define AEJ_X_BLUR_DYNLDS 0            // experiment: dynamic LDS the compiler does not see (caps the workgroups per CU without changing its register budget)
 #endif
 #ifndef AEJ_X_BLUR_WAVES
 #define AEJ_X_BLUR_WAVES 3
@@ -289,6 +290,18 @@ __device__ __forceinline__ bool locate_blur_strip(const Geom &g, int strip, int 
     return false;
 }
 
+#ifdef AEJ_X_BLUR_STAMPS
+// diagnostic build only (tools/profiling/variants.py + blur_stamps.py): cycles per phase of the tile loop, per wave of the first 512 workgroups
+__device__ long long g_blur_stamps[512][4][10];
+#define AEJ_BSTAMP(i) { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
+extern "C" __attribute__((visibility("default"))) int aej_debug_read_blur_stamps(long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blur_stamps), sizeof(g_blur_stamps), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define AEJ_BSTAMP(i)
+#endif
+
 __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD: 168 VGPRs
 {
     __shared__ BlurLds L;
@@ -312,6 +325,9 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         return x0 >= 4 && y0 >= 3 && x0 + kBTW + 4 <= w && y0 + kBTH + 3 <= h && (w % 4) == 0;
     };
     unsigned int raw[kAIter];
+#ifdef AEJ_X_BLUR_STAMPS
+    long long st_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = __builtin_amdgcn_s_memtime();
+#endif
     blur_prefetch(src, w, h, tx_begin * kBTW, y0, is_aligned(tx_begin), raw);      // flies while the per-strip tables are built
 
     // ---- per-strip set-up
@@ -351,6 +367,7 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         if (tid == 0) L.cls[5] = n;            // read by every tile's prologue after its own barrier
     }
     unsigned char *dst = cb.u8b + pbase;
+    AEJ_BSTAMP(0)
 
     for (int tx = tx_begin; tx < tx_end; tx++) {
         const int x0 = tx * kBTW;
@@ -406,6 +423,7 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         // Thread -> work mappings are re-derived per tile from a copy of the thread id the compiler cannot see through: otherwise
         // it hoists a few dozen per-thread LDS addresses out of the tile loop and, with stage C needing the whole register
         // budget, parks them in scratch memory.
+        AEJ_BSTAMP(1)
         int tq = tid;
         asm volatile("" : "+v"(tq));
         const int acol = tq % kBAW4, aslot = tq / kBAW4;      // stage A / B: this thread's column dword and row slot / row group
@@ -458,8 +476,10 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
             }
         }
         // raw[] is free again: the next tile's bytes fly while this tile runs stages B and C
+        AEJ_BSTAMP(2)
         if (tx + 1 < tx_end) blur_prefetch(src, w, h, (tx + 1) * kBTW, y0, is_aligned(tx + 1), raw);
         __syncthreads();
+        AEJ_BSTAMP(3)
         if (cb.dump_clahe)
             for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
                 int j = idx / kBTW, i = idx - j * kBTW;
@@ -500,92 +520,117 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
                 }
             }
         }
+        AEJ_BSTAMP(4)
         __syncthreads();
+        AEJ_BSTAMP(5)
         if (cb.dump_gauss)
             for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
                 int j = idx / kBTW, i = idx - j * kBTW;
                 if (x0 + i < w && y0 + j < h)
                     cb.dump_gauss[pbase + (long long)(y0 + j) * w + x0 + i] = (unsigned char)(reinterpret_cast<const unsigned short *>(L.G)[(j + 2) * kBGW + i + 6] >> 2);
             }
-        // ---- stage C: bilateral; the thread owns output pixels (x0 + 4 c4 + c, y0 + yy + r), c = 0..3, r = 0..1.
-        // Window element W[wr][wc] = Gaussian row yy + wr (wr = 0..5 <-> dy = -2..3 from output row 0), column 4 c4 + 2 + wc
-        // (wc = 0..7 <-> dx = -2..5 from output column 0); output pixel (r, c) is W[r + 2][c + 2].
+        // ---- stage C: bilateral; the thread owns output pixels (x0 + 4 c4 + c, y0 + 4 rg + r), c = 0..3, r = 0..3, as two row pairs
+        // handled one after the other ("it" = 0, 1; yy = 4 rg + 2 it is the pair's first row).
+        // Window element W[wr][wc] = Gaussian row 4 rg + wr (wr = 0..7), column 4 c4 + 2 + wc (wc = 0..7 <-> dx = -2..5 from output
+        // column 0); in terms of the pair's own rows ro = 2 it: W[ro + wr'] is dy = wr' - 2 from the pair's first output row, and output
+        // pixel (r, c) of the pair is W[ro + r + 2][c + 2].  The second pair re-uses six of the eight window rows and the 18 pair
+        // weights that straddle the two pairs (its "above" pairs are the first pair's "below" pairs): 58 table gathers instead of 76.
         int tc = tid;
         asm volatile("" : "+v"(tc));
         const int c4 = tc & 31;
         unsigned int *hcopy = L.hist + (tc % kHistCopies) * kHistStride;
-#pragma unroll 1
-        for (int pass = 0; pass < kBTH / (2 * kBPairsPerPass); pass++) {
-            const int yy = 2 * ((tc >> 5) + kBPairsPerPass * pass);
-            unsigned int W[6][4];          // halfword wc of row wr = half (wc & 1) of W[wr][wc >> 1]
-            {
-                // twelve aligned 8-byte reads (256 contiguous bytes per 32 lanes: conflict-free), issued as written: left to itself
-                // the compiler narrows them to the halfwords that are used and emits reads at a lane stride that collide in the banks
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 m[12];
-                const unsigned int base = (unsigned int)(size_t)(L.G + yy * kBGW2 + 2 * c4 + 2);       // W[0][0]: 8-byte aligned LDS address
-                constexpr int RS = kBGW2 * 4;
-                static_assert(5 * RS + 8 < 65536 && (RS % 8) == 0, "DS offset field, alignment");
-                asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:8\n\t"
-                             "ds_read_b64 %2, %12 offset:%c13\n\tds_read_b64 %3, %12 offset:%c14\n\t"
-                             "ds_read_b64 %4, %12 offset:%c15\n\tds_read_b64 %5, %12 offset:%c16\n\t"
-                             "ds_read_b64 %6, %12 offset:%c17\n\tds_read_b64 %7, %12 offset:%c18\n\t"
-                             "ds_read_b64 %8, %12 offset:%c19\n\tds_read_b64 %9, %12 offset:%c20\n\t"
-                             "ds_read_b64 %10, %12 offset:%c21\n\tds_read_b64 %11, %12 offset:%c22\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6]), "=&v"(m[7]), "=&v"(m[8]),
-                               "=&v"(m[9]), "=&v"(m[10]), "=&v"(m[11])
-                             : "v"(base), "i"(RS), "i"(RS + 8), "i"(2 * RS), "i"(2 * RS + 8), "i"(3 * RS), "i"(3 * RS + 8), "i"(4 * RS), "i"(4 * RS + 8),
-                               "i"(5 * RS), "i"(5 * RS + 8)
-                             : "memory");
+        static_assert(kBTH == 4 * (kBT / 32), "one group of four rows per 32 threads");
+        unsigned int W[8][4];          // halfword wc of row wr = half (wc & 1) of W[wr][wc >> 1]
+        {
+            // sixteen aligned 8-byte reads (256 contiguous bytes per 32 lanes: conflict-free), issued as written: left to itself
+            // the compiler narrows them to the halfwords that are used and emits reads at a lane stride that collide in the banks
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 m[16];
+            const unsigned int base = (unsigned int)(size_t)(L.G + 4 * (tc >> 5) * kBGW2 + 2 * c4 + 2);       // W[0][0]: 8-byte aligned LDS address
+            constexpr int RS = kBGW2 * 4;
+            static_assert(7 * RS + 8 < 65536 && (RS % 8) == 0, "DS offset field, alignment");
+            asm volatile("ds_read_b64 %0, %16\n\tds_read_b64 %1, %16 offset:8\n\t"
+                         "ds_read_b64 %2, %16 offset:%c17\n\tds_read_b64 %3, %16 offset:%c18\n\t"
+                         "ds_read_b64 %4, %16 offset:%c19\n\tds_read_b64 %5, %16 offset:%c20\n\t"
+                         "ds_read_b64 %6, %16 offset:%c21\n\tds_read_b64 %7, %16 offset:%c22\n\t"
+                         "ds_read_b64 %8, %16 offset:%c23\n\tds_read_b64 %9, %16 offset:%c24\n\t"
+                         "ds_read_b64 %10, %16 offset:%c25\n\tds_read_b64 %11, %16 offset:%c26\n\t"
+                         "ds_read_b64 %12, %16 offset:%c27\n\tds_read_b64 %13, %16 offset:%c28\n\t"
+                         "ds_read_b64 %14, %16 offset:%c29\n\tds_read_b64 %15, %16 offset:%c30\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6]), "=&v"(m[7]), "=&v"(m[8]),
+                           "=&v"(m[9]), "=&v"(m[10]), "=&v"(m[11]), "=&v"(m[12]), "=&v"(m[13]), "=&v"(m[14]), "=&v"(m[15])
+                         : "v"(base), "i"(RS), "i"(RS + 8), "i"(2 * RS), "i"(2 * RS + 8), "i"(3 * RS), "i"(3 * RS + 8), "i"(4 * RS), "i"(4 * RS + 8),
+                           "i"(5 * RS), "i"(5 * RS + 8), "i"(6 * RS), "i"(6 * RS + 8), "i"(7 * RS), "i"(7 * RS + 8)
+                         : "memory");
 #pragma unroll
-                for (int wr = 0; wr < 6; wr++) {
-                    W[wr][0] = m[2 * wr].x; W[wr][1] = m[2 * wr].y; W[wr][2] = m[2 * wr + 1].x; W[wr][3] = m[2 * wr + 1].y;
-                }
+            for (int wr = 0; wr < 8; wr++) {
+                W[wr][0] = m[2 * wr].x; W[wr][1] = m[2 * wr].y; W[wr][2] = m[2 * wr + 1].x; W[wr][3] = m[2 * wr + 1].y;
             }
+        }
+        float two24 = kTwo24;
+        asm volatile("" : "+s"(two24));          // the centre weight lives in a scalar register (VOP3P takes no literal)
+        auto PW0 = [&](int ar, int ac, int br, int bc) { return pair_w<0>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
+        auto PW1 = [&](int ar, int ac, int br, int bc) { return pair_w<1>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
+        auto PW2 = [&](int ar, int ac, int br, int bc) { return pair_w<2>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
+        // weights of the pairs between the first pair's rows and the second's, as the first pair fetched them
+        float cV1[4], cV2a[4], cV2b[4], cD1[4], cD2[4];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int ro = 2 * it;
+            const int yy = 4 * (tc >> 5) + ro;
             // Pair weights: each is fetched once and used by both pixels of the pair when both belong to this thread.  Indexing
-            // (window coordinates): H1[r][i] = pair (r+2, 1+i)-(r+2, 2+i); H2[r][i] = (r+2, i)-(r+2, i+2); V1[rr][c] = (1+rr, c+2)-(2+rr, c+2);
+            // (window rows relative to ro): H1[r][i] = pair (r+2, 1+i)-(r+2, 2+i); H2[r][i] = (r+2, i)-(r+2, i+2); V1[rr][c] = (1+rr, c+2)-(2+rr, c+2);
             // V2[rr][c] = (rr, c+2)-(rr+2, c+2); D1[rr][i] = (1+rr, 1+i)-(2+rr, 2+i); D2[rr][i] = (1+rr, 2+i)-(2+rr, 1+i).
             // The two output rows are done one after the other (a scheduling barrier keeps the second row's gathers from being
             // hoisted over the first row's sums); the pairs between them (V1[1], D1[1], D2[1]) carry over.
-            auto PW0 = [&](int ar, int ac, int br, int bc) { return pair_w<0>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
-            auto PW1 = [&](int ar, int ac, int br, int bc) { return pair_w<1>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
-            auto PW2 = [&](int ar, int ac, int br, int bc) { return pair_w<2>(L, W[ar][ac >> 1], ac & 1, W[br][bc >> 1], bc & 1); };
             float sums[8], wsums[8];
             float V1m[4], D1m[5], D2m[5];
 #pragma unroll
-            for (int c = 0; c < 4; c++) V1m[c] = PW0(2, c + 2, 3, c + 2);
+            for (int c = 0; c < 4; c++) V1m[c] = PW0(ro + 2, c + 2, ro + 3, c + 2);
 #pragma unroll
             for (int i = 0; i < 5; i++) {
-                D1m[i] = PW1(2, 1 + i, 3, 2 + i);
-                D2m[i] = PW1(2, 2 + i, 3, 1 + i);
+                D1m[i] = PW1(ro + 2, 1 + i, ro + 3, 2 + i);
+                D2m[i] = PW1(ro + 2, 2 + i, ro + 3, 1 + i);
             }
-            float two24 = kTwo24;
-            asm volatile("" : "+s"(two24));          // the centre weight lives in a scalar register (VOP3P takes no literal)
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 float H1[5], H2[6], V1o[4], V2a[4], V2b[4], D1o[4], D2o[4];
 #pragma unroll
-                for (int i = 0; i < 5; i++) H1[i] = PW0(r + 2, 1 + i, r + 2, 2 + i);
+                for (int i = 0; i < 5; i++) H1[i] = PW0(ro + r + 2, 1 + i, ro + r + 2, 2 + i);
 #pragma unroll
-                for (int i = 0; i < 6; i++) H2[i] = PW2(r + 2, i, r + 2, i + 2);
+                for (int i = 0; i < 6; i++) H2[i] = PW2(ro + r + 2, i, ro + r + 2, i + 2);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    V2a[c] = PW2(r, c + 2, r + 2, c + 2);                  // (-2, 0)
-                    V2b[c] = PW2(r + 2, c + 2, r + 4, c + 2);              // (+2, 0)
-                    // the vertical / diagonal pairs towards the row that is NOT this thread's other output row
-                    V1o[c] = r == 0 ? PW0(1, c + 2, 2, c + 2) : PW0(3, c + 2, 4, c + 2);
-                    D1o[c] = r == 0 ? PW1(1, 1 + c, 2, 2 + c) : PW1(3, 2 + c, 4, 3 + c);      // r = 0: (-1,-1); r = 1: (+1,+1)
-                    D2o[c] = r == 0 ? PW1(1, 3 + c, 2, 2 + c) : PW1(3, 2 + c, 4, 1 + c);      // r = 0: (-1,+1); r = 1: (+1,-1)
+                    // (-2, 0): the second pair's are the first pair's (+2, 0)
+                    V2a[c] = it == 1 ? (r == 0 ? cV2a[c] : cV2b[c]) : PW2(ro + r, c + 2, ro + r + 2, c + 2);
+                    V2b[c] = PW2(ro + r + 2, c + 2, ro + r + 4, c + 2);              // (+2, 0)
+                    // the vertical / diagonal pairs towards the row that is NOT this pair's other output row
+                    if (r == 0) {
+                        V1o[c] = it == 1 ? cV1[c] : PW0(ro + 1, c + 2, ro + 2, c + 2);
+                        D1o[c] = it == 1 && c >= 1 ? cD1[c - 1] : PW1(ro + 1, 1 + c, ro + 2, 2 + c);      // (-1,-1)
+                        D2o[c] = it == 1 && c <= 2 ? cD2[c + 1] : PW1(ro + 1, 3 + c, ro + 2, 2 + c);      // (-1,+1)
+                    } else {
+                        V1o[c] = PW0(ro + 3, c + 2, ro + 4, c + 2);
+                        D1o[c] = PW1(ro + 3, 2 + c, ro + 4, 3 + c);      // (+1,+1)
+                        D2o[c] = PW1(ro + 3, 2 + c, ro + 4, 1 + c);      // (+1,-1)
+                    }
+                }
+                if (it == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (r == 0) cV2a[c] = V2b[c];
+                        else { cV2b[c] = V2b[c]; cV1[c] = V1o[c]; cD1[c] = D1o[c]; cD2[c] = D2o[c]; }
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     auto tap = [&](float &sum, float &wsum, int wr, int wc, float wgt) {
                         wsum = wsum + wgt;
-                        sum = tap_fma(W[wr][wc >> 1], wc & 1, wgt, sum);
+                        sum = tap_fma(W[ro + wr][wc >> 1], wc & 1, wgt, sum);
                     };
                     float wsum = V2a[c];                                                 // (-2,  0): 0 + w = w, fma(v, w, 0) = v * w
-                    float sum = tap_first(W[r][(c + 2) >> 1], (c + 2) & 1, V2a[c]);
+                    float sum = tap_first(W[ro + r][(c + 2) >> 1], (c + 2) & 1, V2a[c]);
                     tap(sum, wsum, r + 1, c + 1, r == 0 ? D1o[c] : D1m[c]);              // (-1, -1)
                     tap(sum, wsum, r + 1, c + 2, r == 0 ? V1o[c] : V1m[c]);              // (-1,  0)
                     tap(sum, wsum, r + 1, c + 3, r == 0 ? D2o[c] : D2m[c + 1]);          // (-1, +1)
@@ -600,7 +645,7 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
                     tap(sum, wsum, r + 4, c + 2, V2b[c]);                                // (+2,  0)
                     sums[r * 4 + c] = sum; wsums[r * 4 + c] = wsum;
                 }
-                if (r == 0) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             float z[8];
             // cvRound(sum / wsum): only the nearest integer is needed, so the quotient is first formed with the hardware reciprocal
@@ -647,8 +692,17 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
                 }
             }
         }
+#ifdef AEJ_X_BLUR_STAMPS
+        AEJ_BSTAMP(6)
+        st_acc[7] += 1;
+#endif
     }
     __syncthreads();
+#ifdef AEJ_X_BLUR_STAMPS
+    AEJ_BSTAMP(8)
+    if ((tid & 63) == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 10; i++) g_blur_stamps[blockIdx.x][tid >> 6][i] = st_acc[i];
+#endif
     if (tid < 256) {
         unsigned int c = 0;
 #pragma unroll
@@ -1382,7 +1436,7 @@ static int pick_strip(const Geom &g, int TW, int TH, int strip_max, long long wa
 void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
     const int strip = pick_strip(g, kBTW, kBTH, kBStripMax, 1024);       // 256 CUs x 2 resident workgroups x 2
-    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), 0, st, g, cb, strip);
+    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), AEJ_X_BLUR_DYNLDS, st, g, cb, strip);
 }
 
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
