@@ -927,6 +927,373 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
 }
 
 // ------------------------------------------------------------------------------------------------
+// 64 x 64, one WAVE per leaf: no barrier and no LDS hand-off inside the leaf loop.
+//
+// The four-wave kernel above spends 4 096 of ~16 000 cycles per leaf and SIMD in its MFMA chains: a float32 MFMA occupies the SIMD's
+// vector pipe, so the vector / LDS phases between the chains (P through LDS, quantise + scatter, copy-out) wait for the other waves'
+// MFMAs, and every one of them ends in a workgroup barrier that waits for the slowest wave.  Here a wave owns the whole leaf:
+//   * chain 1, P = X^T.D^T as four 32 x 32 tiles (wi = block of x, wj = block of u): A = X[2s + lh][32 wi + li] straight from global
+//     memory into 64 registers (two 128-byte row segments per load), B = D[32 wj + li][2s + lh] from an operand-ordered LDS table
+//     shared by the workgroup; the same operands in the same order as the four-wave kernel, so the sums are bit-identical;
+//   * the accumulators ARE chain 2's A operands after eight `v_permlane32_swap` per tile: accumulator register 4g + j of lane
+//     (li, lh) holds P[8g + j + 4 lh][li]; swapping the upper half of register 4g with the lower half of 4g + 1 leaves
+//     (x = 8g | x = 8g + 1) in the first and (8g + 4 | 8g + 5) in the second -- the A operand of steps 4g and 4g + 2 (likewise
+//     4g + 2 / 4g + 3 give steps 4g + 1 and 4g + 3);
+//   * chain 2, Y = T.D^T, tiles (iu, jv): A = the swapped P tiles (s / 16, iu), B = the same LDS operands;
+//   * X of the NEXT leaf is requested as soon as chain 1 has consumed the registers, and lands under chain 2 and the epilogue;
+//   * epilogue: quantisers and zigzag positions come from LDS tables transposed to [v][u] (a lane's four consecutive rows are one
+//     16- / 8-byte read); the first 1 024 zigzag positions go through a 4 KiB per-wave slab and leave as 16-byte stores; the other
+//     3 072 are zero in nearly every 64 x 64 leaf (a leaf that large has no edge in it) and are then written as zeros directly --
+//     a leaf with a non-zero coefficient up there takes the same slab path once per quarter.
+// Two waves per SIMD (<= 256 registers): while one is in its epilogue or waiting for memory the other's MFMAs have the pipe.
+// ------------------------------------------------------------------------------------------------
+#ifndef AEJ_X_W64_WAVES
+#define AEJ_X_W64_WAVES 8
+#endif
+constexpr int kW64Waves = AEJ_X_W64_WAVES;
+constexpr int kW64Stride = 68;          // elements per row of the transposed tables: 16-byte aligned rows, conflict-free 16-byte reads
+struct __attribute__((aligned(16))) Wave64Lds {
+    float dop[2][32][64];               // D operands: [wj][s][lane] = D[32 wj + li][2 s + lh]
+    float qT[3][64][kW64Stride];        // quantisers as floats, [layer][v][u]
+    unsigned short zT[64][kW64Stride];  // zigzag position of (u, v), [v][u]
+    float qlo[3][64][16];               // 0.499 x min of the four quantisers [v][4 g .. 4 g + 3]
+    float qlo16[3][64][4];              // ... of the sixteen rows a lane holds of tile row iu: [v][2 iu + lh]
+    int slab[kW64Waves][1024];
+    LayerTab lt;
+    int q_slow[4];
+};
+
+// four k-steps of the 2 x 2 tile product: acc[i][j] += A_i(:, 2s .. 2s+1) * B_j(2s .. 2s+1, :), B operands from the LDS table; the
+// operands of the NEXT four steps are requested first (scheduling barriers keep that order), so that every wait finds data that was
+// requested 16 MFMAs earlier and no more than eight operand registers are live
+struct Wave64B { float b[2][4]; };
+__device__ __forceinline__ Wave64B wave64_b(const Wave64Lds &L, int s0, int lane)
+{
+    Wave64B r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r.b[0][i] = L.dop[0][s0 + i][lane]; r.b[1][i] = L.dop[1][s0 + i][lane]; }
+    return r;
+}
+
+template <bool WANT_DCT>
+__global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom q, DctArgs a, long long max_items,
+                                                                 const int4 *__restrict__ work /* = a.work, read-only: scalar loads */)
+{
+    constexpr int S = 64;
+    __shared__ Wave64Lds L;
+    extern __shared__ int s_pref[];      // [nplanes + 1]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // (the wave index as a SCALAR: everything derived from it -- the
+                                                                                     // item, the leaf, its geometry -- then stays in scalar registers)
+    const int li = lane & 31, lh = lane >> 5;
+    for (int idx = tid; idx < 2 * 32 * 64; idx += kW64Waves * 64) {
+        const int wj = idx >> 11, s = (idx >> 6) & 31, ln = idx & 63;
+        L.dop[wj][s][ln] = a.D[(32 * wj + (ln & 31)) * S + 2 * s + (ln >> 5)];
+    }
+    if (tid < 4) L.q_slow[tid] = 0;
+    __syncthreads();
+    for (int l = 0; l < 3; l++) {
+        const int *qm = a.qm[l];
+        int qmax = 0;
+        for (int idx = tid; idx < S * S; idx += kW64Waves * 64) {
+            const int u = idx >> 6, v = idx & 63;
+            const int qi = qm ? qm[idx] : 1;
+            qmax = max(qmax, qi);
+            L.qT[l][v][u] = (float)qi;
+            if (l == 0) L.zT[v][u] = (unsigned short)zigzag_pos<S>(u, v);
+        }
+        if (qmax > (1 << 22)) L.q_slow[l] = 1;
+    }
+    __syncthreads();
+    // 0.499 x the smallest quantiser of each group of four consecutive rows: "all four coefficients quantise to 0" in one comparison
+    for (int idx = tid; idx < 3 * 64 * 16; idx += kW64Waves * 64) {
+        const int l = idx >> 10, v = (idx >> 4) & 63, u4 = idx & 15;
+        const float *qq = &L.qT[l][v][4 * u4];
+        L.qlo[l][v][u4] = 0.499f * __builtin_fminf(__builtin_fminf(qq[0], qq[1]), __builtin_fminf(qq[2], qq[3]));
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 3 * 64 * 4; idx += kW64Waves * 64) {
+        const int l = idx >> 8, v = (idx >> 2) & 63, k4 = idx & 3, iu = k4 >> 1, hh = k4 & 1;
+        float mn = L.qlo[l][v][8 * iu + hh];
+        for (int gq = 1; gq < 4; gq++) mn = __builtin_fminf(mn, L.qlo[l][v][8 * iu + 2 * gq + hh]);
+        L.qlo16[l][v][k4] = mn;
+    }
+    dct_prologue(g, q, a, s_pref, L.lt);       // ends with a barrier
+    // (scalar: a value loaded from LDS counts as divergent, and so would every branch on it; 32-bit, because a 64-bit comparison is a
+    // vector instruction whose result makes the branch -- and everything defined behind it -- divergent again)
+    int count = __builtin_amdgcn_readfirstlane(s_pref[a.nplanes]);
+    if ((long long)count > max_items) count = (int)max_items;
+    const long long wstride = q.work_stride[a.k];
+    const int step = (int)gridDim.x * kW64Waves;
+    int item = (int)blockIdx.x * kW64Waves + wave;
+    struct LeafU { int plane, x, y, coef; };
+    // A wave's items ascend, so the plane of an item is found by walking a running index up the per-plane prefix (usually zero or
+    // one step; the binary search of fetch_item costs ~60 vector instructions, and vector instructions outside the MFMA chains are
+    // what this kernel has to ration: while the other wave of the SIMD is in a chain they issue once per MFMA)
+    int pl = 0;
+    auto leaf_at = [&](int it) {
+        if (it >= count) return LeafU{ 0, 0, 0, 0 };
+        while (pl + 1 < a.nplanes && __builtin_amdgcn_readfirstlane(s_pref[pl + 1]) <= it) pl++;
+        pl = __builtin_amdgcn_readfirstlane(pl);        // (the LDS addresses above keep it in a vector register; what follows is scalar arithmetic)
+        const int b = pl / 3, l = pl - 3 * b;
+        const long long lw = L.lt.woff[l];        // (the LDS copy: indexing the kernel-argument array with a.k would be a dependent global load per leaf)
+        const long long woff = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(lw >> 32)) << 32) |
+                                           (unsigned)__builtin_amdgcn_readfirstlane((int)lw));
+        const long long idx = (long long)b * wstride + woff + (long long)(it - __builtin_amdgcn_readfirstlane(s_pref[pl]));
+        const int4 d = work[idx];          // a scalar load (counted by lgkmcnt): it does not wait for the vector loads and stores in flight
+        return LeafU{ __builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z),
+                      __builtin_amdgcn_readfirstlane(d.w) };
+    };
+    float xr[2][32];
+    // X of one leaf into the A-operand registers: xr[wi][s] = X[2 s + lh][32 wi + li], np.pad(reflect) applied to leaves clipped by the
+    // plane's border.  (The leaf and its geometry are scalar values -- see `wave` and `count` above -- so the branch between the two
+    // forms is a scalar branch, not a pair of masked regions.)
+    auto load_x = [&](const LeafU &d) {
+        const int b = d.plane / 3, layer = d.plane - 3 * b;
+        const int w = layer == 0 ? g.w[0] : layer == 1 ? g.w[1] : g.w[2];
+        const int h = layer == 0 ? g.h[0] : layer == 1 ? g.h[1] : g.h[2];
+        const long long poff = layer == 0 ? g.poff[0] : layer == 1 ? g.poff[1] : g.poff[2];
+        const float *src = a.norm + (long long)b * g.pstride + poff;
+        const int hc = min(S, h - d.y), wc = min(S, w - d.x);
+        typedef const char __attribute__((address_space(1))) *gbytes;          // (an integer cast to a plain pointer would give flat loads)
+        typedef const float __attribute__((address_space(1))) *gfloat;
+        unsigned long long base = (unsigned long long)(size_t)(src + (long long)d.y * w + d.x);
+        const unsigned rowb = (unsigned)w * 4u;
+        if (hc == S && wc == S) {
+            // the unclipped leaf: scalar row bases, one constant byte offset per lane -- two scalar and two memory instructions per step
+            const unsigned off = (lh ? rowb : 0u) + (unsigned)li * 4u;
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                // (readfirstlane pins the row base to scalar registers: without it the compiler adds the lane offset first and carries
+                // 32 64-bit vector addresses)
+                const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+                const gbytes rowp = (gbytes)(size_t)(((unsigned long long)bhi << 32) | blo);
+                xr[0][s] = *(gfloat)(rowp + off);
+                xr[1][s] = *(gfloat)(rowp + off + 128u);
+                base += 2ull * rowb;
+            }
+        } else {
+            // clipped by the plane's border (the last row / column of leaves of a plane): np.pad(reflect) row by row
+            const unsigned c0 = (unsigned)reflect_pad_idx(li, wc) * 4u, c1 = (unsigned)reflect_pad_idx(32 + li, wc) * 4u;
+            int r = 0, dir = hc > 1 ? 1 : 0;
+            auto advance = [&]() {
+                r += dir;
+                if (r == hc - 1 && dir > 0) dir = -1;
+                else if (r == 0 && dir < 0) dir = 1;
+            };
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                const int r0 = r;
+                advance();
+                const int r1 = r;
+                advance();
+                const unsigned lr = (unsigned)(lh ? r1 : r0) * rowb;
+                const gbytes leafp = (gbytes)(size_t)base;
+                xr[0][s] = *(gfloat)(leafp + (lr + c0));
+                xr[1][s] = *(gfloat)(leafp + (lr + c1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if (item >= count) return;
+    LeafU cur = leaf_at(item);
+    load_x(cur);
+    int *slab = L.slab[wave];
+#ifdef AEJ_X_STAMPS
+    long long st_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (; item < count; item += step) {
+        const LeafU nxt = leaf_at(item + step);
+        AEJ_STAMP(0)
+#ifdef AEJ_X_STAMPS
+        st_acc[6] += 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AEJ_STAMP(2)
+#endif
+        const int b = cur.plane / 3, layer = cur.plane - 3 * b;
+        const long long coff = layer == 0 ? q.coeff_off[0] : layer == 1 ? q.coeff_off[1] : q.coeff_off[2];
+        const long long out_base = (long long)b * q.coeff_stride + coff + cur.coef;
+#ifdef AEJ_X_W64_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        // ---- chain 1: P tiles [wi][wj]
+        floatx16 P[2][2];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) P[t >> 1][t & 1][r] = 0.f;
+        {
+            Wave64B bc = wave64_b(L, 0, lane), bn = bc;
+#pragma unroll
+            for (int s0 = 0; s0 < 32; s0 += 4) {
+                if (s0 + 4 < 32) bn = wave64_b(L, s0 + 4, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    P[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0][s0 + i], bc.b[0][i], P[0][0], 0, 0, 0);
+                    P[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0][s0 + i], bc.b[1][i], P[0][1], 0, 0, 0);
+                    P[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[1][s0 + i], bc.b[0][i], P[1][0], 0, 0, 0);
+                    P[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[1][s0 + i], bc.b[1][i], P[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bc = bn;
+            }
+        }
+        AEJ_STAMP(3)
+        // the registers of X are free: the next leaf's pixels fly while this one is finished
+        if (item + step < count) load_x(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        AEJ_STAMP(1)
+        // ---- accumulators -> A operands of chain 2: PA[wi][wj][s & 15]
+        float PA[2][2][16];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const auto e = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[t >> 1][t & 1][4 * gq]), __float_as_uint(P[t >> 1][t & 1][4 * gq + 1]), false, false);
+                const auto o = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[t >> 1][t & 1][4 * gq + 2]), __float_as_uint(P[t >> 1][t & 1][4 * gq + 3]), false, false);
+                PA[t >> 1][t & 1][4 * gq + 0] = __uint_as_float(e[0]);
+                PA[t >> 1][t & 1][4 * gq + 2] = __uint_as_float(e[1]);
+                PA[t >> 1][t & 1][4 * gq + 1] = __uint_as_float(o[0]);
+                PA[t >> 1][t & 1][4 * gq + 3] = __uint_as_float(o[1]);
+            }
+        // ---- chain 2: Y tiles [iu][jv]
+        floatx16 Y[2][2];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) Y[t >> 1][t & 1][r] = 0.f;
+        {
+            Wave64B bc = wave64_b(L, 0, lane), bn = bc;
+#pragma unroll
+            for (int s0 = 0; s0 < 32; s0 += 4) {
+                if (s0 + 4 < 32) bn = wave64_b(L, s0 + 4, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int s = s0 + i;
+                    const float a0 = PA[s >> 4][0][s & 15], a1 = PA[s >> 4][1][s & 15];
+                    Y[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bc.b[0][i], Y[0][0], 0, 0, 0);
+                    Y[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bc.b[1][i], Y[0][1], 0, 0, 0);
+                    Y[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bc.b[0][i], Y[1][0], 0, 0, 0);
+                    Y[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bc.b[1][i], Y[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bc = bn;
+            }
+        }
+        AEJ_STAMP(4)
+        // ---- epilogue.  Accumulator register 4 gq + j of tile (iu, jv): u = 32 iu + 8 gq + 4 lh + j, v = 32 jv + li.
+        // A group (tile, gq) whose smallest diagonal 32 iu + 32 jv + 8 gq is 45 or more lies entirely beyond zigzag position 1 024.
+#ifdef AEJ_X_W64_PRIO
+        __builtin_amdgcn_s_setprio(AEJ_X_W64_PRIO);
+#endif
+        const float (*qT)[kW64Stride] = L.qT[layer];
+        const float (*qlo)[16] = L.qlo[layer];
+        // One vote per group of four rows: "every lane's four coefficients quantise to 0" (|y| < 0.499 x the smallest of the four
+        // quantisers: the float32 rounding of the product has orders of magnitude of margin).  True for all but a few groups of a
+        // leaf this large; the first quarter of the output is zeroed up front and only non-zero values are written into it.
+        bool redo = L.q_slow[layer] != 0;   // wave-uniform: some value needs the float64 quantiser (never with the codec's own tables and image-range input)
+        bool upper = false;                 // wave-uniform: a non-zero coefficient at zigzag position >= 1 024
+#pragma unroll
+        for (int c = 0; c < 4; c++) reinterpret_cast<int4 *>(slab)[c * 64 + lane] = make_int4(0, 0, 0, 0);
+        int hi_lane = 0;                    // per lane: a non-zero value beyond position 1 024, or one outside the float32 quantiser's range
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int iu = t >> 1, jv = t & 1;
+            const int v = 32 * jv + li;
+            if (WANT_DCT) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) a.dct_f32[out_base + (32 * iu + 8 * (r >> 2) + 4 * lh + (r & 3)) * S + v] = Y[iu][jv][r];
+            }
+            // the whole tile first: one vote instead of four for the three tiles that hold nothing but zeros
+            float m16 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) m16 = __builtin_fmaxf(__builtin_fmaxf(m16, __builtin_fabsf(Y[iu][jv][r])), __builtin_fabsf(Y[iu][jv][r + 1]));
+            if (__all(m16 < L.qlo16[layer][v][2 * iu + lh])) continue;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int u0 = 32 * iu + 8 * gq + 4 * lh;
+                const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Y[iu][jv][4 * gq]), __builtin_fabsf(Y[iu][jv][4 * gq + 1])),
+                                                __builtin_fmaxf(__builtin_fabsf(Y[iu][jv][4 * gq + 2]), __builtin_fabsf(Y[iu][jv][4 * gq + 3])));
+                if (!__all(m < qlo[v][u0 >> 2])) {
+                    if (32 * iu + 32 * jv + 8 * gq >= 45) {        // the whole group lies beyond position 1 024 (smallest diagonal >= 45)
+                        upper = true;
+                    } else {
+                        const float4 q4 = *reinterpret_cast<const float4 *>(&qT[v][u0]);
+                        const uint2 z2 = *reinterpret_cast<const uint2 *>(&L.zT[v][u0]);
+                        const float qq[4] = { q4.x, q4.y, q4.z, q4.w };
+                        const int zz[4] = { (int)(z2.x & 0xffffu), (int)(z2.x >> 16), (int)(z2.y & 0xffffu), (int)(z2.y >> 16) };
+                        hi_lane |= !(m < 131072.0f);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int val = quantise_f32(Y[iu][jv][4 * gq + j], qq[j]);
+                            if (val != 0) {
+                                if (zz[j] < 1024) slab[zz[j]] = val;
+                                else hi_lane |= 2;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (__any(hi_lane & 1)) redo = true;
+        if (__any(hi_lane & 2)) upper = true;
+        // (LDS operations of one wave execute in order: the reads below see this wave's writes, the next writes come after them)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            reinterpret_cast<int4 *>(a.coeffs + out_base)[c * 64 + lane] = reinterpret_cast<const int4 *>(slab)[c * 64 + lane];
+        if (!upper && !redo) {
+#pragma unroll
+            for (int c = 0; c < 12; c++) reinterpret_cast<int4 *>(a.coeffs + out_base + 1024)[c * 64 + lane] = make_int4(0, 0, 0, 0);
+        } else {
+            // rare: every coefficient beyond position 1 024 (every coefficient, if the float64 quantiser is needed) straight to its place.
+            // A tile at a time through the slab, so that the loop over its registers need not be unrolled.
+            if (redo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores above have landed before other lanes overwrite them
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int iu = t >> 1, jv = t & 1;
+#pragma unroll
+                for (int r = 0; r < 16; r++) reinterpret_cast<float *>(slab)[r * 64 + lane] = Y[iu][jv][r];
+#pragma unroll 1
+                for (int r = 0; r < 16; r++) {
+                    const float y = reinterpret_cast<const float *>(slab)[r * 64 + lane];
+                    const int u = 32 * iu + 8 * (r >> 2) + 4 * lh + (r & 3), v = 32 * jv + li;
+                    const float qq = qT[v][u];
+                    const int zz = L.zT[v][u];
+                    const bool slow = redo && (L.q_slow[layer] != 0 || __any(!(__builtin_fabsf(y) < 131072.0f)));
+                    const int val = slow ? quantise_f64(y, (int)qq) : quantise_f32(y, qq);
+                    if (redo || zz >= 1024) a.coeffs[out_base + zz] = val;
+                }
+            }
+        }
+        AEJ_STAMP(5)
+        cur = nxt;
+    }
+#ifdef AEJ_X_STAMPS
+    if (lane == 0 && blockIdx.x * kW64Waves + wave < 512)
+        for (int i = 0; i < 12; i++) g_stamps[1][blockIdx.x * kW64Waves + wave][i] = st_acc[i];
+#endif
+}
+
+template <bool WANT_DCT>
+static void launch_dct64_wave(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
+{
+    const size_t pref = (size_t)(a.nplanes + 1) * sizeof(int);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const long long want = (max_items + kW64Waves - 1) / kW64Waves;
+    const int blocks = (int)(want < 1 ? 1 : want > cus ? cus : want);
+    hipLaunchKernelGGL((k_dct64_wave<WANT_DCT>), dim3(blocks), dim3(kW64Waves * 64), pref, st, g, q, a, max_items,
+                       reinterpret_cast<const int4 *>(a.work));
+}
+
+// ------------------------------------------------------------------------------------------------
 // stand-alone entry: leaf table -> per-size work lists
 // ------------------------------------------------------------------------------------------------
 struct WorkPtrs { LeafWork *w[kMaxSizes]; };
@@ -1012,7 +1379,12 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
         else hipLaunchKernelGGL((k_dct16_mfma<false>), dim3(cap(4, 2048)), dim3(256), pref, st, g, q, a, max_items);
         break;
     case 32: AEJ_MFMA(32); break;
-    case 64: AEJ_MFMA(64); break;
+    case 64: {
+        static const bool four_waves = getenv("AEJ_DCT64_FOUR_WAVES") != nullptr;     // the previous kernel (one workgroup of four waves per leaf), for comparisons
+        if (four_waves || wd) { AEJ_MFMA(64); }       // (the float32 DCT output, a debugging aid, stays with the four-wave kernel)
+        else launch_dct64_wave<false>(st, g, q, a, max_items);
+        break;
+    }
     case 128: AEJ_MFMA(128); break;
 #define AEJ_BIG(S)                                                                                                               \
     if (!a.scratch) return -1;   /* callers reserve it whenever the settings allow this size */                                 \
