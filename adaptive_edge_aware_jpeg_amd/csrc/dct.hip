@@ -935,10 +935,10 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
 //   * chain 1, P = X^T.D^T as four 32 x 32 tiles (wi = block of x, wj = block of u): A = X[2s + lh][32 wi + li] straight from global
 //     memory into 64 registers (two 128-byte row segments per load), B = D[32 wj + li][2s + lh] from an operand-ordered LDS table
 //     shared by the workgroup; the same operands in the same order as the four-wave kernel, so the sums are bit-identical;
-//   * the accumulators ARE chain 2's A operands after eight `v_permlane32_swap` per tile: accumulator register 4g + j of lane
-//     (li, lh) holds P[8g + j + 4 lh][li]; swapping the upper half of register 4g with the lower half of 4g + 1 leaves
-//     (x = 8g | x = 8g + 1) in the first and (8g + 4 | 8g + 5) in the second -- the A operand of steps 4g and 4g + 2 (likewise
-//     4g + 2 / 4g + 3 give steps 4g + 1 and 4g + 3);
+//   * the accumulators ARE chain 2's A operands: the MFMA leaves output row 8g + 4 lh + j in register 4g + j of lane half lh, so the
+//     lanes of chain 1's A operand carry the columns of X in the order 8g + 2j + h (for lane 8g + 4h + j) -- register r of a P tile
+//     then holds x = 2r + lh, exactly what step r of chain 2 reads (the first version moved the data with eight
+//     `v_permlane32_swap` per tile: 32 vector instructions per leaf that each waited for an MFMA of the other wave);
 //   * chain 2, Y = T.D^T, tiles (iu, jv): A = the swapped P tiles (s / 16, iu), B = the same LDS operands;
 //   * X of the NEXT leaf is requested as soon as chain 1 has consumed the registers, and lands under chain 2 and the epilogue;
 //   * epilogue: quantisers and zigzag positions come from LDS tables transposed to [v][u] (a lane's four consecutive rows are one
@@ -982,27 +982,48 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
     constexpr int S = 64;
     __shared__ Wave64Lds L;
     extern __shared__ int s_pref[];      // [nplanes + 1]
+#ifdef AEJ_X_STAMPS
+    const long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // (the wave index as a SCALAR: everything derived from it -- the
                                                                                      // item, the leaf, its geometry -- then stays in scalar registers)
     const int li = lane & 31, lh = lane >> 5;
-    for (int idx = tid; idx < 2 * 32 * 64; idx += kW64Waves * 64) {
-        const int wj = idx >> 11, s = (idx >> 6) & 31, ln = idx & 63;
-        L.dop[wj][s][ln] = a.D[(32 * wj + (ln & 31)) * S + 2 * s + (ln >> 5)];
-    }
-    if (tid < 4) L.q_slow[tid] = 0;
-    __syncthreads();
-    for (int l = 0; l < 3; l++) {
-        const int *qm = a.qm[l];
-        int qmax = 0;
-        for (int idx = tid; idx < S * S; idx += kW64Waves * 64) {
-            const int u = idx >> 6, v = idx & 63;
-            const int qi = qm ? qm[idx] : 1;
-            qmax = max(qmax, qi);
-            L.qT[l][v][u] = (float)qi;
-            if (l == 0) L.zT[v][u] = (unsigned short)zigzag_pos<S>(u, v);
+    // tables (once per workgroup; the loops are unrolled so that their global loads are in flight together: left as loops, hipcc issues
+    // one load per iteration and waits for it -- two dozen serialised L2 round trips, a leaf and a half of time)
+    {
+        constexpr int NT = kW64Waves * 64;
+        static_assert((2 * 32 * 64) % NT == 0 && (S * S) % NT == 0, "table loops assume whole rounds");
+        float dv[2 * 32 * 64 / NT];
+#pragma unroll
+        for (int i = 0; i < 2 * 32 * 64 / NT; i++) {          // coalesced: consecutive threads read consecutive k of one row of D
+            const int idx = tid + i * NT, row = idx >> 6, kk = idx & 63;
+            dv[i] = a.D[row * S + kk];
         }
-        if (qmax > (1 << 22)) L.q_slow[l] = 1;
+        int qv[3][S * S / NT];
+#pragma unroll
+        for (int l = 0; l < 3; l++)
+#pragma unroll
+            for (int i = 0; i < S * S / NT; i++) qv[l][i] = a.qm[l] ? a.qm[l][tid + i * NT] : 1;
+#pragma unroll
+        for (int i = 0; i < 2 * 32 * 64 / NT; i++) {
+            const int idx = tid + i * NT, row = idx >> 6, kk = idx & 63;
+            L.dop[row >> 5][kk >> 1][(kk & 1) * 32 + (row & 31)] = dv[i];          // [wj][s][lane] = D[32 wj + li][2 s + lh]
+        }
+        if (tid < 4) L.q_slow[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            int qmax = 0;
+#pragma unroll
+            for (int i = 0; i < S * S / NT; i++) {
+                const int idx = tid + i * NT, u = idx >> 6, v = idx & 63;
+                qmax = max(qmax, qv[l][i]);
+                L.qT[l][v][u] = (float)qv[l][i];
+                if (l == 0) L.zT[v][u] = (unsigned short)zigzag_pos<S>(u, v);
+            }
+            if (qmax > (1 << 22)) L.q_slow[l] = 1;
+        }
     }
     __syncthreads();
     // 0.499 x the smallest quantiser of each group of four consecutive rows: "all four coefficients quantise to 0" in one comparison
@@ -1045,6 +1066,11 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
                       __builtin_amdgcn_readfirstlane(d.w) };
     };
     float xr[2][32];
+    // Lane li of an A operand carries column pli, a permutation inside each group of eight (8 g + 4 h + j -> 8 g + 2 j + h): the MFMA
+    // puts row m = 8 g + 4 lh + j of its output into accumulator register 4 g + j of half lh, so with this order register r of a P tile
+    // holds x = 2 r + lh -- it IS chain 2's A operand of step r, no data movement in between.  (The sums do not change: a lane's
+    // column only decides which output row the same chain of products lands in.)
+    const int pli = (li & 24) | ((li & 3) << 1) | ((li >> 2) & 1);
     // X of one leaf into the A-operand registers: xr[wi][s] = X[2 s + lh][32 wi + li], np.pad(reflect) applied to leaves clipped by the
     // plane's border.  (The leaf and its geometry are scalar values -- see `wave` and `count` above -- so the branch between the two
     // forms is a scalar branch, not a pair of masked regions.)
@@ -1061,7 +1087,7 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
         const unsigned rowb = (unsigned)w * 4u;
         if (hc == S && wc == S) {
             // the unclipped leaf: scalar row bases, one constant byte offset per lane -- two scalar and two memory instructions per step
-            const unsigned off = (lh ? rowb : 0u) + (unsigned)li * 4u;
+            const unsigned off = (lh ? rowb : 0u) + (unsigned)pli * 4u;
 #pragma unroll
             for (int s = 0; s < 32; s++) {
                 // (readfirstlane pins the row base to scalar registers: without it the compiler adds the lane offset first and carries
@@ -1074,7 +1100,7 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
             }
         } else {
             // clipped by the plane's border (the last row / column of leaves of a plane): np.pad(reflect) row by row
-            const unsigned c0 = (unsigned)reflect_pad_idx(li, wc) * 4u, c1 = (unsigned)reflect_pad_idx(32 + li, wc) * 4u;
+            const unsigned c0 = (unsigned)reflect_pad_idx(pli, wc) * 4u, c1 = (unsigned)reflect_pad_idx(32 + pli, wc) * 4u;
             int r = 0, dir = hc > 1 ? 1 : 0;
             auto advance = [&]() {
                 r += dir;
@@ -1101,6 +1127,7 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
     int *slab = L.slab[wave];
 #ifdef AEJ_X_STAMPS
     long long st_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = __builtin_amdgcn_s_memtime();
+    st_acc[7] = st_last - st_t0;        // table set-up
 #endif
     for (; item < count; item += step) {
         const LeafU nxt = leaf_at(item + step);
@@ -1144,19 +1171,7 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
         if (item + step < count) load_x(nxt);
         __builtin_amdgcn_sched_barrier(0);
         AEJ_STAMP(1)
-        // ---- accumulators -> A operands of chain 2: PA[wi][wj][s & 15]
-        float PA[2][2][16];
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                const auto e = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[t >> 1][t & 1][4 * gq]), __float_as_uint(P[t >> 1][t & 1][4 * gq + 1]), false, false);
-                const auto o = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[t >> 1][t & 1][4 * gq + 2]), __float_as_uint(P[t >> 1][t & 1][4 * gq + 3]), false, false);
-                PA[t >> 1][t & 1][4 * gq + 0] = __uint_as_float(e[0]);
-                PA[t >> 1][t & 1][4 * gq + 2] = __uint_as_float(e[1]);
-                PA[t >> 1][t & 1][4 * gq + 1] = __uint_as_float(o[0]);
-                PA[t >> 1][t & 1][4 * gq + 3] = __uint_as_float(o[1]);
-            }
+        // (P[wi][wj][r] is chain 2's A operand of step 16 wi + r: see pli)
         // ---- chain 2: Y tiles [iu][jv]
         floatx16 Y[2][2];
 #pragma unroll
@@ -1172,7 +1187,7 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int s = s0 + i;
-                    const float a0 = PA[s >> 4][0][s & 15], a1 = PA[s >> 4][1][s & 15];
+                    const float a0 = P[s >> 4][0][s & 15], a1 = P[s >> 4][1][s & 15];
                     Y[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bc.b[0][i], Y[0][0], 0, 0, 0);
                     Y[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bc.b[1][i], Y[0][1], 0, 0, 0);
                     Y[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bc.b[0][i], Y[1][0], 0, 0, 0);
@@ -1198,44 +1213,68 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
 #pragma unroll
         for (int c = 0; c < 4; c++) reinterpret_cast<int4 *>(slab)[c * 64 + lane] = make_int4(0, 0, 0, 0);
         int hi_lane = 0;                    // per lane: a non-zero value beyond position 1 024, or one outside the float32 quantiser's range
+        if (WANT_DCT) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int iu = t >> 1, jv = t & 1;
-            const int v = 32 * jv + li;
-            if (WANT_DCT) {
+            for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) a.dct_f32[out_base + (32 * iu + 8 * (r >> 2) + 4 * lh + (r & 3)) * S + v] = Y[iu][jv][r];
-            }
-            // the whole tile first: one vote instead of four for the three tiles that hold nothing but zeros
+                for (int r = 0; r < 16; r++)
+                    a.dct_f32[out_base + (32 * (t >> 1) + 8 * (r >> 2) + 4 * lh + (r & 3)) * S + 32 * (t & 1) + li] = Y[t >> 1][t & 1][r];
+        }
+        // (every vote is a round trip vector -> scalar -> branch that the other wave's MFMAs stretch to hundreds of cycles: as few as possible)
+        auto tile_max = [&](int iu, int jv) {
             float m16 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) m16 = __builtin_fmaxf(__builtin_fmaxf(m16, __builtin_fabsf(Y[iu][jv][r])), __builtin_fabsf(Y[iu][jv][r + 1]));
-            if (__all(m16 < L.qlo16[layer][v][2 * iu + lh])) continue;
+            return m16;
+        };
+        auto group_max = [&](int iu, int jv, int gq) {
+            return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Y[iu][jv][4 * gq]), __builtin_fabsf(Y[iu][jv][4 * gq + 1])),
+                                   __builtin_fmaxf(__builtin_fabsf(Y[iu][jv][4 * gq + 2]), __builtin_fabsf(Y[iu][jv][4 * gq + 3])));
+        };
+        auto quantise_group = [&](int iu, int jv, int gq, float m) {          // a group with a coefficient that does not quantise to 0
+            const int u0 = 32 * iu + 8 * gq + 4 * lh, v = 32 * jv + li;
+            if (32 * iu + 32 * jv + 8 * gq >= 45) {        // the whole group lies beyond position 1 024 (smallest diagonal >= 45)
+                upper = true;
+                return;
+            }
+            const float4 q4 = *reinterpret_cast<const float4 *>(&qT[v][u0]);
+            const uint2 z2 = *reinterpret_cast<const uint2 *>(&L.zT[v][u0]);
+            const float qq[4] = { q4.x, q4.y, q4.z, q4.w };
+            const int zz[4] = { (int)(z2.x & 0xffffu), (int)(z2.x >> 16), (int)(z2.y & 0xffffu), (int)(z2.y >> 16) };
+            hi_lane |= !(m < 131072.0f);
 #pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                const int u0 = 32 * iu + 8 * gq + 4 * lh;
-                const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Y[iu][jv][4 * gq]), __builtin_fabsf(Y[iu][jv][4 * gq + 1])),
-                                                __builtin_fmaxf(__builtin_fabsf(Y[iu][jv][4 * gq + 2]), __builtin_fabsf(Y[iu][jv][4 * gq + 3])));
-                if (!__all(m < qlo[v][u0 >> 2])) {
-                    if (32 * iu + 32 * jv + 8 * gq >= 45) {        // the whole group lies beyond position 1 024 (smallest diagonal >= 45)
-                        upper = true;
-                    } else {
-                        const float4 q4 = *reinterpret_cast<const float4 *>(&qT[v][u0]);
-                        const uint2 z2 = *reinterpret_cast<const uint2 *>(&L.zT[v][u0]);
-                        const float qq[4] = { q4.x, q4.y, q4.z, q4.w };
-                        const int zz[4] = { (int)(z2.x & 0xffffu), (int)(z2.x >> 16), (int)(z2.y & 0xffffu), (int)(z2.y >> 16) };
-                        hi_lane |= !(m < 131072.0f);
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int val = quantise_f32(Y[iu][jv][4 * gq + j], qq[j]);
-                            if (val != 0) {
-                                if (zz[j] < 1024) slab[zz[j]] = val;
-                                else hi_lane |= 2;
-                            }
-                        }
-                    }
+            for (int j = 0; j < 4; j++) {
+                const int val = quantise_f32(Y[iu][jv][4 * gq + j], qq[j]);
+                if (val != 0) {
+                    if (zz[j] < 1024) slab[zz[j]] = val;
+                    else hi_lane |= 2;
                 }
+            }
+        };
+        auto groups_of = [&](int iu, int jv, int first) {                     // the groups of a tile, one vote each
+#pragma unroll
+            for (int gq = first; gq < 4; gq++) {
+                const float m = group_max(iu, jv, gq);
+                if (!__all(m < qlo[32 * jv + li][(32 * iu + 8 * gq + 4 * lh) >> 2])) quantise_group(iu, jv, gq, m);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // tile (0, 0): its first group holds the DC coefficient -- no vote; its other three groups share one
+        quantise_group(0, 0, 0, group_max(0, 0, 0));
+        {
+            bool zero = true;
+#pragma unroll
+            for (int gq = 1; gq < 4; gq++) zero = zero && group_max(0, 0, gq) < qlo[li][(8 * gq + 4 * lh) >> 2];
+            if (!__all(zero)) groups_of(0, 0, 1);
+        }
+        // the other three tiles share one vote
+        {
+            const bool zero = tile_max(0, 1) < L.qlo16[layer][32 + li][lh] && tile_max(1, 0) < L.qlo16[layer][li][2 + lh] &&
+                              tile_max(1, 1) < L.qlo16[layer][32 + li][2 + lh];
+            if (!__all(zero)) {
+#pragma unroll
+                for (int t = 1; t < 4; t++)
+                    if (!__all(tile_max(t >> 1, t & 1) < L.qlo16[layer][32 * (t & 1) + li][2 * (t >> 1) + lh])) groups_of(t >> 1, t & 1, 0);
             }
         }
         if (__any(hi_lane & 1)) redo = true;

@@ -27,3 +27,4 @@ for i in range(6):
     tot += v
     print(f"   {names[i]:40s} {v:9.0f}")
 print(f"   {'total':40s} {tot:9.0f}   (256 MFMAs = 16384 pipe cycles)")
+print(f"   table set-up before the first leaf: {d[:, 7].mean():.0f} cycles per wave ({d[:, 7].mean() / (tot * n / len(d)) * 100:.1f} % of the wave's leaf time in this run)")
