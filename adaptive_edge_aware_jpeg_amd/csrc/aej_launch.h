@@ -93,6 +93,7 @@ struct DctArgs {
     const float *D;           // [s][s]
     const int *zzinv;         // [s*s]
     const int *qm[3];         // [s*s] per layer
+    int crowded = 0;          // other kernels are expected beside this launch (sub-batches, calls in flight): prefer kernels that share a CU
 };
 int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items);   // 0, or -1 when no kernel serves the request
 // builds a work list from a leaf table (stand-alone aej_dct_quant_zigzag)

@@ -61,6 +61,7 @@ struct aej_ctx {
     int hw_queues = 4;                 // hardware queues the runtime maps streams onto, as the host states it (aej_set_hw_queues; HIP's default 4): streams beyond it share queues
     int fail_after = -1;               // aej_test_fail_after_stage (test instrumentation)
     static constexpr int kMaxSub = 8;
+    int dct_crowded = 0;               // this call runs as sub-batches or beside other calls: DCT kernels that share CUs (aej_launch.h DctArgs::crowded)
     hipStream_t sub_stream[kMaxSub] = {};
     hipEvent_t sub_color_done[kMaxSub] = {}, sub_in = nullptr;
     int *sub_flag[kMaxSub] = {};       // pinned read-back words per sub-batch (layout of h_flag)
@@ -830,6 +831,7 @@ static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &
         a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
         a.scratch = w.big;
         a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
+        a.crowded = ctx->dct_crowded;
         for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
         if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k])) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
         mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
@@ -988,9 +990,9 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
 // smaller calls have too few workgroups per kernel to share the chip).  Never for profiled calls (the
 // stage timings describe the serial chain), graph replay, the verified (host-synchronising) hysteresis loop, or shapes that need the
 // host-built INTER_AREA tables.
-static int sub_batches(const aej_ctx *ctx, const Geom &g, int hw_queues)
+static int sub_batches(const aej_ctx *ctx, const Geom &g, int hw_queues, bool as_if_unprofiled = false)
 {
-    if (ctx->sub_mode == 1 || ctx->profiling || ctx->graph_mode == 2 || !planes_fast_ok(g) || !ctx->hyst_speculate) return 1;
+    if (ctx->sub_mode == 1 || (ctx->profiling && !as_if_unprofiled) || ctx->graph_mode == 2 || !planes_fast_ok(g) || !ctx->hyst_speculate) return 1;
     int n = ctx->sub_mode;
     if (n == 0) {
         const long long px = (long long)g.B * g.H * g.W;
@@ -1109,6 +1111,12 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     ctx->n_ev = 0;
     ctx->n_encode_calls++;
     const int nsub = sub_batches(ctx, g, ctx->hw_queues);
+    {
+        std::lock_guard<std::mutex> lock(g_chain_mutex);
+        ctx->dct_crowded = nsub > 1 || (ctx->device < 64 && g_calls_in_flight[ctx->device] > 0);
+    }
+    // (a profiled call runs unsplit so that its stage times describe the serial chain, but with the kernels the same call uses unprofiled)
+    if (ctx->profiling && sub_batches(ctx, g, ctx->hw_queues, true) > 1) ctx->dct_crowded = 1;
     pd.parts.assign((size_t)nsub, EncodePart());
     pd.complete = false;
     hipStream_t user = ctx->stream;

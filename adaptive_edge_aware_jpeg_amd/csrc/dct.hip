@@ -1419,8 +1419,12 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
         break;
     case 32: AEJ_MFMA(32); break;
     case 64: {
-        static const bool four_waves = getenv("AEJ_DCT64_FOUR_WAVES") != nullptr;     // the previous kernel (one workgroup of four waves per leaf), for comparisons
-        if (four_waves || wd) { AEJ_MFMA(64); }       // (the float32 DCT output, a debugging aid, stays with the four-wave kernel)
+        // Two kernels.  One wave per leaf (k_dct64_wave) is the faster one on an otherwise idle device (0.79 against 0.86 ms for 64 x 4K), but
+        // its workgroups take a whole CU each (122 KiB LDS, 2 x 242 registers per SIMD lane): beside the kernels of other sub-batches it
+        // waits for CUs to drain and then shares them with nobody -- the pipelined 64 x 4K step is 6.70 ms with it and 6.45 ms with the
+        // four-wave kernel, whose workgroups are a third of a CU.  So the caller says whether the launch will have company.
+        static const bool force_four = getenv("AEJ_DCT64_FOUR_WAVES") != nullptr, force_wave = getenv("AEJ_DCT64_ONE_WAVE") != nullptr;
+        if (wd || force_four || (a.crowded && !force_wave)) { AEJ_MFMA(64); }       // (the float32 DCT output, a debugging aid, stays with the four-wave kernel)
         else launch_dct64_wave<false>(st, g, q, a, max_items);
         break;
     }
