@@ -19,7 +19,7 @@ assert lib.aej_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 d = buf[1]
 d = d[d[:, 6] > 0]
 n = d[:, 6].sum()
-names = {0: "descriptor (binary search + load)", 1: "issue the loads of X", 2: "wait for X", 3: "chain 1 (128 MFMAs)", 4: "swaps + chain 2 (128 MFMAs)", 5: "epilogue"}
+names = {0: "descriptor (+ in this build: the wait for X)", 1: "issue the loads of X", 2: "drain of the vector memory queue", 3: "chain 1 (128 MFMAs)", 4: "chain 2 (128 MFMAs)", 5: "epilogue"}
 print(f"k_dct64_wave: {len(d)} waves sampled, {n / len(d):.1f} leaves each; cycles per leaf (s_memtime ticks):")
 tot = 0
 for i in range(6):
