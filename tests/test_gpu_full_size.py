@@ -513,3 +513,34 @@ def test_schedule_report_follows_the_stated_hardware_queues(env):
         assert ctx.schedule(1, 1080, 1920)["sub_batches"] == 1
     finally:
         ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, n))
+
+
+def test_both_64x64_dct_kernels_agree():
+    """launch_dct picks the one-wave 64 x 64 kernel for calls that have the device to themselves and the four-wave kernel for sub-batched /
+    pipelined ones (DctArgs::crowded).  The choice is read once per process, so each kernel is forced in a process of its own
+    (AEJ_DCT64_ONE_WAVE / AEJ_DCT64_FOUR_WAVES) on an image whose plane heights clip the last row of 64 x 64 leaves: same bytes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import hashlib, torch, bench, adaptive_edge_aware_jpeg_amd as A\n"
+            "x = bench.synth_batch(torch, 2, 1000, 1480, 7, torch.device('cuda', 0))\n"
+            "enc = A.Jpeg(A.JpegCompressionSettings('YCbCr', (40, 80), (4, 64))).compress_batch(x)\n"
+            "h = hashlib.sha256()\n"
+            "n64 = 0\n"
+            "for b in range(2):\n"
+            "    for l in range(3):\n"
+            "        d = enc.layer(b, l)\n"
+            "        h.update(d['coeffs'].tobytes()); h.update(d['leaves'].tobytes())\n"
+            "        n64 += int((d['leaves'][:, 2] == 64).sum())\n"
+            "print('RESULT', h.hexdigest(), n64)\n")
+    out = {}
+    for knob in ("AEJ_DCT64_ONE_WAVE", "AEJ_DCT64_FOUR_WAVES"):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env[knob] = "1"
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        out[knob] = line[0].split()[1:]
+    assert out["AEJ_DCT64_ONE_WAVE"] == out["AEJ_DCT64_FOUR_WAVES"]
+    assert int(out["AEJ_DCT64_ONE_WAVE"][1]) > 50, "the image must contain 64 x 64 leaves"
