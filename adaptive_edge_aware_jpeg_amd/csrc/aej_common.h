@@ -20,6 +20,7 @@ struct Geom {
     int rh[3], rw[3]; // down-sampling ratios (jpeg.py:62-147)
     long long poff[3];   // element offset of layer l inside one image's plane storage
     long long pstride;   // plane elements per image = sum h*w
+    int tiled;           // the normalised float32 planes (what the DCT kernels read) are stored in 4 x 4 blocks, see plane_elem(); 0 = row-major
     // CLAHE tile geometry per layer (clahe.cpp): padded size / 4
     int ctw[3], cth[3];
     // edge bit-planes (weak / strong): one 64-bit word per 64 pixels of a row, stored TILE-MAJOR: the 64 row-words of a
@@ -73,6 +74,15 @@ struct DctTables {
     const int *zzinv[kMaxSizes];      // [s*s] zigzag position of raster index
     const int *qm[3][kMaxSizes];      // [s*s] quantisation matrix per layer
 };
+
+// Element index of (y, x) in a plane of width w.  Row-major, or -- Geom::tiled, only for planes whose sides are multiples of 4 -- in 4 x 4
+// blocks: blocks row-major, the four rows of a block consecutive.  A quadtree leaf of any size is then a few contiguous runs (4 x 4: one
+// 64-byte sector; 8 x 8: two 128-byte lines; 64 x 64: sixteen 1 KiB runs) instead of one short piece per row of lines it shares with leaves
+// of other sizes: the small-block DCT kernels read 2.5 x their pixels from row-major planes.
+__host__ __device__ inline long long plane_elem(int tiled, int w, int y, int x)
+{
+    return tiled ? ((long long)(y >> 2) * (w >> 2) + (x >> 2)) * 16 + ((y & 3) << 2) + (x & 3) : (long long)y * w + x;
+}
 
 __host__ __device__ inline long long bp_index(int y, int xw, int wpr) { return ((long long)(y >> 6) * wpr + xw) * 64 + (y & 63); }
 __host__ __device__ inline long long bp_words(int h, int wpr) { return (long long)((h + 63) / 64) * wpr * 64; }

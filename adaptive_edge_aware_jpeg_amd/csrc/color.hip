@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
     // one row of four pixels: colour transform, luma outputs, histogram; the chroma values come back to the caller
     // (RH = RW = 2: the horizontal pair sums (c[0] + c[1], c[2] + c[3]) of both chroma channels; RH = 1, RW = 4: the row's finished
     // means in h1[0] / h2[0])
-    auto do_row = [&](const RowRaw<IN> &raw, float (&h1)[2], float (&h2)[2], float *norm0, float *raw0, unsigned char *u80, unsigned o, lds_int *hcopy) {
+    auto do_row = [&](const RowRaw<IN> &raw, float (&h1)[2], float (&h2)[2], float *norm0, float *raw0, unsigned char *u80, unsigned o, unsigned on, lds_int *hcopy) {
         float in[12];
         if constexpr (kU8) {
 #pragma unroll
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
             h2[0] = (((c2[0] + c2[1]) + c2[2]) + c2[3]) * 0.25f; h2[1] = 0.f;
         }
         if (has_norm)
-            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(norm0) + 4u * o) =
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(norm0) + 4u * on) =
                 make_float4((c0[0] - nc.mid[0]) * nc.scale[0], (c0[1] - nc.mid[0]) * nc.scale[0], (c0[2] - nc.mid[0]) * nc.scale[0], (c0[3] - nc.mid[0]) * nc.scale[0]);
         if (has_raw) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(raw0) + 4u * o) = make_float4(c0[0], c0[1], c0[2], c0[3]);
         uchar4 u;
@@ -481,15 +481,20 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                 unsigned ioff = (unsigned)(ya * g.W + px) * (3u * (unsigned)sizeof(IN));      // byte offset inside the image: < 2^32
                 unsigned o_l = (unsigned)(ya * g.w[0] + px);
                 unsigned o_c = RH == 2 ? (unsigned)((ya >> 1) * g.w[1] + (px >> 1)) : (unsigned)(ya * g.w[1] + (px >> 2));
+                // element offsets of the NORMALISED planes (what the DCT kernels read): the same as o_l / o_c when those planes are row-major;
+                // Geom::tiled: 4 x 4 blocks (plane_elem) -- ya is a multiple of 4, a lane's four luma pixels are one row of a block, and the
+                // four rows of a block are written by consecutive iterations of the same lane
+                unsigned n_l = g.tiled ? (unsigned)plane_elem(1, g.w[0], ya, px) : o_l;
+                unsigned n_c = g.tiled ? (unsigned)(RH == 2 ? plane_elem(1, g.w[1], ya >> 1, px >> 1) : plane_elem(1, g.w[1], ya, px >> 2)) : o_c;
                 RowRaw<IN> rowA = strip_load_row<IN>(img, ioff);
                 for (int y = ya; y < yb; y += 2) {
                     const RowRaw<IN> rowB = strip_load_row<IN>(img, ioff + in_row_bytes);
                     float a1[2], a2[2], b1[2], b2[2];
-                    do_row(rowA, a1, a2, norm0, raw0, u80, o_l, hcopy);
+                    do_row(rowA, a1, a2, norm0, raw0, u80, o_l, n_l, hcopy);
                     // the next row A (the band's last step re-reads row B instead: an unconditional load keeps the registers of
                     // rowA out of a copy at the loop's back edge)
                     rowA = strip_load_row<IN>(img, ioff + (y + 2 < yb ? 2u : 1u) * in_row_bytes);
-                    do_row(rowB, b1, b2, norm0, raw0, u80, o_l + (unsigned)g.w[0], hcopy);
+                    do_row(rowB, b1, b2, norm0, raw0, u80, o_l + (unsigned)g.w[0], g.tiled ? n_l + 4u : n_l + (unsigned)g.w[0], hcopy);
                     // ---- layers 1, 2 (chroma): INTER_AREA box mean
 #pragma unroll
                     for (int ch = 1; ch < 3; ch++) {
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                             v[0] = (ca[0] + cb[0]) * 0.25f;
                             v[1] = (ca[1] + cb[1]) * 0.25f;
                             if (has_norm)
-                                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * o_c) =
+                                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * n_c) =
                                     make_float2((v[0] - nc.mid[ch]) * nc.scale[ch], (v[1] - nc.mid[ch]) * nc.scale[ch]);
                             if (has_raw) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(rawc[ch - 1]) + 4u * o_c) = make_float2(v[0], v[1]);
                             uchar2 u;
@@ -515,7 +520,9 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
 #pragma unroll
                             for (int q = 0; q < 2; q++) {
                                 const unsigned o = o_c + (unsigned)(q * g.w[ch]);
-                                if (has_norm) *reinterpret_cast<float *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * o) = (v[q] - nc.mid[ch]) * nc.scale[ch];
+                                if (has_norm)
+                                    *reinterpret_cast<float *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * (g.tiled ? n_c + 4u * q : n_c + (unsigned)(q * g.w[ch]))) =
+                                        (v[q] - nc.mid[ch]) * nc.scale[ch];
                                 if (has_raw) *reinterpret_cast<float *>(reinterpret_cast<char *>(rawc[ch - 1]) + 4u * o) = v[q];
                                 const unsigned char u = scale_u8(v[q]);
                                 if (has_u8) u8c[ch - 1][o] = u;
@@ -526,6 +533,15 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                     ioff += 2u * in_row_bytes;
                     o_l += 2u * (unsigned)g.w[0];
                     o_c += RH == 2 ? (unsigned)g.w[1] : 2u * (unsigned)g.w[1];
+                    if (g.tiled) {
+                        // two rows further: inside the block, or to the first row of the block below (w / 4 blocks of 16 elements on)
+                        n_l += (y & 2) ? 4u * (unsigned)g.w[0] - 8u : 8u;
+                        if (RH == 2) n_c += ((y >> 1) & 3) == 3 ? 4u * (unsigned)g.w[1] - 12u : 4u;
+                        else n_c += (y & 2) ? 4u * (unsigned)g.w[1] - 8u : 8u;
+                    } else {
+                        n_l = o_l;
+                        n_c = o_c;
+                    }
                 }
             }
         }
@@ -643,6 +659,38 @@ int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out
     return 0;
 }
 
+// Shapes the persistent strip kernel takes (CLAHE tiles without padding whose edges no 4 x 2 patch straddles, in every layer), and its strip
+// height.  Tuning knobs (tools/profiling), read once: AEJ_COLOR_NO_STRIP = the 128 x 16 kernel of rounds 1-2, AEJ_COLOR_STRIP_ROWS = strip height.
+static bool strip_shape(const Geom &g, int &nxb, int &rows)
+{
+    static const bool no_strip = getenv("AEJ_COLOR_NO_STRIP") != nullptr;
+    static const int env_rows = getenv("AEJ_COLOR_STRIP_ROWS") ? atoi(getenv("AEJ_COLOR_STRIP_ROWS")) : 0;
+    if (!((g.W % 16) == 0 && (g.H % 8) == 0 && g.ctw[0] * 4 == g.W && g.cth[0] * 4 == g.H && g.ctw[0] >= 128 && !no_strip)) return false;
+    nxb = (g.W + 127) / 128;
+    // rows per workgroup: as long as the launch still has a few thousand workgroups (one image spreads over the chip), at most 64
+    rows = 64;
+    while (rows > 16 && (long long)nxb * ((g.cth[0] + rows - 1) / rows) * 4 * g.B < 4096) rows >>= 1;
+    if (env_rows > 0) rows = (env_rows + 15) / 16 * 16;
+    return true;
+}
+
+// Whether the encode path may keep the normalised planes of this geometry in 4 x 4 blocks (Geom::tiled, plane_elem): the strip kernel
+// writes them (its half-waves start on rows that are multiples of 4 when the strip height is a multiple of 32 and the CLAHE tile
+// height a multiple of 4) and every layer's sides are multiples of 4.
+// OFF unless AEJ_PLANES_TILED is set (read once): with it `k_dct4` / `k_dct8_shfl` take 0.22 / 0.16 instead of 0.27 / 0.215 ms per 64 x 4K
+// (every leaf is whole sectors), but the strip kernel's stores -- 16-byte pieces at a 64-byte stride per instruction, four times the
+// memory transactions of a row -- cost 0.45 ms more than that saves; the stores need staging through LDS.
+bool color_planes_can_tile(const Geom &g)
+{
+    static const bool enabled = getenv("AEJ_PLANES_TILED") != nullptr;
+    int nxb, rows;
+    if (!enabled || g.nl != 3 || !strip_shape(g, nxb, rows)) return false;
+    if ((rows % 32) != 0 || (g.cth[0] % 4) != 0) return false;
+    for (int l = 0; l < 3; l++)
+        if ((g.w[l] % 4) != 0 || (g.h[l] % 4) != 0) return false;
+    return true;
+}
+
 template <int SPACE, int RH, int RW>
 static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const Geom &g, const NormConst &nc, float *raw, float *norm,
                             unsigned char *u8, int *hist)
@@ -650,15 +698,9 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
     // strip kernel: CLAHE tiles without padding whose edges no 4 x 2 patch straddles, in every layer
     // tuning knobs (tools/profiling), read once: AEJ_COLOR_NO_STRIP = the 128 x 16 kernel of rounds 1-2, AEJ_COLOR_STRIP_ROWS / AEJ_COLOR_WGS = strip
     // height / workgroups in the persistent launch
-    static const bool no_strip = getenv("AEJ_COLOR_NO_STRIP") != nullptr;
-    static const int env_rows = getenv("AEJ_COLOR_STRIP_ROWS") ? atoi(getenv("AEJ_COLOR_STRIP_ROWS")) : 0;
     static const int env_wgs = getenv("AEJ_COLOR_WGS") ? atoi(getenv("AEJ_COLOR_WGS")) : 0;
-    if ((g.W % 16) == 0 && (g.H % 8) == 0 && g.ctw[0] * 4 == g.W && g.cth[0] * 4 == g.H && g.ctw[0] >= 128 && !no_strip) {
-        const int nxb = (g.W + 127) / 128;
-        // rows per workgroup: as long as the launch still has a few thousand workgroups (one image spreads over the chip), at most 64
-        int rows = 64;
-        while (rows > 16 && (long long)nxb * ((g.cth[0] + rows - 1) / rows) * 4 * g.B < 4096) rows >>= 1;
-        if (env_rows > 0) rows = (env_rows + 15) / 16 * 16;
+    int nxb, rows;
+    if (strip_shape(g, nxb, rows)) {
         const int nys = (g.cth[0] + rows - 1) / rows;
         const long long nstrips = (long long)nxb * nys * 4 * g.B;
         // Workgroups in the launch.  The matrix spaces are a pure stream: ONE workgroup per CU (256 in all, each walking ~270 strips)
@@ -692,6 +734,7 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
 int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                         float *raw, float *norm, unsigned char *u8, int *hist)
 {
+    if (g.tiled && !color_planes_can_tile(g)) return -1;       // only the strip kernel writes the tiled form
     NormConst nc;
     for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
     switch (space) {

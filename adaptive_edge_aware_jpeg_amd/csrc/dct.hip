@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
             const int col = cur.y + reflect_pad_idx(j, wc);
             float x[S];
 #pragma unroll
-            for (int k = 0; k < S; k++) x[k] = src[(long long)(cur.z + reflect_pad_idx(k, hc)) * w + col];
+            for (int k = 0; k < S; k++) x[k] = src[plane_elem(g.tiled, w, cur.z + reflect_pad_idx(k, hc), col)];
             if (base + step + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + step + slot);
             // T[i][j] = sum_k D[i][k] X[k][j]
 #pragma unroll
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
         if (hc == 4 && wc == 4 && (w & 3) == 0) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float4 v = *reinterpret_cast<const float4 *>(src + (long long)(cur.z + r) * w + cur.y);
+                const float4 v = *reinterpret_cast<const float4 *>(src + plane_elem(g.tiled, w, cur.z + r, cur.y));      // (tiled: the four rows are one 64-byte run)
                 x[r][0] = v.x; x[r][1] = v.y; x[r][2] = v.z; x[r][3] = v.w;
             }
         } else {                              // clipped at the plane border (np.pad reflect) or unaligned rows
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int c = 0; c < 4; c++)
-                    x[r][c] = src[(long long)(cur.z + reflect_pad_idx(r, hc)) * w + cur.y + reflect_pad_idx(c, wc)];
+                    x[r][c] = src[plane_elem(g.tiled, w, cur.z + reflect_pad_idx(r, hc), cur.y + reflect_pad_idx(c, wc))];
         }
         float T[4][4];                        // T[i][j] = sum_k D[i][k] X[k][j]
 #pragma unroll
@@ -393,13 +393,13 @@ __global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, 
             const int w = lt.w[layer], h = lt.h[layer];
             const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
             const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
-            const float *colp = src + cur.y + reflect_pad_idx(j, wc);
+            const int col = cur.y + reflect_pad_idx(j, wc);
             if (hc == S) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = colp[(long long)(cur.z + k) * w];
+                for (int k = 0; k < 8; k++) x[k] = src[plane_elem(g.tiled, w, cur.z + k, col)];      // (tiled: the leaf is two 128-byte lines)
             } else {
 #pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = colp[(long long)(cur.z + reflect_pad_idx(k, hc)) * w];
+                for (int k = 0; k < 8; k++) x[k] = src[plane_elem(g.tiled, w, cur.z + reflect_pad_idx(k, hc), col)];
             }
             if (base + step + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + step + slot);
         }
@@ -506,15 +506,15 @@ __global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a,
     auto load_x = [&](const int4 &d, float (&x)[4]) {      // d scalar
         const int b = d.x / 3, layer = d.x - b * 3;
         const int w = rfl(lt.w[layer]), h = rfl(lt.h[layer]);
-        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer] + (long long)d.z * w + d.y;
+        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
         if (d.z + S <= h && d.y + S <= w) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) x[s] = src[(4 * s + gq) * w + i];
+            for (int s = 0; s < 4; s++) x[s] = src[plane_elem(g.tiled, w, d.z + 4 * s + gq, d.y + i)];
         } else {                                           // clipped at the plane border: np.pad(reflect) indices
             const int hc = min(S, h - d.z), wc = min(S, w - d.y);
-            const int col = reflect_pad_idx(i, wc);
+            const int col = d.y + reflect_pad_idx(i, wc);
 #pragma unroll
-            for (int s = 0; s < 4; s++) x[s] = src[(long long)reflect_pad_idx(4 * s + gq, hc) * w + col];
+            for (int s = 0; s < 4; s++) x[s] = src[plane_elem(g.tiled, w, d.z + reflect_pad_idx(4 * s + gq, hc), col)];
         }
     };
     auto rfl4 = [&](const int4 &v) { return make_int4(rfl(v.x), rfl(v.y), rfl(v.z), rfl(v.w)); };
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_dct_big(Geom g, QtGeom q, DctArgs a, lo
         const float *D = a.D;
         big_product<S>(L,
             [&](int i, int k) { return D[i * S + k]; },
-            [&](int k, int j) { return src[(long long)(cur.z + reflect_pad_idx(k, hc)) * w + cur.y + reflect_pad_idx(j, wc)]; },
+            [&](int k, int j) { return src[plane_elem(g.tiled, w, cur.z + reflect_pad_idx(k, hc), cur.y + reflect_pad_idx(j, wc))]; },
             [&](int i, int j, float v) { T[i * S + j] = v; });
         big_scratch_sync();
         const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
@@ -666,26 +666,26 @@ template <int S, int NWAVES>
 struct XOffsets { unsigned off[S * S / 256 / NWAVES]; int w; };
 
 template <int S, int NWAVES>
-__device__ __forceinline__ void dct_x_offsets(XOffsets<S, NWAVES> &xo, int w, int wave, int lane)
+__device__ __forceinline__ void dct_x_offsets(XOffsets<S, NWAVES> &xo, int w, int tiled, int wave, int lane)
 {
     constexpr int ROWS = 256 / S;                 // rows per wave instruction
 #pragma unroll
     for (int t = 0; t < S * S / 256 / NWAVES; t++) {
         const int chunk = t * NWAVES + wave;
         const int r = chunk * ROWS + lane / (S / 4), c = (lane % (S / 4)) * 4;
-        xo.off[t] = (unsigned)(r * w + c) * 4u;
+        xo.off[t] = (unsigned)plane_elem(tiled, w, r, c) * 4u;        // (tiled: a wave instruction's 4 rows x 64 columns are one contiguous KiB)
     }
     xo.w = w;
 }
 
 template <int S, int NWAVES>
-__device__ __forceinline__ void dct_load_x(const float *src, int w, int h, const int4 &d, float *sX, int wave, int lane, XOffsets<S, NWAVES> &xo)
+__device__ __forceinline__ void dct_load_x(const float *src, int w, int h, int tiled, const int4 &d, float *sX, int wave, int lane, XOffsets<S, NWAVES> &xo)
 {
     constexpr int SS = S * S;
     const int hc = min(S, h - d.z), wc = min(S, w - d.y);
     if (hc == S && wc == S && (w & 3) == 0) {
-        if (xo.w != w) dct_x_offsets<S, NWAVES>(xo, w, wave, lane);     // the layer changed (wave-uniform)
-        const float *leaf = src + (long long)d.z * w + d.y;
+        if (xo.w != w) dct_x_offsets<S, NWAVES>(xo, w, tiled, wave, lane);     // the layer changed (wave-uniform)
+        const float *leaf = src + plane_elem(tiled, w, d.z, d.y);
 #pragma unroll
         for (int t = 0; t < SS / 256 / NWAVES; t++) glds16_s(leaf, xo.off[t], sX + (t * NWAVES + wave) * 256);
     } else {
@@ -694,7 +694,7 @@ __device__ __forceinline__ void dct_load_x(const float *src, int w, int h, const
             const int chunk = t * NWAVES + wave;
             const int idx = chunk * 64 + lane;
             const int r = idx / S, c = idx - r * S;
-            glds4(src + (long long)(d.z + reflect_pad_idx(r, hc)) * w + d.y + reflect_pad_idx(c, wc), sX + chunk * 64);
+            glds4(src + plane_elem(tiled, w, d.z + reflect_pad_idx(r, hc), d.y + reflect_pad_idx(c, wc)), sX + chunk * 64);
         }
     }
 }
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
         int b0, l0, w0, h0;
         const float *src0;
         plane_of(cur, b0, l0, w0, h0, src0);
-        dct_load_x<S, NWAVES>(src0, w0, h0, make_int4(cur.plane, cur.x, cur.y, cur.coef), sXb, wave, lane, xo);
+        dct_load_x<S, NWAVES>(src0, w0, h0, g.tiled, make_int4(cur.plane, cur.x, cur.y, cur.coef), sXb, wave, lane, xo);
         wait_vmem_but<0>();
     }
     // quantisers of this lane's outputs (as floats: they are < 2^24), kept in registers while consecutive leaves belong to the same
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
             }
         }
         if (NXB == 1) {
-            dct_load_x<S, NWAVES>(src, lw, lhh, make_int4(cur.plane, cur.x, cur.y, cur.coef), sX, wave, lane, xo);
+            dct_load_x<S, NWAVES>(src, lw, lhh, g.tiled, make_int4(cur.plane, cur.x, cur.y, cur.coef), sX, wave, lane, xo);
             wait_vmem_but<0>();
         }
         lds_barrier();                    // X of this leaf has landed: every wave waited for its own pieces before arriving
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
             int bn, ln, wn, hn;
             const float *srcn;
             plane_of(nxt, bn, ln, wn, hn, srcn);
-            dct_load_x<S, NWAVES>(srcn, wn, hn, make_int4(nxt.plane, nxt.x, nxt.y, nxt.coef), sXb + (pb ^ 1) * SS, wave, lane, xo);
+            dct_load_x<S, NWAVES>(srcn, wn, hn, g.tiled, make_int4(nxt.plane, nxt.x, nxt.y, nxt.coef), sXb + (pb ^ 1) * SS, wave, lane, xo);
         }
         AEJ_STAMP(11)
         // entering a chunk: the chunk before it is finished, its buffer takes the chunk after this one (needed 64 leaves from now)
@@ -1083,11 +1083,15 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
         const int hc = min(S, h - d.y), wc = min(S, w - d.x);
         typedef const char __attribute__((address_space(1))) *gbytes;          // (an integer cast to a plain pointer would give flat loads)
         typedef const float __attribute__((address_space(1))) *gfloat;
-        unsigned long long base = (unsigned long long)(size_t)(src + (long long)d.y * w + d.x);
+        unsigned long long base = (unsigned long long)(size_t)(src + plane_elem(g.tiled, w, d.y, d.x));
         const unsigned rowb = (unsigned)w * 4u;
         if (hc == S && wc == S) {
-            // the unclipped leaf: scalar row bases, one constant byte offset per lane -- two scalar and two memory instructions per step
-            const unsigned off = (lh ? rowb : 0u) + (unsigned)pli * 4u;
+            // the unclipped leaf: scalar row bases, one constant byte offset per lane -- two scalar and two memory instructions per step.
+            // Row-major: step s reads rows 2s / 2s + 1 (lane half) at column pli.  Tiled: row 2s + lh is row 2 (s & 1) + lh of block row
+            // s >> 1, column pli is element pli & 3 of block pli >> 2; the second tile's columns are 8 blocks further.
+            const unsigned off = g.tiled ? (unsigned)(pli >> 2) * 64u + (unsigned)(pli & 3) * 4u + (lh ? 16u : 0u) : (lh ? rowb : 0u) + (unsigned)pli * 4u;
+            const unsigned second = g.tiled ? 512u : 128u;
+            const unsigned long long even_step = g.tiled ? 32ull : 2ull * rowb, odd_step = g.tiled ? 4ull * rowb - 32ull : 2ull * rowb;
 #pragma unroll
             for (int s = 0; s < 32; s++) {
                 // (readfirstlane pins the row base to scalar registers: without it the compiler adds the lane offset first and carries
@@ -1095,12 +1099,12 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
                 const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
                 const gbytes rowp = (gbytes)(size_t)(((unsigned long long)bhi << 32) | blo);
                 xr[0][s] = *(gfloat)(rowp + off);
-                xr[1][s] = *(gfloat)(rowp + off + 128u);
-                base += 2ull * rowb;
+                xr[1][s] = *(gfloat)(rowp + (off + second));
+                base += (s & 1) ? odd_step : even_step;
             }
         } else {
             // clipped by the plane's border (the last row / column of leaves of a plane): np.pad(reflect) row by row
-            const unsigned c0 = (unsigned)reflect_pad_idx(pli, wc) * 4u, c1 = (unsigned)reflect_pad_idx(32 + pli, wc) * 4u;
+            const int cc0 = reflect_pad_idx(pli, wc), cc1 = reflect_pad_idx(32 + pli, wc);
             int r = 0, dir = hc > 1 ? 1 : 0;
             auto advance = [&]() {
                 r += dir;
@@ -1113,10 +1117,10 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
                 advance();
                 const int r1 = r;
                 advance();
-                const unsigned lr = (unsigned)(lh ? r1 : r0) * rowb;
-                const gbytes leafp = (gbytes)(size_t)base;
-                xr[0][s] = *(gfloat)(leafp + (lr + c0));
-                xr[1][s] = *(gfloat)(leafp + (lr + c1));
+                const int rr = lh ? r1 : r0;
+                const gfloat plane = (gfloat)(size_t)src;
+                xr[0][s] = plane[plane_elem(g.tiled, w, d.y + rr, d.x + cc0)];
+                xr[1][s] = plane[plane_elem(g.tiled, w, d.y + rr, d.x + cc1)];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -544,3 +544,36 @@ def test_both_64x64_dct_kernels_agree():
         out[knob] = line[0].split()[1:]
     assert out["AEJ_DCT64_ONE_WAVE"] == out["AEJ_DCT64_FOUR_WAVES"]
     assert int(out["AEJ_DCT64_ONE_WAVE"][1]) > 50, "the image must contain 64 x 64 leaves"
+
+
+def test_tiled_planes_give_the_same_bytes():
+    """AEJ_PLANES_TILED keeps the normalised planes of strip-kernel shapes in 4 x 4 blocks (Geom::tiled: the colour kernel's stores and every
+    DCT kernel's loads change their addressing).  Read once per process, so the two layouts run in processes of their own: same bytes, for a
+    batch large enough for the strip kernel's 32- / 64-row strips, in a 2 x 2 and in a 1 x 4 chroma space, with planes that clip 64 x 64 leaves."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import hashlib, torch, bench, adaptive_edge_aware_jpeg_amd as A\n"
+            "x = bench.synth_batch(torch, 12, 1072, 1920, 11, torch.device('cuda', 0))\n"
+            "out = []\n"
+            "for space in ('YCbCr', 'ICtCp'):\n"
+            "    enc = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), (4, 64))).compress_batch(x)\n"
+            "    h = hashlib.sha256()\n"
+            "    for b in (0, 5, 11):\n"
+            "        for l in range(3):\n"
+            "            d = enc.layer(b, l)\n"
+            "            h.update(d['coeffs'].tobytes()); h.update(d['leaves'].tobytes())\n"
+            "    out.append(h.hexdigest())\n"
+            "print('RESULT', *out)\n")
+    res = {}
+    for tiled in (False, True):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.pop("AEJ_PLANES_TILED", None)
+        if tiled:
+            env["AEJ_PLANES_TILED"] = "1"
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        res[tiled] = line[0].split()[1:]
+    assert res[False] == res[True]
