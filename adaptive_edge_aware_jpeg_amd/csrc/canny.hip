@@ -165,9 +165,10 @@ constexpr int kBRows = (kBGH + kASlots - 1) / kASlots;      // Gaussian output r
 static_assert(kASlots * kBRows >= kBGH && kASlots * kAIter >= kBAH, "thread -> row mapping must cover the tile");
 constexpr float kTwo24 = 16777216.0f, kTwo22 = 4194304.0f;
 #ifndef AEJ_X_BLUR_HIST
-#define AEJ_X_BLUR_HIST 8
+#define AEJ_X_BLUR_HIST 6
 #endif
-constexpr int kHistCopies = AEJ_X_BLUR_HIST;             // (8 copies keep the workgroup under a third of the LDS)
+constexpr int kHistCopies = AEJ_X_BLUR_HIST;             // (6 copies: 39.5 KiB per workgroup, so that three of them leave the colour kernel its 38 KiB --
+                                                        // with the tiled planes it stages four rows per half-wave; 8 and 16 copies measured the same speed)
 constexpr int kHistStride = 257;          // dwords per histogram copy: odd, so the same bin of different copies sits in different banks
 
 // Member order matters: DS instructions carry a 16-bit immediate offset, so everything addressed with small compile-time offsets

@@ -353,12 +353,13 @@ __device__ __forceinline__ RowRaw<IN> strip_load_row(const IN *img, unsigned byt
     return r;
 }
 
-template <int SPACE, int RH, int RW, typename IN, bool PROD>
+template <int SPACE, int RH, int RW, typename IN, bool PROD, bool TILED>
 __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict__ rgb, Geom g, NormConst nc, float *__restrict__ planes_raw,
                                                             float *__restrict__ planes_norm, unsigned char *__restrict__ planes_u8,
                                                             int *__restrict__ tile_hist, int nxb, int nys, int rows, int nstrips)
 {
     __shared__ int s_hist[3 * kStripSlots * kStripHistStride];
+    extern __shared__ __attribute__((aligned(16))) float s_stage[];      // Geom::tiled only: 8 half-waves x 1024 floats (luma 4 x 128, chroma 2 x 4 x 64)
     const int tid = threadIdx.x;
     constexpr bool kU8 = sizeof(IN) == 1;
     constexpr bool kLin = SPACE >= 3;
@@ -421,9 +422,11 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
             h1[0] = (((c1[0] + c1[1]) + c1[2]) + c1[3]) * 0.25f; h1[1] = 0.f;
             h2[0] = (((c2[0] + c2[1]) + c2[2]) + c2[3]) * 0.25f; h2[1] = 0.f;
         }
-        if (has_norm)
-            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(norm0) + 4u * on) =
-                make_float4((c0[0] - nc.mid[0]) * nc.scale[0], (c0[1] - nc.mid[0]) * nc.scale[0], (c0[2] - nc.mid[0]) * nc.scale[0], (c0[3] - nc.mid[0]) * nc.scale[0]);
+        if (has_norm) {
+            const float4 nv = make_float4((c0[0] - nc.mid[0]) * nc.scale[0], (c0[1] - nc.mid[0]) * nc.scale[0], (c0[2] - nc.mid[0]) * nc.scale[0], (c0[3] - nc.mid[0]) * nc.scale[0]);
+            if (TILED) *reinterpret_cast<float4 *>(s_stage + on) = nv;          // (staged: whole 4 x 4 blocks leave together, see the row loop)
+            else *reinterpret_cast<float4 *>(reinterpret_cast<char *>(norm0) + 4u * on) = nv;
+        }
         if (has_raw) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(raw0) + 4u * o) = make_float4(c0[0], c0[1], c0[2], c0[3]);
         uchar4 u;
         u.x = scale_u8(c0[0]); u.y = scale_u8(c0[1]); u.z = scale_u8(c0[2]); u.w = scale_u8(c0[3]);
@@ -484,17 +487,32 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                 // element offsets of the NORMALISED planes (what the DCT kernels read): the same as o_l / o_c when those planes are row-major;
                 // Geom::tiled: 4 x 4 blocks (plane_elem) -- ya is a multiple of 4, a lane's four luma pixels are one row of a block, and the
                 // four rows of a block are written by consecutive iterations of the same lane
-                unsigned n_l = g.tiled ? (unsigned)plane_elem(1, g.w[0], ya, px) : o_l;
-                unsigned n_c = g.tiled ? (unsigned)(RH == 2 ? plane_elem(1, g.w[1], ya >> 1, px >> 1) : plane_elem(1, g.w[1], ya, px >> 2)) : o_c;
+                // With Geom::tiled the rows are STAGED in LDS, four at a time per half-wave, and leave as whole blocks: a half-wave's 4 x 128
+                // luma pixels are 32 blocks = 2 KiB contiguous in the plane (chroma: 4 x 64 = 1 KiB, or 4 x 32 = 512 B), written as 16-byte
+                // pieces by consecutive lanes.  In LDS, 16-byte unit u of row r sits at u ^ 4r (rows of 8 units: u ^ 4 (r >> 1)), which
+                // makes the row-wise writes and the block-wise reads conflict-free without padding.  n_l / n_c = this lane's slot in the
+                // current block row's run.
+                const unsigned st0 = (unsigned)(tq >> 5) * 1024u;          // this half-wave's staging area (floats)
+                unsigned n_l = TILED ? (unsigned)plane_elem(1, g.w[0], ya, x0) + 4u * (unsigned)(tq & 31) : o_l;
+                unsigned n_c = TILED ? (unsigned)(RH == 2 ? plane_elem(1, g.w[1], (ya >> 1) & ~3, x0 >> 1) : plane_elem(1, g.w[1], ya, x0 >> 2)) + 4u * (unsigned)(tq & 31) : o_c;
+                int c_lo = (ya >> 1) & 3;          // (RH == 2) first row of the current chroma block this half-wave produces: 0, or 2 when the band starts
+                                                   // in the middle of a block (CLAHE tiles 4 (mod 8) rows high) -- the other rows are another half-wave's
                 RowRaw<IN> rowA = strip_load_row<IN>(img, ioff);
                 for (int y = ya; y < yb; y += 2) {
                     const RowRaw<IN> rowB = strip_load_row<IN>(img, ioff + in_row_bytes);
                     float a1[2], a2[2], b1[2], b2[2];
-                    do_row(rowA, a1, a2, norm0, raw0, u80, o_l, n_l, hcopy);
+                    const int rb = y & 3;                 // row of the block (0 or 2: ya is a multiple of 4)
+                    // (the lane index once more from a copy the compiler cannot see through: hoisted out of the row loop, the dozen LDS addresses
+                    // derived from it cost two dozen registers, and the kernel has to stay within 56)
+                    int tl = tq;
+                    asm volatile("" : "+v"(tl));
+                    const int lane32 = tl & 31;
+                    do_row(rowA, a1, a2, norm0, raw0, u80, o_l, TILED ? st0 + (unsigned)(rb * 128 + ((lane32 ^ (4 * rb)) << 2)) : n_l, hcopy);
                     // the next row A (the band's last step re-reads row B instead: an unconditional load keeps the registers of
                     // rowA out of a copy at the loop's back edge)
                     rowA = strip_load_row<IN>(img, ioff + (y + 2 < yb ? 2u : 1u) * in_row_bytes);
-                    do_row(rowB, b1, b2, norm0, raw0, u80, o_l + (unsigned)g.w[0], g.tiled ? n_l + 4u : n_l + (unsigned)g.w[0], hcopy);
+                    do_row(rowB, b1, b2, norm0, raw0, u80, o_l + (unsigned)g.w[0],
+                           TILED ? st0 + (unsigned)((rb + 1) * 128 + ((lane32 ^ (4 * (rb + 1))) << 2)) : n_l + (unsigned)g.w[0], hcopy);
                     // ---- layers 1, 2 (chroma): INTER_AREA box mean
 #pragma unroll
                     for (int ch = 1; ch < 3; ch++) {
@@ -503,9 +521,15 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                         if constexpr (RH == 2 && RW == 2) {      // ((r0e+r0o)+(r1e+r1o))*0.25f
                             v[0] = (ca[0] + cb[0]) * 0.25f;
                             v[1] = (ca[1] + cb[1]) * 0.25f;
-                            if (has_norm)
-                                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * n_c) =
-                                    make_float2((v[0] - nc.mid[ch]) * nc.scale[ch], (v[1] - nc.mid[ch]) * nc.scale[ch]);
+                            if (has_norm) {
+                                const float2 nv = make_float2((v[0] - nc.mid[ch]) * nc.scale[ch], (v[1] - nc.mid[ch]) * nc.scale[ch]);
+                                if (TILED) {
+                                    const int rc = (y >> 1) & 3;
+                                    *reinterpret_cast<float2 *>(s_stage + st0 + 512u + (unsigned)((ch - 1) * 256 + rc * 64 + (((lane32 >> 1) ^ (4 * rc)) << 2) + (lane32 & 1) * 2)) = nv;
+                                } else {
+                                    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * n_c) = nv;
+                                }
+                            }
                             if (has_raw) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(rawc[ch - 1]) + 4u * o_c) = make_float2(v[0], v[1]);
                             uchar2 u;
                             u.x = scale_u8(v[0]); u.y = scale_u8(v[1]);
@@ -520,9 +544,15 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
 #pragma unroll
                             for (int q = 0; q < 2; q++) {
                                 const unsigned o = o_c + (unsigned)(q * g.w[ch]);
-                                if (has_norm)
-                                    *reinterpret_cast<float *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * (g.tiled ? n_c + 4u * q : n_c + (unsigned)(q * g.w[ch]))) =
-                                        (v[q] - nc.mid[ch]) * nc.scale[ch];
+                                if (has_norm) {
+                                    const float nv = (v[q] - nc.mid[ch]) * nc.scale[ch];
+                                    if (TILED) {
+                                        const int rr = (y & 3) + q;
+                                        s_stage[st0 + 512u + (unsigned)((ch - 1) * 256 + rr * 32 + (((lane32 >> 2) ^ ((rr >> 1) << 2)) << 2) + (lane32 & 3))] = nv;
+                                    } else {
+                                        *reinterpret_cast<float *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * (n_c + (unsigned)(q * g.w[ch]))) = nv;
+                                    }
+                                }
                                 if (has_raw) *reinterpret_cast<float *>(reinterpret_cast<char *>(rawc[ch - 1]) + 4u * o) = v[q];
                                 const unsigned char u = scale_u8(v[q]);
                                 if (has_u8) u8c[ch - 1][o] = u;
@@ -533,11 +563,43 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                     ioff += 2u * in_row_bytes;
                     o_l += 2u * (unsigned)g.w[0];
                     o_c += RH == 2 ? (unsigned)g.w[1] : 2u * (unsigned)g.w[1];
-                    if (g.tiled) {
-                        // two rows further: inside the block, or to the first row of the block below (w / 4 blocks of 16 elements on)
-                        n_l += (y & 2) ? 4u * (unsigned)g.w[0] - 8u : 8u;
-                        if (RH == 2) n_c += ((y >> 1) & 3) == 3 ? 4u * (unsigned)g.w[1] - 12u : 4u;
-                        else n_c += (y & 2) ? 4u * (unsigned)g.w[1] - 8u : 8u;
+                    if (TILED) {
+                        // (LDS operations of one wave execute in order: the reads below see the writes above, the next rows' writes come after)
+                        const int fr = lane32 & 3, fb = lane32 >> 2;          // this lane's row / block in a flush
+                        if (y & 2) {                              // rows 2, 3 of the luma blocks are in: 32 blocks = 2 KiB leave
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(norm0) + 4u * (n_l + 128u * k)) =
+                                    *reinterpret_cast<const float4 *>(s_stage + st0 + (unsigned)(fr * 128 + (((fb + 8 * k) ^ (4 * fr)) << 2)));
+                                __builtin_amdgcn_sched_barrier(0);       // (one piece in registers at a time: the kernel has to stay within 56 VGPRs)
+                            }
+                            n_l += 4u * (unsigned)g.w[0];         // the next block row: w / 4 blocks of 16 elements on
+                        }
+                        if (RH == 2) {
+                            const int rc = (y >> 1) & 3;
+                            if (rc == 3 || y + 2 >= yb) {         // the block's last row, or the band's: rows c_lo .. rc of 16 blocks per plane leave
+                                if (fr >= c_lo && fr <= rc) {
+#pragma unroll
+                                    for (int ch = 1; ch < 3; ch++)
+#pragma unroll
+                                        for (int k = 0; k < 2; k++) {
+                                            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * (n_c + 128u * k)) =
+                                                *reinterpret_cast<const float4 *>(s_stage + st0 + 512u + (unsigned)((ch - 1) * 256 + fr * 64 + (((fb + 8 * k) ^ (4 * fr)) << 2)));
+                                            __builtin_amdgcn_sched_barrier(0);
+                                        }
+                                }
+                                n_c += 4u * (unsigned)g.w[1];
+                                c_lo = 0;
+                            }
+                        } else if (y & 2) {                       // RH == 1, RW == 4: 8 blocks = 512 B per plane
+#pragma unroll
+                            for (int ch = 1; ch < 3; ch++) {
+                                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(normc[ch - 1]) + 4u * n_c) =
+                                    *reinterpret_cast<const float4 *>(s_stage + st0 + 512u + (unsigned)((ch - 1) * 256 + fr * 32 + ((fb ^ ((fr >> 1) << 2)) << 2)));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            n_c += 4u * (unsigned)g.w[1];
+                        }
                     } else {
                         n_l = o_l;
                         n_c = o_c;
@@ -677,15 +739,16 @@ static bool strip_shape(const Geom &g, int &nxb, int &rows)
 // Whether the encode path may keep the normalised planes of this geometry in 4 x 4 blocks (Geom::tiled, plane_elem): the strip kernel
 // writes them (its half-waves start on rows that are multiples of 4 when the strip height is a multiple of 32 and the CLAHE tile
 // height a multiple of 4) and every layer's sides are multiples of 4.
-// OFF unless AEJ_PLANES_TILED is set (read once): with it `k_dct4` / `k_dct8_shfl` take 0.22 / 0.16 instead of 0.27 / 0.215 ms per 64 x 4K
-// (every leaf is whole sectors), but the strip kernel's stores -- 16-byte pieces at a 64-byte stride per instruction, four times the
-// memory transactions of a row -- cost 0.45 ms more than that saves; the stores need staging through LDS.
+// On by default; AEJ_PLANES_ROW_MAJOR (read once) keeps the planes row-major.  64 x 4K: `k_dct4` / `k_dct8_shfl` 0.285 / 0.225 -> 0.23 / 0.163 ms (every
+// leaf is whole sectors; 1.35 GB less read per call), the colour stage 2.12 -> 2.15 ms.  (Written piecewise -- 16 bytes per lane at a 64-byte
+// stride, four times the memory transactions of a row -- the colour stage took 2.5 ms: hence the staging in LDS.)
 bool color_planes_can_tile(const Geom &g)
 {
-    static const bool enabled = getenv("AEJ_PLANES_TILED") != nullptr;
+    static const bool row_major = getenv("AEJ_PLANES_ROW_MAJOR") != nullptr;
     int nxb, rows;
-    if (!enabled || g.nl != 3 || !strip_shape(g, nxb, rows)) return false;
-    if ((rows % 32) != 0 || (g.cth[0] % 4) != 0) return false;
+    if (row_major || g.nl != 3 || !strip_shape(g, nxb, rows)) return false;
+    // (every strip full: W a multiple of 128; half-waves start on multiples of 4 luma rows: strips of 32 or 64 rows, CLAHE tiles a multiple of 4 high)
+    if ((rows % 32) != 0 || (g.cth[0] % 4) != 0 || (g.W % 128) != 0) return false;
     for (int l = 0; l < 3; l++)
         if ((g.w[l] % 4) != 0 || (g.h[l] % 4) != 0) return false;
     return true;
@@ -712,13 +775,17 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
         if (env_wgs > 0) want = env_wgs;
         dim3 sgrid((unsigned)(nstrips < want ? nstrips : want));
         const bool prod = norm && u8 && hist && !raw;
-        auto go = [&](auto kern, auto *in) { hipLaunchKernelGGL(kern, sgrid, dim3(256), 0, st, in, g, nc, raw, norm, u8, hist, nxb, nys, rows, (int)nstrips); };
+        const size_t stage_bytes = g.tiled ? 8 * 1024 * sizeof(float) : 0;
+        auto go = [&](auto kern, auto *in) { hipLaunchKernelGGL(kern, sgrid, dim3(256), stage_bytes, st, in, g, nc, raw, norm, u8, hist, nxb, nys, rows, (int)nstrips); };
+        // (the tiled form of the normalised planes only exists for the encode path's instantiation)
         if (in_u8) {
-            if (prod) go(k_color_planes_strip<SPACE, RH, RW, unsigned char, true>, static_cast<const unsigned char *>(rgb));
-            else go(k_color_planes_strip<SPACE, RH, RW, unsigned char, false>, static_cast<const unsigned char *>(rgb));
+            if (prod && g.tiled) go(k_color_planes_strip<SPACE, RH, RW, unsigned char, true, true>, static_cast<const unsigned char *>(rgb));
+            else if (prod) go(k_color_planes_strip<SPACE, RH, RW, unsigned char, true, false>, static_cast<const unsigned char *>(rgb));
+            else go(k_color_planes_strip<SPACE, RH, RW, unsigned char, false, false>, static_cast<const unsigned char *>(rgb));
         } else {
-            if (prod) go(k_color_planes_strip<SPACE, RH, RW, float, true>, static_cast<const float *>(rgb));
-            else go(k_color_planes_strip<SPACE, RH, RW, float, false>, static_cast<const float *>(rgb));
+            if (prod && g.tiled) go(k_color_planes_strip<SPACE, RH, RW, float, true, true>, static_cast<const float *>(rgb));
+            else if (prod) go(k_color_planes_strip<SPACE, RH, RW, float, true, false>, static_cast<const float *>(rgb));
+            else go(k_color_planes_strip<SPACE, RH, RW, float, false, false>, static_cast<const float *>(rgb));
         }
         return;
     }
@@ -734,7 +801,7 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
 int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                         float *raw, float *norm, unsigned char *u8, int *hist)
 {
-    if (g.tiled && !color_planes_can_tile(g)) return -1;       // only the strip kernel writes the tiled form
+    if (g.tiled && (!color_planes_can_tile(g) || !(norm && u8 && hist && !raw))) return -1;       // only the encode path's strip kernel writes the tiled form
     NormConst nc;
     for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
     switch (space) {

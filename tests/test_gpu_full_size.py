@@ -547,15 +547,16 @@ def test_both_64x64_dct_kernels_agree():
 
 
 def test_tiled_planes_give_the_same_bytes():
-    """AEJ_PLANES_TILED keeps the normalised planes of strip-kernel shapes in 4 x 4 blocks (Geom::tiled: the colour kernel's stores and every
-    DCT kernel's loads change their addressing).  Read once per process, so the two layouts run in processes of their own: same bytes, for a
-    batch large enough for the strip kernel's 32- / 64-row strips, in a 2 x 2 and in a 1 x 4 chroma space, with planes that clip 64 x 64 leaves."""
+    """The normalised planes of strip-kernel shapes are kept in 4 x 4 blocks (Geom::tiled: the colour kernel stages its rows in LDS and writes
+    whole blocks, every DCT kernel's loads change their addressing); AEJ_PLANES_ROW_MAJOR keeps them row-major.  Read once per process, so the
+    two layouts run in processes of their own: same bytes, for a batch large enough for the strip kernel's 32- / 64-row strips, in a 2 x 2 and
+    in a 1 x 4 chroma space, with planes that clip 64 x 64 leaves and CLAHE tiles 4 (mod 8) rows high (chroma blocks split between half-waves)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prog = ("import hashlib, torch, bench, adaptive_edge_aware_jpeg_amd as A\n"
-            "x = bench.synth_batch(torch, 12, 1072, 1920, 11, torch.device('cuda', 0))\n"
+            "x = bench.synth_batch(torch, 12, 1072, 1920, 11, torch.device('cuda', 0))      # 1072 / 4 = 268 = 4 (mod 8)\n"
             "out = []\n"
             "for space in ('YCbCr', 'ICtCp'):\n"
             "    enc = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), (4, 64))).compress_batch(x)\n"
@@ -569,9 +570,9 @@ def test_tiled_planes_give_the_same_bytes():
     res = {}
     for tiled in (False, True):
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        env.pop("AEJ_PLANES_TILED", None)
-        if tiled:
-            env["AEJ_PLANES_TILED"] = "1"
+        env.pop("AEJ_PLANES_ROW_MAJOR", None)
+        if not tiled:
+            env["AEJ_PLANES_ROW_MAJOR"] = "1"
         r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600, cwd=root)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
         assert r.returncode == 0 and line, r.stderr[-2000:]
