@@ -7,7 +7,7 @@ namespace aej {
 // color.hip
 int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out, long long n);
 // whether the encode path may keep this geometry's normalised planes in 4 x 4 blocks (Geom::tiled): the strip kernel writes them, every DCT kernel reads both forms
-bool color_planes_can_tile(const Geom &g, bool in_u8);
+bool color_planes_can_tile(const Geom &g, int space, bool in_u8);
 int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                         float *raw, float *norm, unsigned char *u8, int *tile_hist);
 // tables of cv.resize(INTER_AREA) for the chroma layers when the ratios are not exact 2x2 (device arrays)

@@ -1125,7 +1125,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     if (nsub == 1) {
         EncodePart &p = pd.parts[0];
         p.g = g; p.coeffs = coeffs; p.dct = dct_f32; p.stream = user; p.flag = user_flag; p.n_spec = 0; p.used = true; p.whole_call = true;
-        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, in_u8);
+        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8);
         carve_encode(workspace, g, q, p.w);
         if (p.w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", p.w.bytes, (unsigned long long)workspace_bytes);
         apply_canny_params(ctx, p.w.canny.cb);
@@ -1172,7 +1172,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         const int b0 = (int)((long long)g.B * i / nsub), b1 = (int)((long long)g.B * (i + 1) / nsub);
         p.g = g;
         p.g.B = b1 - b0;
-        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, in_u8);      // (decided per part: the strip height depends on the part's batch)
+        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8);      // (decided per part: the strip height depends on the part's batch)
         p.n_spec = 0;
         carve_encode(static_cast<char *>(workspace) + (size_t)i * slice, p.g, q, p.w);
         apply_canny_params(ctx, p.w.canny.cb);

@@ -742,8 +742,11 @@ static bool strip_shape(const Geom &g, int &nxb, int &rows)
 // On by default; AEJ_PLANES_ROW_MAJOR (read once) keeps the planes row-major.  64 x 4K: `k_dct4` / `k_dct8_shfl` 0.285 / 0.225 -> 0.23 / 0.163 ms (every
 // leaf is whole sectors; 1.35 GB less read per call), the colour stage 2.12 -> 2.15 ms.  (Written piecewise -- 16 bytes per lane at a 64-byte
 // stride, four times the memory transactions of a row -- the colour stage took 2.5 ms: hence the staging in LDS.)
-bool color_planes_can_tile(const Geom &g, bool in_u8)
+bool color_planes_can_tile(const Geom &g, int space, bool in_u8)
 {
+    // (the spaces with float64 pows -- OKLAB, ICtCp, ICaCb, JzAzBz -- are arithmetic-bound in the colour stage: the staging costs them 0.15-0.2 ms per
+    // 8 x 8K / 16 x 4K, the small-block DCTs gain 0.03: row-major)
+    if (space >= 3) return false;
     // (8-bit input: the colour stage reads a quarter of the bytes and is no longer hidden behind them -- the staging costs it 0.26 ms per 64 x 4K,
     // more than the small-block DCTs gain: row-major)
     if (in_u8) return false;
@@ -804,7 +807,7 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
 int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
                         float *raw, float *norm, unsigned char *u8, int *hist)
 {
-    if (g.tiled && (!color_planes_can_tile(g, in_u8) || !(norm && u8 && hist && !raw))) return -1;       // only the encode path's strip kernel writes the tiled form
+    if (g.tiled && (!color_planes_can_tile(g, space, in_u8) || !(norm && u8 && hist && !raw))) return -1;       // only the encode path's strip kernel writes the tiled form
     NormConst nc;
     for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
     switch (space) {

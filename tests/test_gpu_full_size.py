@@ -549,8 +549,7 @@ def test_both_64x64_dct_kernels_agree():
 def test_tiled_planes_give_the_same_bytes():
     """The normalised planes of strip-kernel shapes are kept in 4 x 4 blocks (Geom::tiled: the colour kernel stages its rows in LDS and writes
     whole blocks, every DCT kernel's loads change their addressing); AEJ_PLANES_ROW_MAJOR keeps them row-major.  Read once per process, so the
-    two layouts run in processes of their own: same bytes, for a batch large enough for the strip kernel's 32- / 64-row strips, in a 2 x 2 and
-    in a 1 x 4 chroma space, with planes that clip 64 x 64 leaves and CLAHE tiles 4 (mod 8) rows high (chroma blocks split between half-waves)."""
+    two layouts run in processes of their own: same bytes, for a batch large enough for the strip kernel's 32- / 64-row strips, in two of the matrix colour spaces (the ones that use it), with planes that clip 64 x 64 leaves and CLAHE tiles 4 (mod 8) rows high (chroma blocks split between half-waves)."""
     import os
     import subprocess
     import sys
@@ -558,7 +557,7 @@ def test_tiled_planes_give_the_same_bytes():
     prog = ("import hashlib, torch, bench, adaptive_edge_aware_jpeg_amd as A\n"
             "x = bench.synth_batch(torch, 12, 1072, 1920, 11, torch.device('cuda', 0))      # 1072 / 4 = 268 = 4 (mod 8)\n"
             "out = []\n"
-            "for space in ('YCbCr', 'ICtCp'):\n"
+            "for space in ('YCbCr', 'YCoCg-R'):\n"
             "    enc = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), (4, 64))).compress_batch(x)\n"
             "    h = hashlib.sha256()\n"
             "    for b in (0, 5, 11):\n"
