@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256) void k_clahe_lut(Geom g, const int *__restrict
 // Every float operation per pixel is the same single IEEE operation in the same order as before (and as the CPU oracle).
 // ------------------------------------------------------------------------------------------------
 // Workgroup shape.  Alone, 512 threads on 128 x 64 tiles (two workgroups per CU, 128 VGPRs with ~40 dwords of spills, 9 % halo) is the
-// fastest: 2.19 ms against 2.32 ms for 256 threads on 128 x 32 tiles (three workgroups per CU, 168 VGPRs, 16 % halo).  But this kernel
+// fastest (round 2: 2.19 ms against 2.32 ms for 256 threads on 128 x 32 tiles -- three workgroups per CU, 16 % halo).  But this kernel
 // never runs alone in the throughput path -- it shares the chip with the HBM-bound stages of other sub-batches -- and
-// there the smaller footprint wins: resources change hands in units of 51 KiB LDS / one wave per SIMD instead of 77 KiB / two, and the
+// there the smaller footprint wins: resources change hands in units of a third of the LDS / one wave per SIMD instead of a half / two, and the
 // 64 x 4K step goes from 7.50 to 7.33 ms (256 threads on 128 x 64 tiles, 235 VGPRs: 7.44; 384 threads on 128 x 48: 3.8 ms alone).
 constexpr int kBT = 256;                  // threads per workgroup
 constexpr int kBTW = 128, kBTH = 32;      // output tile
@@ -303,7 +303,7 @@ extern "C" __attribute__((visibility("default"))) int aej_debug_read_blur_stamps
 #define AEJ_BSTAMP(i)
 #endif
 
-__global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD: 168 VGPRs
+__global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD (145 VGPRs), 39.5 KiB LDS
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;

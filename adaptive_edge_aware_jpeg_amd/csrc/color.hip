@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_color_planes(const IN *__restrict__ rgb
 //     LDS base -- no tile test per update; columns that meet no edge use the two slots as lane-striped copies (odd stride: equal
 //     values of neighbouring pixels land in different banks);
 //   * the kernel's footprint is small on purpose -- 6 KiB of LDS, at most 56 VGPRs -- so that one of its workgroups fits on a CU
-//     beside three resident workgroups of the blur kernel (3 x 152 VGPRs per SIMD, 3 x 50.5 KiB): the HBM-bound stage of one chain
+//     beside three resident workgroups of the blur kernel (3 x 152 VGPRs per SIMD, 3 x 39.5 KiB; with the tiled planes' staging this kernel takes 38 KiB of what is left): the HBM-bound stage of one chain
 //     then really shares SIMDs with the issue-bound stage of another.
 // Per-pixel arithmetic is the same sequence of single IEEE operations as k_color_planes.
 // ------------------------------------------------------------------------------------------------
