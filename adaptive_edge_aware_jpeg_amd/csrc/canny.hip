@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
 #endif
     blur_prefetch(src, w, h, tx_begin * kBTW, y0, is_aligned(tx_begin), raw);      // flies while the per-strip tables are built
 
-    // ---- per-strip set-up
+    // ---- per-strip set-up (the two rounds of the table loop unrolled: their global loads overlap instead of following each other)
+    static_assert(512 % kBT == 0, "weight table set-up assumes whole rounds");
+#pragma unroll
     for (int i = tid; i < 512; i += kBT) {
         const int d = i - 256;
         const float cwv = i == 0 ? 0.f : cb.color_w[d < 0 ? -d : d];     // slot 0 (d = -256) is never addressed
@@ -1243,14 +1245,24 @@ __device__ __forceinline__ void hyst_pass_body(const Geom &g, const CannyBuffers
             if (!hasB) Bm = 0;
             if (!__any(W != 0ull)) break;        // no candidate pixel in the tile: nothing can change here
             const unsigned long long S0 = S;
+            // the rows above / below come from the neighbouring lanes by DPP whole-wave shifts (one vector instruction per 32 bits; lane 0 /
+            // 63 keep the `old` operand = the halo row) instead of `__shfl` (ds_bpermute: an LDS round trip in the loop's dependence chain);
+            // the left / right halo columns do not change inside the loop, so their part of the mask is formed once
+            auto row_above = [&](unsigned long long v, unsigned long long halo) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)halo, (int)(unsigned)v, 0x138, 0xf, 0xf, false);          // wave_shr:1
+                const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(halo >> 32), (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+                return ((unsigned long long)hi << 32) | lo;
+            };
+            auto row_below = [&](unsigned long long v, unsigned long long halo) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)halo, (int)(unsigned)v, 0x130, 0xf, 0xf, false);          // wave_shl:1
+                const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(halo >> 32), (int)(unsigned)(v >> 32), 0x130, 0xf, 0xf, false);
+                return ((unsigned long long)hi << 32) | lo;
+            };
+            const unsigned long long edge = (SL | row_above(SL, Tl) | row_below(SL, Bl)) | ((SR | row_above(SR, Tr) | row_below(SR, Br)) << 63);
             for (;;) {
-                unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
-                unsigned long long upL = __shfl_up(SL, 1), dnL = __shfl_down(SL, 1);
-                unsigned long long upR = __shfl_up(SR, 1), dnR = __shfl_down(SR, 1);
-                if (lane == 0) { up = Tm; upL = Tl; upR = Tr; }
-                if (lane == 63) { dn = Bm; dnL = Bl; dnR = Br; }
+                const unsigned long long up = row_above(S, Tm), dn = row_below(S, Bm);
                 unsigned long long m = S | up | dn;
-                unsigned long long mm = m | (m << 1) | (m >> 1) | (SL | upL | dnL) | ((SR | upR | dnR) << 63);
+                unsigned long long mm = m | (m << 1) | (m >> 1) | edge;
                 unsigned long long seed = W & mm & ~S;
                 unsigned long long f = fill_runs(seed, W);
                 unsigned long long nS = S | f;
