@@ -1150,16 +1150,20 @@ template <bool L2>
 __global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles)
 {
     const int lane = threadIdx.x & 63;
-    const long long T = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (T >= total_tiles) return;
-    const int b = (int)(T / tiles_per_img);
+    // the tile index as a 32-bit SCALAR (wave index through readfirstlane): the division by the tiles per image, the walk over the layers and
+    // the tile's base addresses are then scalar work, not a 64-bit vector division per wave
+    const int T = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if ((long long)T >= total_tiles) return;
+    const int tpi = (int)tiles_per_img;
+    const int b = T / tpi;
     int l, tx, ty, ntx, nty, tbase;
-    if (!locate_tile(g, kHystTile, kHystTile, (int)(T - (long long)b * tiles_per_img), l, tx, ty, ntx, nty, tbase)) return;
-    const int w = g.w[l], h = g.h[l], wpr = g.wpr[l];
-    const unsigned char *src = cb.u8b + (long long)b * g.pstride + g.poff[l];
+    if (!locate_tile(g, kHystTile, kHystTile, T - b * tpi, l, tx, ty, ntx, nty, tbase)) return;
+    const int w = l == 0 ? g.w[0] : l == 1 ? g.w[1] : g.w[2], h = l == 0 ? g.h[0] : l == 1 ? g.h[1] : g.h[2], wpr = l == 0 ? g.wpr[0] : l == 1 ? g.wpr[1] : g.wpr[2];
+    const long long poff_l = l == 0 ? g.poff[0] : l == 1 ? g.poff[1] : g.poff[2], bpoff_l = l == 0 ? g.bpoff[0] : l == 1 ? g.bpoff[1] : g.bpoff[2];
+    const unsigned char *src = cb.u8b + (long long)b * g.pstride + poff_l;
     const int low = cb.thr[((long long)b * 3 + l) * 2], high = cb.thr[((long long)b * 3 + l) * 2 + 1];
-    unsigned short *wk16 = reinterpret_cast<unsigned short *>(cb.weak + (long long)b * g.bpstride + g.bpoff[l]);
-    unsigned short *sg16 = reinterpret_cast<unsigned short *>(cb.strong + (long long)b * g.bpstride + g.bpoff[l]);
+    unsigned short *wk16 = reinterpret_cast<unsigned short *>(cb.weak + (long long)b * g.bpstride + bpoff_l);
+    unsigned short *sg16 = reinterpret_cast<unsigned short *>(cb.strong + (long long)b * g.bpstride + bpoff_l);
     const long long bp_tile = bp_index(ty * 64, tx, wpr);
     // tiles whose 68 x 68 source window leaves the plane: clamped loads (BORDER_REPLICATE), magnitudes outside the image are 0
     const bool edge_tile = tx == 0 || tx * 64 + 68 > w || ty == 0 || ty * 64 + 66 > h;

@@ -1,0 +1,8 @@
+run() { env $1 python3 bench.py --no-cpu-baseline --no-verify --steps 20 --warmup 4 2>/dev/null | python3 -c "
+import json,sys
+d=json.load(sys.stdin)
+print('[$1]:', d['ms_per_step'], 'ms/step; blocking', d['pipeline']['serial_ms_per_step'])"; }
+for rep in 0 1 2; do
+run "A=1"
+run "AEJ_LIBRARY=build/variants/sobscalar/libaejpeg_hip.so"
+done
