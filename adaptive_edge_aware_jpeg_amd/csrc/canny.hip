@@ -303,6 +303,10 @@ extern "C" __attribute__((visibility("default"))) int aej_debug_read_blur_stamps
 #define AEJ_BSTAMP(i)
 #endif
 
+// DUMP: the test hooks that copy the CLAHE / Gaussian intermediates out (aej_canny's stage outputs); the production instantiation does not
+// carry their pointers -- four scalar registers that, live across the tile loop, tipped the kernel into scalar-register spills, and a
+// spilled scalar costs a VECTOR register (145 -> 144: one allocation granule, 24 more free registers per SIMD lane beside three workgroups)
+template <bool DUMP>
 __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD (145 VGPRs), 39.5 KiB LDS
 {
     __shared__ BlurLds L;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         if (tx + 1 < tx_end) blur_prefetch(src, w, h, (tx + 1) * kBTW, y0, is_aligned(tx + 1), raw);
         __syncthreads();
         AEJ_BSTAMP(3)
-        if (cb.dump_clahe)
+        if (DUMP && cb.dump_clahe)
             for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
                 int j = idx / kBTW, i = idx - j * kBTW;
                 if (x0 + i < w && y0 + j < h)
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         AEJ_BSTAMP(4)
         __syncthreads();
         AEJ_BSTAMP(5)
-        if (cb.dump_gauss)
+        if (DUMP && cb.dump_gauss)
             for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
                 int j = idx / kBTW, i = idx - j * kBTW;
                 if (x0 + i < w && y0 + j < h)
@@ -1453,7 +1457,10 @@ static int pick_strip(const Geom &g, int TW, int TH, int strip_max, long long wa
 void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
     const int strip = pick_strip(g, kBTW, kBTH, kBStripMax, 1024);       // 256 CUs x 2 resident workgroups x 2
-    hipLaunchKernelGGL(k_clahe_blur, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), AEJ_X_BLUR_DYNLDS, st, g, cb, strip);
+    if (cb.dump_clahe || cb.dump_gauss)
+        hipLaunchKernelGGL(k_clahe_blur<true>, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), AEJ_X_BLUR_DYNLDS, st, g, cb, strip);
+    else
+        hipLaunchKernelGGL(k_clahe_blur<false>, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), AEJ_X_BLUR_DYNLDS, st, g, cb, strip);
 }
 
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
