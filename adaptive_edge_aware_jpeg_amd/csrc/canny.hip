@@ -307,7 +307,7 @@ extern "C" __attribute__((visibility("default"))) int aej_debug_read_blur_stamps
 // carry their pointers -- four scalar registers that, live across the tile loop, tipped the kernel into scalar-register spills, and a
 // spilled scalar costs a VECTOR register (145 -> 144: one allocation granule, 24 more free registers per SIMD lane beside three workgroups)
 template <bool DUMP>
-__global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD (145 VGPRs), 39.5 KiB LDS
+__global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD (136 VGPRs), 39.5 KiB LDS
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;
@@ -1148,7 +1148,7 @@ __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__
 }
 
 #ifndef AEJ_X_SOBEL_MINW
-#define AEJ_X_SOBEL_MINW 4
+#define AEJ_X_SOBEL_MINW 5             // register budget for five waves per SIMD: 96 registers, no spills (99 = four waves when left to the compiler): 0.865 -> 0.78 ms
 #endif
 template <bool L2>
 __global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles)
