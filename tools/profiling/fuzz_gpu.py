@@ -1,12 +1,12 @@
 """Randomised parity sweep (GPU box, manual): random sizes / colour spaces / block ranges / image kinds, whole encode and decode
-against the oracle.  python tests/fuzz_gpu.py [n_cases] [seed]"""
+against the oracle.  python tools/profiling/fuzz_gpu.py [n_cases] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import adaptive_edge_aware_jpeg_amd as A          # noqa: E402
 from oracle import oracle as O                     # noqa: E402
 
