@@ -4,7 +4,7 @@ import hashlib
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch                                      # noqa: E402
 import bench                                      # noqa: E402
 import adaptive_edge_aware_jpeg_amd as A          # noqa: E402

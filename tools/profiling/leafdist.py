@@ -1,6 +1,6 @@
 """diagnostic (GPU box): area share of each leaf size on the bench workload"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 import bench, adaptive_edge_aware_jpeg_amd as A
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
