@@ -1,5 +1,5 @@
 """Randomised parity sweep (GPU box, manual): random sizes / colour spaces / block ranges / image kinds, whole encode and decode
-against the oracle.  python tools/profiling/fuzz_gpu.py [n_cases] [seed]"""
+against the oracle.  python tests/manual/fuzz_gpu.py [n_cases] [seed]"""
 import os
 import sys
 import time

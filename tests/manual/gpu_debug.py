@@ -1,9 +1,9 @@
 """Ad-hoc stage-by-stage GPU-vs-oracle report (not a pytest file). Run on the GPU box:
-    python tests/gpu_debug.py > gpurun_out/debug.log 2>&1
+    python tests/manual/gpu_debug.py > gpurun_out/debug.log 2>&1
 """
 import ctypes, os, sys, time, traceback
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import adaptive_edge_aware_jpeg_amd as A

@@ -339,7 +339,7 @@ def test_begin_end_on_two_contexts(env, oracle):
 
 
 def test_randomised_parity_sweep(env, oracle):
-    """A bounded, seeded slice of tools/profiling/fuzz_gpu.py inside the suite: random sizes (ragged and aligned), colour spaces,
+    """A bounded, seeded slice of tests/manual/fuzz_gpu.py inside the suite: random sizes (ragged and aligned), colour spaces,
     block ranges, quality ranges and image kinds (8-bit levels and arbitrary floats) -- whole encode and decode against the oracle."""
     torch, A, bench = env
     rng = np.random.default_rng(20250718)

@@ -1,5 +1,5 @@
 """manual (GPU box): the bench workload encoded repeatedly must give identical outputs (hysteresis chase passes race by design;
-the fix-point must not depend on the interleaving).  python tests/determinism_gpu.py [reps]"""
+the fix-point must not depend on the interleaving).  python tools/profiling/determinism_gpu.py [reps]"""
 import hashlib
 import os
 import sys

@@ -13,6 +13,6 @@ b)
   python3 bench.py --steps 20 > gpurun_out/cycle_bench.json 2> gpurun_out/cycle_bench.err; echo "bench done"
   python3 bench.py --steps 20 --data natural > gpurun_out/cycle_bench_natural.json 2> gpurun_out/cycle_bench_natural.err; echo "bench natural done"
   bash tools/profiling/configs.sh > gpurun_out/cycle_configs.txt 2>&1; echo "configs done"
-  python3 tools/profiling/fuzz_gpu.py > gpurun_out/cycle_fuzz.txt 2>&1; tail -2 gpurun_out/cycle_fuzz.txt
+  python3 tests/manual/fuzz_gpu.py > gpurun_out/cycle_fuzz.txt 2>&1; tail -2 gpurun_out/cycle_fuzz.txt
   ;;
 esac
