@@ -305,7 +305,8 @@ extern "C" __attribute__((visibility("default"))) int aej_debug_read_blur_stamps
 
 // DUMP: the test hooks that copy the CLAHE / Gaussian intermediates out (aej_canny's stage outputs); the production instantiation does not
 // carry their pointers -- four scalar registers that, live across the tile loop, tipped the kernel into scalar-register spills, and a
-// spilled scalar costs a VECTOR register (145 -> 144: one allocation granule, 24 more free registers per SIMD lane beside three workgroups)
+// spilled scalar lives in a lane of a VECTOR register (v144 held nothing else).  Without them the kernel needs 136 vector registers
+// instead of 145: a 136- instead of a 152-register allocation, 104 instead of 56 free registers per SIMD lane beside three workgroups
 template <bool DUMP>
 __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD (136 VGPRs), 39.5 KiB LDS
 {
