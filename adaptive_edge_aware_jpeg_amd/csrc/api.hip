@@ -647,7 +647,7 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool specula
     return 0;
 }
 
-// Diagnostic only (tools/profiling/graph_dbg.py): AEJ_GRAPH_NODES=all-and-it-faults captures the runtime's memset / memcpy nodes as
+// Diagnostic only (tests/manual/graph_dbg.py): AEJ_GRAPH_NODES=all-and-it-faults captures the runtime's memset / memcpy nodes as
 // round 2's first graph did and prints every address the graph holds.  ON ROCm 7.2 THIS FAULTS on the second replay inside a PyTorch
 // process ("Memory access fault by GPU ... on address 0x7d011bbc3000", profiles/r03_graph_memcpy_nodes_fault.txt): the address lies in
 // none of the buffers the library captured (pinned flag words, workspace, tables, inputs, outputs -- all printed beside it), i.e. it
