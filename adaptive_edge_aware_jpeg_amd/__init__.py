@@ -5,12 +5,12 @@ Same Python surface as the reference for this path (fevzibabaoglu/adaptive-edge-
 ``apply_normalization``, ``get_color_spaces``.  The arithmetic runs in hand-written HIP kernels behind the
 C ABI of ``libaejpeg_hip.so`` (include/aej.h); there is no CPU fallback.
 """
-from ._lib import hw_queues, request_hw_queues as _request_hw_queues, set_hw_queues
+from ._lib import _look_at_hw_queues, configure_hw_queues, hw_queues, set_hw_queues
 
 # Streams beyond the HIP runtime's hardware queues share queues and serialise; the library's overlap of sub-batches and calls wants a
-# queue per stream.  The policy (and why importing this package after HIP has initialised changes nothing in the environment) is
-# written down in _lib.py; `hw_queues()` reports what the library schedules for and `set_hw_queues(n)` overrides it.
-_request_hw_queues()
+# queue per stream.  Importing this package only LOOKS at GPU_MAX_HW_QUEUES (it never writes the environment); `configure_hw_queues()`
+# is the explicit opt-in, `hw_queues()` reports what the library schedules for, `set_hw_queues(n)` states it (policy: _lib.py).
+_look_at_hw_queues()
 
 from .color import apply_normalization, convert, get_color_spaces  # noqa: E402
 from .edge_detection import EdgeDetection  # noqa: E402
@@ -21,4 +21,4 @@ from .quadtree import QuadNode, QuadTree  # noqa: E402
 from .settings import JpegCompressionSettings  # noqa: E402
 
 __all__ = ["Jpeg", "JpegCompressionSettings", "EncodedBatch", "Image", "EvaluationMetrics", "EdgeDetection", "QuadTree", "QuadNode",
-           "convert", "apply_normalization", "get_color_spaces", "hw_queues", "set_hw_queues"]
+           "convert", "apply_normalization", "get_color_spaces", "hw_queues", "set_hw_queues", "configure_hw_queues"]

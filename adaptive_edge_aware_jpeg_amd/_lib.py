@@ -42,26 +42,21 @@ _lib_lock = threading.Lock()
 # ---- hardware queues ------------------------------------------------------------------------------------------------
 # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue run one after the other.
 # The library overlaps sub-batches and calls on several streams and picks its schedule by the number of queues --
-# which only the host can know: the runtime reads the variable once, when it initialises (any HIP call does that, torch.cuda.is_available()
-# included -- and nothing tells a later importer whether it has happened; torch.cuda.is_initialized() only speaks for torch's own lazy
-# initialisation).  Policy, from sure to unsure:
-#   * the variable is ALREADY in the environment when this package is imported (set by the launcher, or by a script before it imported
-#     torch, as bench.py does): that is what the runtime starts with -- trust its value, change nothing;
-#   * the variable is absent and torch has not even been imported: HIP cannot have initialised through it -- ask for 16 queues (unless
-#     AEJ_KEEP_HW_QUEUES=1 forbids touching the environment) and trust that;
-#   * the variable is absent and torch is imported: HIP may or may not be up.  Setting the variable can still help and cannot hurt
-#     (done unless torch says it is initialised, or AEJ_KEEP_HW_QUEUES=1), but it is NOT trusted: the library is told HIP's default of 4
-#     (its conservative two-sub-batch schedule) unless the application states the value with set_hw_queues().
+# which only the host can know: the runtime reads the variable once, when it initialises (any HIP call does that,
+# torch.cuda.is_available() included).  IMPORTING THIS PACKAGE CHANGES NOTHING IN THE PROCESS: it only looks.
+#   * the variable is in the environment when the package is imported (set by the launcher, or by a script before it imported torch,
+#     as bench.py does): that is what the runtime starts with -- its value is what the library is told;
+#   * otherwise the library is told HIP's default of 4 (its conservative two-sub-batch schedule).  An application that wants the wide
+#     schedule calls configure_hw_queues() BEFORE anything initialises HIP (it sets the variable, explicitly, at the caller's request),
+#     or states the value its runtime really started with through set_hw_queues().
 HIP_DEFAULT_HW_QUEUES = 4
 _hw_queues = HIP_DEFAULT_HW_QUEUES
 _hw_queues_source = "HIP default (assumed)"
 
 
-def request_hw_queues(want=16):
-    """Called once at package import (see the policy above)."""
+def _look_at_hw_queues():
+    """Called once at package import: read-only (see the policy above)."""
     global _hw_queues, _hw_queues_source
-    import sys
-    keep = bool(os.environ.get("AEJ_KEEP_HW_QUEUES"))
     present = os.environ.get("GPU_MAX_HW_QUEUES")
     if present is not None:
         try:
@@ -69,21 +64,31 @@ def request_hw_queues(want=16):
         except ValueError:
             v = 0
         if v > 0:
-            _hw_queues, _hw_queues_source = v, "GPU_MAX_HW_QUEUES was already in the environment when the package was imported"
-        return _hw_queues
+            _hw_queues, _hw_queues_source = v, "GPU_MAX_HW_QUEUES was in the environment when the package was imported"
+    return _hw_queues
+
+
+def configure_hw_queues(want=16):
+    """Explicit opt-in, to be called before the process's first HIP call (before `import torch` to be sure): puts
+    GPU_MAX_HW_QUEUES=<want> into this process's environment so that every stream of the library gets a hardware queue of its own, and
+    tells the library.  If torch is already imported the variable may have been read already: it is still set (it cannot hurt) but the
+    library keeps assuming HIP's default unless torch says HIP is not up yet.  Returns the queue count the library will schedule for."""
+    global _hw_queues, _hw_queues_source
+    import sys
+    if os.environ.get("GPU_MAX_HW_QUEUES") is not None:
+        return _look_at_hw_queues()
     torch = sys.modules.get("torch")
-    if torch is None:
-        if not keep:
-            os.environ["GPU_MAX_HW_QUEUES"] = str(want)
-            _hw_queues, _hw_queues_source = want, "set at import, before torch (and with it HIP) was loaded"
-        return _hw_queues
-    try:
-        torch_up = bool(torch.cuda.is_initialized())
-    except Exception:
-        torch_up = True
-    if not keep and not torch_up:
-        os.environ["GPU_MAX_HW_QUEUES"] = str(want)          # may still take effect; not relied upon
-    _hw_queues, _hw_queues_source = HIP_DEFAULT_HW_QUEUES, "torch was imported before this package and the variable was absent: HIP's default assumed"
+    trusted = torch is None
+    if torch is not None:
+        try:
+            trusted = not bool(torch.cuda.is_initialized())
+        except Exception:
+            trusted = False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(want))
+    if trusted:
+        _hw_queues, _hw_queues_source = int(want), "configure_hw_queues() before HIP initialised"
+        for ctx in _contexts.values():
+            ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, _hw_queues))
     return _hw_queues
 
 
@@ -122,7 +127,9 @@ SIGNATURES = {
     "aej_set_sub_batches": (_I, [_P, _I]),
     "aej_set_hw_queues": (_I, [_P, _I]),
     "aej_get_schedule_host": (_I, [_P, _I, _I, _I, _P]),
-    "aej_test_fail_after_stage": (_I, [_P, _I]),
+    "aej_set_option": (_I, [_P, ctypes.c_char_p, _I64]),
+    "aej_get_option": (_I, [_P, ctypes.c_char_p, _P]),
+    "aej_test_fail_after_stage": (_I, [_P, _I]),            # include/aej_testing.h (tests only)
     "aej_encode_batch_begin": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _U64]),
     "aej_encode_batch_end": (_I, [_P]),
     "aej_get_split_calls": (ctypes.c_int64, [_P]),
@@ -263,6 +270,15 @@ class Context:
         buf = (ctypes.c_int32 * 4)()
         self.check(self.lib.aej_get_schedule_host(self.handle, int(batch), int(H), int(W), ctypes.cast(buf, ctypes.c_void_p)))
         return {"hw_queues": int(buf[0]), "sub_batches": int(buf[1]), "limited_by_hw_queues": bool(buf[2]), "hw_queues_source": _hw_queues_source}
+
+    def set_option(self, name, value):
+        """aej_set_option: the library's tuning / A-B choices (table in include/aej.h); it reads no environment variable."""
+        self.check(self.lib.aej_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int64()
+        self.check(self.lib.aej_get_option(self.handle, name.encode(), ctypes.cast(ctypes.pointer(v), ctypes.c_void_p)))
+        return int(v.value)
 
     def split_calls(self):
         return int(self.lib.aej_get_split_calls(self.handle))

@@ -52,6 +52,18 @@ struct QtGeom {
     int nsizes;
     long long work_off[3][kMaxSizes], work_stride[kMaxSizes];
 };
+// Per-context tuning / A-B options (aej_set_option, include/aej.h): the only way a caller changes which kernel or launch shape serves a
+// stage.  Nothing in the library reads the environment.
+struct Tuning {
+    int color_strip = 1;           // "color_strip": 0 = never the persistent strip colour kernel (the 128 x 16 kernel of rounds 1-2 instead)
+    int color_strip_rows = 0;      // "color_strip_rows": strip height of that kernel, 0 = automatic (16 .. 64 by batch size)
+    int color_workgroups = 0;      // "color_workgroups": workgroups of the persistent launch, 0 = automatic (256 for the matrix spaces)
+    int planes_row_major = 0;      // "planes_row_major": 1 = keep the normalised planes row-major (default: 4 x 4 blocks where the strip kernel can write them)
+    int dct64_kernel = 0;          // "dct64_kernel": 0 = by company (DctArgs::crowded), 1 = one wave per leaf, 4 = four waves per leaf
+    int dct_small_workgroups = 0;  // "dct_small_workgroups": cap on the grids of the 4 / 8 / 16 kernels, 0 = automatic
+    int sobel_lds = 0;             // "sobel_lds": 1 = the LDS-tiled Sobel / NMS kernel of rounds 1-2 for every shape
+};
+
 constexpr int kChunkInts = 4 + kMaxSizes;   // per-chunk record: nsym, nleaf, ncoef, pad, leaves per size
 constexpr int kMaxPlanes = 3072;            // planes (3 x images) one DCT launch can address
 

@@ -7,9 +7,9 @@ namespace aej {
 // color.hip
 int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out, long long n);
 // whether the encode path may keep this geometry's normalised planes in 4 x 4 blocks (Geom::tiled): the strip kernel writes them, every DCT kernel reads both forms
-bool color_planes_can_tile(const Geom &g, int space, bool in_u8);
+bool color_planes_can_tile(const Geom &g, int space, bool in_u8, const Tuning &t);
 int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
-                        float *raw, float *norm, unsigned char *u8, int *tile_hist);
+                        float *raw, float *norm, unsigned char *u8, int *tile_hist, const Tuning &t);
 // tables of cv.resize(INTER_AREA) for the chroma layers when the ratios are not exact 2x2 (device arrays)
 struct AreaTabs {
     int mode;                  // 0: exact 2x2, 1: other integer ratios (isx, isy), 2: general tables
@@ -49,7 +49,7 @@ void launch_clahe_pad_hist(hipStream_t st, const Geom &g, const CannyBuffers &cb
 void launch_clahe_lut(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb);
-void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb);
+void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, const Tuning &t);
 void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass);
 void launch_hyst_finish(hipStream_t st, const Geom &g, const CannyBuffers &cb, int first_pass);   // one workgroup: passes first_pass .. fix-point
 constexpr long long kHystFinishTiles = 4096;   // problems of at most this many 64x64 tiles finish their hysteresis inside one launch
@@ -97,7 +97,7 @@ struct DctArgs {
     const int *qm[3];         // [s*s] per layer
     int crowded = 0;          // other kernels are expected beside this launch (sub-batches, calls in flight): prefer kernels that share a CU
 };
-int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items);   // 0, or -1 when no kernel serves the request
+int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const Tuning &t);   // 0, or -1 when no kernel serves the request
 // builds a work list from a leaf table (stand-alone aej_dct_quant_zigzag)
 void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int bmin, int plane, LeafWork *const *work, int *work_count);
 

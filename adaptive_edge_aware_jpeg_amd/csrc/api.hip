@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/aej.h"
+#include "../../include/aej_testing.h"
 #include "aej_common.h"
 #include "aej_launch.h"
 
@@ -69,15 +70,10 @@ struct aej_ctx {
     int sub_chain = -1;                // colour stages wait for a stage of the previous part (g_last_color_done): 1 its colour stage, 2 its blur, 3 its
                                        // Sobel / NMS; 0 no staggering; -1 (default) = 1 between the sub-batches of one call, 2 between whole calls --
                                        // measured best of each (64 x 4K: sub-batches 8.1 / 8.35 / 8.35 / 8.4 ms for 1 / 2 / 3 / 0, two contexts
-                                       // 8.0 / 7.8 / 7.9 / 8.4).  AEJ_SUB_CHAIN overrides (tuning knob).
+                                       // 8.0 / 7.8 / 7.9 / 8.4).  aej_set_option "sub_chain" overrides.
     int chain_hook = 0;                // run_canny_chain publishes chain_event after the blur (2) / Sobel (3) stage of the part being enqueued
     hipEvent_t chain_event = nullptr;
-    // per-stage serialisation across parts (stage_mask, AEJ_STAGE_CHAIN): bit 0 blur, bit 1 Sobel / NMS, bit 2 DCT -- a part's kernel of such a
-    // stage waits for the same stage of the part enqueued before it (any context): two issue-bound kernels of one kind gain nothing from
-    // sharing the chip, they only dilate each other
-    int stage_mask = 0;
-    hipEvent_t stage_ev[kMaxSub][3] = {};
-    hipEvent_t *cur_stage_ev = nullptr;     // the three events of the part being enqueued (null: not chained)
+    Tuning tune;                       // aej_set_option: kernel / launch-shape choices (nothing in the library reads the environment)
     struct aej_pending *pending = nullptr;     // the call between aej_encode_batch_begin and aej_encode_batch_end
     // optional stage timing (aej_set_profiling): events on ctx->stream around each stage of aej_encode_batch
     bool profiling = false;
@@ -139,23 +135,9 @@ static void collect_marks(aej_ctx *ctx)
 // Sobel of the other).  Waiting on an event that has long completed costs nothing.
 #include <mutex>
 static std::mutex g_chain_mutex;
-static hipEvent_t g_last_color_done[64] = {};      // per device; owned by the context that recorded it
-static hipEvent_t g_last_stage_done[64][3] = {};   // per device and chained stage (blur, Sobel, DCT), same ownership rule
-
-// wait for the previous part's kernel of chained stage `k` / publish this part's (no-ops unless the part is chained on that stage)
-static void stage_wait(aej_ctx *ctx, int k)
-{
-    if (!ctx->cur_stage_ev || !(ctx->stage_mask & (1 << k)) || ctx->device >= 64) return;
-    std::lock_guard<std::mutex> lock(g_chain_mutex);
-    if (hipEvent_t after = g_last_stage_done[ctx->device][k]) (void)hipStreamWaitEvent(ctx->stream, after, 0);
-}
-static void stage_publish(aej_ctx *ctx, int k)
-{
-    if (!ctx->cur_stage_ev || !(ctx->stage_mask & (1 << k)) || ctx->device >= 64) return;
-    std::lock_guard<std::mutex> lock(g_chain_mutex);
-    if (hipEventRecord(ctx->cur_stage_ev[k], ctx->stream) == hipSuccess) g_last_stage_done[ctx->device][k] = ctx->cur_stage_ev[k];
-}
-static int g_calls_in_flight[64] = {};             // per device: calls between aej_encode_batch_begin and _end (guarded by g_chain_mutex)
+constexpr int kMaxDevices = 64;
+static hipEvent_t g_last_color_done[kMaxDevices] = {};      // per device (aej_create refuses device >= kMaxDevices); owned by the context that recorded it
+static int g_calls_in_flight[kMaxDevices] = {};             // per device: calls between aej_encode_batch_begin and _end (guarded by g_chain_mutex)
 
 static void free_pending(aej_ctx *ctx);      // defined with aej_pending
 static bool call_in_flight(const aej_ctx *ctx);
@@ -381,15 +363,12 @@ extern "C" int aej_abi_version(void) { return AEJ_ABI_VERSION; }
 extern "C" aej_ctx *aej_create(int device, void *hip_stream)
 {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || device >= kMaxDevices) return nullptr;      // (the per-device chain state below is indexed by it)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     aej_ctx *ctx = new aej_ctx();
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
-    if (const char *e = getenv("AEJ_SUB_CHAIN")) ctx->sub_chain = atoi(e);
-    if (const char *e = getenv("AEJ_STAGE_CHAIN")) ctx->stage_mask = atoi(e) & 7;      // tuning knob (tools/profiling/sched_sweep.sh)
-    if (const char *e = getenv("AEJ_HYST_MARGIN")) { const int v = atoi(e); if (v >= 0 && v <= 8) ctx->hyst_margin = v; }      // tuning knob
     return ctx;
 }
 
@@ -400,16 +379,13 @@ extern "C" void aej_destroy(aej_ctx *ctx)
     if (call_in_flight(ctx)) {
         (void)hipDeviceSynchronize();
         std::lock_guard<std::mutex> lock(g_chain_mutex);
-        if (ctx->device < 64 && g_calls_in_flight[ctx->device] > 0) g_calls_in_flight[ctx->device]--;
+        if (g_calls_in_flight[ctx->device] > 0) g_calls_in_flight[ctx->device]--;
     }
     free_pending(ctx);
     {
         std::lock_guard<std::mutex> lock(g_chain_mutex);
         for (int i = 0; i < aej_ctx::kMaxSub; i++)
-            if (ctx->sub_color_done[i] && ctx->device < 64 && g_last_color_done[ctx->device] == ctx->sub_color_done[i]) g_last_color_done[ctx->device] = nullptr;
-        for (int i = 0; i < aej_ctx::kMaxSub; i++)
-            for (int k = 0; k < 3; k++)
-                if (ctx->stage_ev[i][k] && ctx->device < 64 && g_last_stage_done[ctx->device][k] == ctx->stage_ev[i][k]) g_last_stage_done[ctx->device][k] = nullptr;
+            if (ctx->sub_color_done[i] && g_last_color_done[ctx->device] == ctx->sub_color_done[i]) g_last_color_done[ctx->device] = nullptr;
     }
     drop_graphs(ctx);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
@@ -419,7 +395,6 @@ extern "C" void aej_destroy(aej_ctx *ctx)
     for (int i = 0; i < aej_ctx::kMaxSub; i++) {
         if (ctx->sub_stream[i]) (void)hipStreamDestroy(ctx->sub_stream[i]);
         if (ctx->sub_color_done[i]) (void)hipEventDestroy(ctx->sub_color_done[i]);
-        for (int k = 0; k < 3; k++) if (ctx->stage_ev[i][k]) (void)hipEventDestroy(ctx->stage_ev[i][k]);
         if (ctx->sub_flag[i]) (void)hipHostFree(ctx->sub_flag[i]);
     }
     if (ctx->sub_in) (void)hipEventDestroy(ctx->sub_in);
@@ -626,19 +601,15 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool specula
     mark(ctx, AEJ_STAGE_CLAHE_LUT);
     auto publish = [&]() {
         std::lock_guard<std::mutex> lock(g_chain_mutex);
-        if (hipEventRecord(ctx->chain_event, st) == hipSuccess && ctx->device < 64) g_last_color_done[ctx->device] = ctx->chain_event;
+        if (hipEventRecord(ctx->chain_event, st) == hipSuccess) g_last_color_done[ctx->device] = ctx->chain_event;
     };
-    stage_wait(ctx, 0);
     launch_clahe_blur(st, g, w.cb);
     mark(ctx, AEJ_STAGE_CLAHE_BLUR);
-    stage_publish(ctx, 0);
     if (ctx->chain_hook == 2) publish();
     launch_thresholds(st, g, w.cb);
     mark(ctx, AEJ_STAGE_THRESHOLDS);
-    stage_wait(ctx, 1);
-    launch_sobel_nms(st, g, w.cb);
+    launch_sobel_nms(st, g, w.cb, ctx->tune);
     mark(ctx, AEJ_STAGE_SOBEL_NMS);
-    stage_publish(ctx, 1);
     if (ctx->chain_hook == 3) publish();
     int rc = run_hysteresis(ctx, g, w, speculate);
     if (rc) return rc;
@@ -647,18 +618,12 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool specula
     return 0;
 }
 
-// Diagnostic only (tests/manual/graph_dbg.py): AEJ_GRAPH_NODES=all-and-it-faults captures the runtime's memset / memcpy nodes as
-// round 2's first graph did and prints every address the graph holds.  ON ROCm 7.2 THIS FAULTS on the second replay inside a PyTorch
-// process ("Memory access fault by GPU ... on address 0x7d011bbc3000", profiles/r03_graph_memcpy_nodes_fault.txt): the address lies in
-// none of the buffers the library captured (pinned flag words, workspace, tables, inputs, outputs -- all printed beside it), i.e. it
-// belongs to the runtime's own staging for the captured copies; the same node types replay cleanly in a stand-alone HIP program
-// (tools/ubench/graph_memcpy_replay.hip, 8 replays with pageable / pinned copies in between).  So: not a lifetime bug of this
-// library; the shipped graph holds kernel nodes only and reads its counters back with ordinary copies behind the launch.
-static bool graph_debug_all_nodes() { static const bool v = getenv("AEJ_GRAPH_NODES") && !strcmp(getenv("AEJ_GRAPH_NODES"), "all-and-it-faults"); return v; }
-
+// The zero-fills are kernels while a hipGraph is being captured: the shipped graph holds kernel nodes only (a graph that also held the
+// runtime's memset / memcpy nodes faulted on its second replay inside a PyTorch process in round 2; the record of that is
+// profiles/r03_graph_memcpy_nodes_fault.txt, the stand-alone replay of the same node types tools/ubench/graph_memcpy_replay.hip).
 static int clear_canny_ws(aej_ctx *ctx, const CannyWs &w)
 {
-    if (ctx->capturing && !graph_debug_all_nodes()) launch_zero(ctx->stream, w.zero_begin, (size_t)(w.zero_end - w.zero_begin));       // both ends are 256-byte aligned (Carver)
+    if (ctx->capturing) launch_zero(ctx->stream, w.zero_begin, (size_t)(w.zero_end - w.zero_begin));       // both ends are 256-byte aligned (Carver)
     else AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), ctx->stream));
     return 0;
 }
@@ -666,7 +631,7 @@ static int clear_canny_ws(aej_ctx *ctx, const CannyWs &w)
 static int run_quadtree(aej_ctx *ctx, const Geom &g, const QtGeom &q, QtWs &w, const unsigned long long *edge_bits)
 {
     hipStream_t st = ctx->stream;
-    if (ctx->capturing && !graph_debug_all_nodes()) launch_zero(st, w.zero_begin, (size_t)(w.zero_end - w.zero_begin));
+    if (ctx->capturing) launch_zero(st, w.zero_begin, (size_t)(w.zero_end - w.zero_begin));
     else AEJ_HIP_CHECK(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));
     w.qb.edge_bits = edge_bits;
     launch_qt_cells(st, g, q, edge_bits, w.qb);
@@ -719,7 +684,7 @@ static int run_color_planes(aej_ctx *ctx, const void *rgb, bool in_u8, const Geo
     float mid[3], scale[3];
     for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
     if (planes_fast_ok(g)) {
-        if (launch_color_planes(ctx->stream, ctx->space, rgb, in_u8, g, mid, scale, raw, norm, u8, hist)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+        if (launch_color_planes(ctx->stream, ctx->space, rgb, in_u8, g, mid, scale, raw, norm, u8, hist, ctx->tune)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
         return 0;
     }
     AreaTabs t;
@@ -824,7 +789,6 @@ static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &
     if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
     mark(ctx, AEJ_STAGE_QUADTREE);
     int k = 0;
-    stage_wait(ctx, 2);
     for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
         DctArgs a;
         a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
@@ -833,10 +797,9 @@ static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &
         a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
         a.crowded = ctx->dct_crowded;
         for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
-        if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k])) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
+        if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k], ctx->tune)) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
         mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
     }
-    stage_publish(ctx, 2);
     AEJ_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -934,7 +897,7 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
             launch_clahe_lut(st, g, w.canny.cb);
             launch_clahe_blur(st, g, w.canny.cb);
             launch_thresholds(st, g, w.canny.cb);
-            launch_sobel_nms(st, g, w.canny.cb);
+            launch_sobel_nms(st, g, w.canny.cb, ctx->tune);
             if (small) {
                 launch_hyst_pass(st, g, w.canny.cb, 0);
                 launch_hyst_finish(st, g, w.canny.cb, 1);
@@ -942,14 +905,6 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
                 for (int i = 0; i < n; i++) launch_hyst_pass(st, g, w.canny.cb, i);
             }
             rc = enqueue_back(ctx, g, q, w, coeffs, dct_f32);
-            if (!rc && graph_debug_all_nodes()) {
-                rc = enqueue_readback(ctx, w, small ? 0 : n);
-                fprintf(stderr, "aej graph capture: h_flag %p (+%zu B) canny zero [%p, %p) qt zero [%p, %p) workspace %p tables %p bilateral %p rgb %p coeffs %p leaves %p "
-                                "states %p counts %p overflow %p pass_count %p\n", (void *)ctx->h_flag, (size_t)(kMaxHystPasses + 16) * sizeof(int),
-                        (void *)w.canny.zero_begin, (void *)w.canny.zero_end, (void *)w.qt.zero_begin, (void *)w.qt.zero_end, workspace, ctx->tables,
-                        (void *)ctx->d_bilateral, rgb, (void *)coeffs, (void *)leaves, (void *)states, (void *)counts, (void *)w.qt.qb.overflow,
-                        (void *)w.canny.cb.pass_count);
-            }
         }
         hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(ctx->gstream, &graph) : hipSuccess;
         ctx->stream = user;
@@ -970,11 +925,9 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
     AEJ_HIP_CHECK(hipEventRecord(ctx->gevent, user));     // inputs produced on the caller's stream are complete before the graph reads them
     AEJ_HIP_CHECK(hipStreamWaitEvent(ctx->gstream, ctx->gevent, 0));
     AEJ_HIP_CHECK(hipGraphLaunch(hit->exec, ctx->gstream));
-    // the counter read-back stays outside the graph (ordinary copies behind it on the same stream): a graph with memcpy / memset
-    // nodes faulted on its second replay ("write access to a read-only page") whenever other device-to-host copies had run in
-    // between -- the runtime appears to recycle the staging those nodes were captured with
+    // the counter read-back stays outside the graph (ordinary copies behind it on the same stream): kernel nodes only, see clear_canny_ws
     ctx->stream = ctx->gstream;
-    const int rb = graph_debug_all_nodes() ? 0 : enqueue_readback(ctx, w, small ? 0 : n);      // (debug: the copies are nodes of the graph)
+    const int rb = enqueue_readback(ctx, w, small ? 0 : n);
     ctx->stream = user;
     if (rb) return rb;
     AEJ_HIP_CHECK(hipStreamSynchronize(ctx->gstream));
@@ -1005,7 +958,7 @@ static int sub_batches(const aej_ctx *ctx, const Geom &g, int hw_queues, bool as
             // HIP's default of 4 hardware queues: streams start to share queues (two streams on one queue run one after the other), so
             // two sub-batches, and only for a call that has the device to itself (with 4 queues: 4 sub-batches 8.4 ms, 2: 8.1 ms)
             bool alone;
-            { std::lock_guard<std::mutex> lock(g_chain_mutex); alone = ctx->device >= 64 || g_calls_in_flight[ctx->device] == 0; }
+            { std::lock_guard<std::mutex> lock(g_chain_mutex); alone = g_calls_in_flight[ctx->device] == 0; }
             n = (alone && px >= (64LL << 20) && g.B >= 8) ? 2 : 1;
         }
     }
@@ -1057,7 +1010,7 @@ static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void
     mark(ctx, AEJ_STAGE_CLEAR);
     // one stage behind the part enqueued before this one (g_last_color_done): its colour stage (HBM-bound) has finished, its blur
     // (issue-bound) is starting
-    const bool chain = ctx->sub_chain && done && ctx->device < 64 && !ctx->profiling;
+    const bool chain = ctx->sub_chain && done && !ctx->profiling;
     const int chain_mode = ctx->sub_chain > 0 ? ctx->sub_chain : (p.whole_call ? 2 : 1);
     if (chain) {
         std::lock_guard<std::mutex> lock(g_chain_mutex);
@@ -1074,14 +1027,7 @@ static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void
     };
     if (chain && chain_mode == 1 && (rc = publish())) return rc;
     // (the hook is cleared on every exit: a later stand-alone aej_canny on this context must not re-record the shared chain event)
-    struct HookGuard { aej_ctx *c; ~HookGuard() { c->chain_hook = 0; c->cur_stage_ev = nullptr; } } hook_guard{ ctx };
-    if (chain && ctx->stage_mask) {
-        int idx = 0;
-        for (int i = 0; i < aej_ctx::kMaxSub; i++) if (ctx->sub_color_done[i] == done) idx = i;
-        for (int k3 = 0; k3 < 3; k3++)
-            if (!ctx->stage_ev[idx][k3]) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_ev[idx][k3], hipEventDisableTiming));
-        ctx->cur_stage_ev = ctx->stage_ev[idx];
-    }
+    struct HookGuard { aej_ctx *c; ~HookGuard() { c->chain_hook = 0; } } hook_guard{ ctx };
     ctx->chain_hook = (chain && chain_mode > 1) ? chain_mode : 0;
     ctx->chain_event = done;
     if ((rc = run_canny_chain(ctx, p.g, p.w.canny, true))) return rc;      // first call (no hint yet): verified loop, synchronises this stream
@@ -1113,7 +1059,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     const int nsub = sub_batches(ctx, g, ctx->hw_queues);
     {
         std::lock_guard<std::mutex> lock(g_chain_mutex);
-        ctx->dct_crowded = nsub > 1 || (ctx->device < 64 && g_calls_in_flight[ctx->device] > 0);
+        ctx->dct_crowded = nsub > 1 || g_calls_in_flight[ctx->device] > 0;
     }
     // (a profiled call runs unsplit so that its stage times describe the serial chain, but with the kernels the same call uses unprofiled)
     if (ctx->profiling && sub_batches(ctx, g, ctx->hw_queues, true) > 1) ctx->dct_crowded = 1;
@@ -1125,7 +1071,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     if (nsub == 1) {
         EncodePart &p = pd.parts[0];
         p.g = g; p.coeffs = coeffs; p.dct = dct_f32; p.stream = user; p.flag = user_flag; p.n_spec = 0; p.used = true; p.whole_call = true;
-        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8);
+        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8, ctx->tune);
         carve_encode(workspace, g, q, p.w);
         if (p.w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", p.w.bytes, (unsigned long long)workspace_bytes);
         apply_canny_params(ctx, p.w.canny.cb);
@@ -1135,7 +1081,8 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         bool graphed = false;
         const bool want_graph = ctx->graph_mode != 0 && !ctx->profiling && (hyst_small(g) || (ctx->hyst_speculate && ctx->hyst_hint > 0)) && planes_fast_ok(g) &&
                                 (ctx->graph_mode == 2 || (long long)batch * H * W <= kGraphAutoPixels);
-        if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, g, q, p.w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) {
+        // (p.g, not g: capture, replay and a miss repair in encode_end_impl must share one plane layout -- Geom::tiled)
+        if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, p.g, q, p.w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) {
             if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);       // a replay whose read-back failed may still be running
             return rc;
         }
@@ -1147,7 +1094,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         // also after an error: whatever enqueue_part had already put on the stream is drained by the caller (encode_end_impl), exactly as
         // on the sub-batch path below
         pd.active = started = true;
-        { std::lock_guard<std::mutex> lock(g_chain_mutex); if (ctx->device < 64) g_calls_in_flight[ctx->device]++; }
+        { std::lock_guard<std::mutex> lock(g_chain_mutex); g_calls_in_flight[ctx->device]++; }
         return rc;
     }
 
@@ -1172,7 +1119,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         const int b0 = (int)((long long)g.B * i / nsub), b1 = (int)((long long)g.B * (i + 1) / nsub);
         p.g = g;
         p.g.B = b1 - b0;
-        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8);      // (decided per part: the strip height depends on the part's batch)
+        p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8, ctx->tune);      // (decided per part: the strip height depends on the part's batch)
         p.n_spec = 0;
         carve_encode(static_cast<char *>(workspace) + (size_t)i * slice, p.g, q, p.w);
         apply_canny_params(ctx, p.w.canny.cb);
@@ -1194,7 +1141,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
     ctx->stream = user;
     ctx->h_flag = user_flag;
     pd.active = started = true;  // also after an error: the caller drains whatever was enqueued
-    { std::lock_guard<std::mutex> lock(g_chain_mutex); if (ctx->device < 64) g_calls_in_flight[ctx->device]++; }
+    { std::lock_guard<std::mutex> lock(g_chain_mutex); g_calls_in_flight[ctx->device]++; }
     return rc;
 }
 
@@ -1206,7 +1153,7 @@ static int encode_end_impl(aej_ctx *ctx, int rc_begin)
     aej_pending &pd = pending_of(ctx);
     if (!pd.active) return rc_begin ? rc_begin : fail(ctx, AEJ_ERR_STATE, "aej_encode_batch_end without a call in flight");
     pd.active = false;
-    { std::lock_guard<std::mutex> lock(g_chain_mutex); if (ctx->device < 64 && g_calls_in_flight[ctx->device] > 0) g_calls_in_flight[ctx->device]--; }
+    { std::lock_guard<std::mutex> lock(g_chain_mutex); if (g_calls_in_flight[ctx->device] > 0) g_calls_in_flight[ctx->device]--; }
     (void)hipSetDevice(ctx->device);
     hipStream_t user = ctx->stream;
     int *user_flag = ctx->h_flag;
@@ -1353,7 +1300,7 @@ extern "C" int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t
     if (stages) AEJ_HIP_CHECK(hipMemcpyAsync(stages + 3 * n, w.cb.u8b, n, hipMemcpyDeviceToDevice, st));
     launch_thresholds(st, g, w.cb);
     if (thresholds) AEJ_HIP_CHECK(hipMemcpyAsync(thresholds, w.cb.thr, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
-    launch_sobel_nms(st, g, w.cb);
+    launch_sobel_nms(st, g, w.cb, ctx->tune);
     Geom ge = g;
     ge.pstride = n;   // uint8 outputs are exactly H*W
     if (stages) launch_bits_to_map(st, ge, w.cb.weak, w.cb.strong, stages + 4 * n);
@@ -1461,7 +1408,7 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
             a.scratch = big_scratch_floats(ctx->bmax) ? reinterpret_cast<float *>(scratch + big_off) : nullptr;
             a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
             for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
-            if (launch_dct(st, s, g, q, a, n_leaves)) { e = hipErrorInvalidValue; break; }
+            if (launch_dct(st, s, g, q, a, n_leaves, ctx->tune)) { e = hipErrorInvalidValue; break; }
         }
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1740,7 +1687,50 @@ extern "C" int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int3
     out_host[1] = n;
     out_host[2] = (ctx->hw_queues < 8 && n_wide > n) ? 1 : 0;
     out_host[3] = 0;
-    if (out_host[2]) ctx->err = "fewer than 8 hardware queues (GPU_MAX_HW_QUEUES, read by the HIP runtime at its initialisation): the two-sub-batch schedule is used";
+    return 0;
+}
+
+// ---- options: every tuning / A-B choice of the library is a per-context value set through this entry (include/aej.h has the table) ----
+namespace {
+struct OptionDef { const char *name; int aej::Tuning::*field; int aej_ctx::*ctx_field; long long lo, hi; bool drops_graphs; };
+const OptionDef kOptions[] = {
+    { "color_strip", &aej::Tuning::color_strip, nullptr, 0, 1, true },
+    { "color_strip_rows", &aej::Tuning::color_strip_rows, nullptr, 0, 64, true },
+    { "color_workgroups", &aej::Tuning::color_workgroups, nullptr, 0, 1 << 16, true },
+    { "planes_row_major", &aej::Tuning::planes_row_major, nullptr, 0, 1, true },
+    { "dct64_kernel", &aej::Tuning::dct64_kernel, nullptr, 0, 4, true },
+    { "dct_small_workgroups", &aej::Tuning::dct_small_workgroups, nullptr, 0, 1 << 16, true },
+    { "sobel_lds", &aej::Tuning::sobel_lds, nullptr, 0, 1, true },
+    { "sub_chain", nullptr, &aej_ctx::sub_chain, -1, 3, false },
+};
+const OptionDef *find_option(const char *name)
+{
+    if (!name) return nullptr;
+    for (const OptionDef &o : kOptions) if (!strcmp(o.name, name)) return &o;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int aej_set_option(aej_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx) return AEJ_ERR_ARG;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
+    const OptionDef *o = find_option(name);
+    if (!o) return fail(ctx, AEJ_ERR_ARG, "aej_set_option: unknown option '%s'", name ? name : "(null)");
+    if (value < o->lo || value > o->hi || (o->field == &aej::Tuning::dct64_kernel && value != 0 && value != 1 && value != 4))
+        return fail(ctx, AEJ_ERR_ARG, "aej_set_option: %s = %lld outside its range [%lld, %lld]", name, (long long)value, o->lo, o->hi);
+    if (o->field) ctx->tune.*(o->field) = (int)value;
+    else ctx->*(o->ctx_field) = (int)value;
+    if (o->drops_graphs) drop_graphs(ctx);      // a captured graph holds the launches the old value chose
+    return 0;
+}
+
+extern "C" int aej_get_option(aej_ctx *ctx, const char *name, int64_t *value_host)
+{
+    if (!ctx || !value_host) return AEJ_ERR_ARG;
+    const OptionDef *o = find_option(name);
+    if (!o) return fail(ctx, AEJ_ERR_ARG, "aej_get_option: unknown option '%s'", name ? name : "(null)");
+    *value_host = o->field ? ctx->tune.*(o->field) : ctx->*(o->ctx_field);
     return 0;
 }
 

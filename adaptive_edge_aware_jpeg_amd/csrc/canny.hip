@@ -1469,11 +1469,11 @@ void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
     hipLaunchKernelGGL(k_thresholds, dim3(g.nl, g.B), dim3(256), 0, st, g, cb.blur_hist, cb.thr, cb.low_q, cb.high_q, cb.l2);
 }
 
-void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb)
+void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, const Tuning &t)
 {
     // register kernel: every layer's rows must be whole aligned dwords (w % 4 == 0, w >= 4); other shapes take the LDS kernel
-    static const bool force_lds = getenv("AEJ_SOBEL_LDS") != nullptr;      // A / B knob (tools/profiling): the LDS-tiled kernel of rounds 1-2
-    bool reg_ok = !force_lds;
+    // (aej_set_option "sobel_lds": the LDS-tiled kernel of rounds 1-2 for every shape)
+    bool reg_ok = !t.sobel_lds;
     for (int l = 0; l < g.nl; l++) reg_ok = reg_ok && (g.w[l] % 4) == 0 && g.w[l] >= 4;
     if (reg_ok) {
         const long long t = hyst_tiles_per_image(g), total = t * g.B;

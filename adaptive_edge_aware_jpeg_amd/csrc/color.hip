@@ -722,27 +722,25 @@ int launch_color_convert(hipStream_t st, int space, const float *rgb, float *out
 }
 
 // Shapes the persistent strip kernel takes (CLAHE tiles without padding whose edges no 4 x 2 patch straddles, in every layer), and its strip
-// height.  Tuning knobs (tools/profiling), read once: AEJ_COLOR_NO_STRIP = the 128 x 16 kernel of rounds 1-2, AEJ_COLOR_STRIP_ROWS = strip height.
-static bool strip_shape(const Geom &g, int &nxb, int &rows)
+// height.  Tuning (aej_set_option): color_strip = 0 -> the 128 x 16 kernel of rounds 1-2, color_strip_rows = strip height.
+static bool strip_shape(const Geom &g, const Tuning &t, int &nxb, int &rows)
 {
-    static const bool no_strip = getenv("AEJ_COLOR_NO_STRIP") != nullptr;
-    static const int env_rows = getenv("AEJ_COLOR_STRIP_ROWS") ? atoi(getenv("AEJ_COLOR_STRIP_ROWS")) : 0;
-    if (!((g.W % 16) == 0 && (g.H % 8) == 0 && g.ctw[0] * 4 == g.W && g.cth[0] * 4 == g.H && g.ctw[0] >= 128 && !no_strip)) return false;
+    if (!((g.W % 16) == 0 && (g.H % 8) == 0 && g.ctw[0] * 4 == g.W && g.cth[0] * 4 == g.H && g.ctw[0] >= 128 && t.color_strip)) return false;
     nxb = (g.W + 127) / 128;
     // rows per workgroup: as long as the launch still has a few thousand workgroups (one image spreads over the chip), at most 64
     rows = 64;
     while (rows > 16 && (long long)nxb * ((g.cth[0] + rows - 1) / rows) * 4 * g.B < 4096) rows >>= 1;
-    if (env_rows > 0) rows = (env_rows + 15) / 16 * 16;
+    if (t.color_strip_rows > 0) rows = (t.color_strip_rows + 15) / 16 * 16;
     return true;
 }
 
 // Whether the encode path may keep the normalised planes of this geometry in 4 x 4 blocks (Geom::tiled, plane_elem): the strip kernel
 // writes them (its half-waves start on rows that are multiples of 4 when the strip height is a multiple of 32 and the CLAHE tile
 // height a multiple of 4) and every layer's sides are multiples of 4.
-// On by default; AEJ_PLANES_ROW_MAJOR (read once) keeps the planes row-major.  64 x 4K: `k_dct4` / `k_dct8_shfl` 0.285 / 0.225 -> 0.23 / 0.163 ms (every
+// On by default; the option planes_row_major keeps the planes row-major.  64 x 4K: `k_dct4` / `k_dct8_shfl` 0.285 / 0.225 -> 0.23 / 0.163 ms (every
 // leaf is whole sectors; 1.35 GB less read per call), the colour stage 2.12 -> 2.15 ms.  (Written piecewise -- 16 bytes per lane at a 64-byte
 // stride, four times the memory transactions of a row -- the colour stage took 2.5 ms: hence the staging in LDS.)
-bool color_planes_can_tile(const Geom &g, int space, bool in_u8)
+bool color_planes_can_tile(const Geom &g, int space, bool in_u8, const Tuning &t)
 {
     // (the spaces with float64 pows -- OKLAB, ICtCp, ICaCb, JzAzBz -- are arithmetic-bound in the colour stage: the staging costs them 0.15-0.2 ms per
     // 8 x 8K / 16 x 4K, the small-block DCTs gain 0.03: row-major)
@@ -750,9 +748,8 @@ bool color_planes_can_tile(const Geom &g, int space, bool in_u8)
     // (8-bit input: the colour stage reads a quarter of the bytes and is no longer hidden behind them -- the staging costs it 0.26 ms per 64 x 4K,
     // more than the small-block DCTs gain: row-major)
     if (in_u8) return false;
-    static const bool row_major = getenv("AEJ_PLANES_ROW_MAJOR") != nullptr;
     int nxb, rows;
-    if (row_major || g.nl != 3 || !strip_shape(g, nxb, rows)) return false;
+    if (t.planes_row_major || g.nl != 3 || !strip_shape(g, t, nxb, rows)) return false;
     // (every strip full: W a multiple of 128; half-waves start on multiples of 4 luma rows: strips of 32 or 64 rows, CLAHE tiles a multiple of 4 high)
     if ((rows % 32) != 0 || (g.cth[0] % 4) != 0 || (g.W % 128) != 0) return false;
     for (int l = 0; l < 3; l++)
@@ -762,14 +759,11 @@ bool color_planes_can_tile(const Geom &g, int space, bool in_u8)
 
 template <int SPACE, int RH, int RW>
 static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const Geom &g, const NormConst &nc, float *raw, float *norm,
-                            unsigned char *u8, int *hist)
+                            unsigned char *u8, int *hist, const Tuning &t)
 {
     // strip kernel: CLAHE tiles without padding whose edges no 4 x 2 patch straddles, in every layer
-    // tuning knobs (tools/profiling), read once: AEJ_COLOR_NO_STRIP = the 128 x 16 kernel of rounds 1-2, AEJ_COLOR_STRIP_ROWS / AEJ_COLOR_WGS = strip
-    // height / workgroups in the persistent launch
-    static const int env_wgs = getenv("AEJ_COLOR_WGS") ? atoi(getenv("AEJ_COLOR_WGS")) : 0;
     int nxb, rows;
-    if (strip_shape(g, nxb, rows)) {
+    if (strip_shape(g, t, nxb, rows)) {
         const int nys = (g.cth[0] + rows - 1) / rows;
         const long long nstrips = (long long)nxb * nys * 4 * g.B;
         // Workgroups in the launch.  The matrix spaces are a pure stream: ONE workgroup per CU (256 in all, each walking ~270 strips)
@@ -778,7 +772,7 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
         // other chains' kernels (64 x 4K pipelined step 7.4 -> 7.0 ms; with 128 workgroups the kernel takes 3.0 ms alone and the step
         // is still 7.0: the stage is off the critical path).  The spaces with float64 pows are arithmetic-bound: fill the chip.
         long long want = SPACE < 3 ? 256 : 256 * 8;
-        if (env_wgs > 0) want = env_wgs;
+        if (t.color_workgroups > 0) want = t.color_workgroups;
         dim3 sgrid((unsigned)(nstrips < want ? nstrips : want));
         const bool prod = norm && u8 && hist && !raw;
         const size_t stage_bytes = g.tiled ? 8 * 1024 * sizeof(float) : 0;
@@ -805,19 +799,19 @@ static void launch_planes_t(hipStream_t st, const void *rgb, bool in_u8, const G
 }
 
 int launch_color_planes(hipStream_t st, int space, const void *rgb, bool in_u8, const Geom &g, const float *mid, const float *scale,
-                        float *raw, float *norm, unsigned char *u8, int *hist)
+                        float *raw, float *norm, unsigned char *u8, int *hist, const Tuning &t)
 {
-    if (g.tiled && (!color_planes_can_tile(g, space, in_u8) || !(norm && u8 && hist && !raw))) return -1;       // only the encode path's strip kernel writes the tiled form
+    if (g.tiled && (!color_planes_can_tile(g, space, in_u8, t) || !(norm && u8 && hist && !raw))) return -1;       // only the encode path's strip kernel writes the tiled form
     NormConst nc;
     for (int i = 0; i < 3; i++) { nc.mid[i] = mid[i]; nc.scale[i] = scale[i]; }
     switch (space) {
-    case 0: launch_planes_t<0, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
-    case 1: launch_planes_t<1, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
-    case 2: launch_planes_t<2, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
-    case 3: launch_planes_t<3, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
-    case 4: launch_planes_t<4, 1, 4>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
-    case 5: launch_planes_t<5, 1, 4>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
-    case 6: launch_planes_t<6, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist); break;
+    case 0: launch_planes_t<0, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist, t); break;
+    case 1: launch_planes_t<1, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist, t); break;
+    case 2: launch_planes_t<2, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist, t); break;
+    case 3: launch_planes_t<3, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist, t); break;
+    case 4: launch_planes_t<4, 1, 4>(st, rgb, in_u8, g, nc, raw, norm, u8, hist, t); break;
+    case 5: launch_planes_t<5, 1, 4>(st, rgb, in_u8, g, nc, raw, norm, u8, hist, t); break;
+    case 6: launch_planes_t<6, 2, 2>(st, rgb, in_u8, g, nc, raw, norm, u8, hist, t); break;
     default: return -1;
     }
     return 0;

@@ -1396,12 +1396,12 @@ static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const 
                        reinterpret_cast<const int4 *>(a.work));
 }
 
-int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items)
+int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const Tuning &t)
 {
     if (max_items <= 0) return 0;                  // an empty work list is not an error
     if (a.nplanes > kMaxPlanes) return -1;         // the per-plane prefix table would not fit the launch's LDS
     const size_t pref = (size_t)(a.nplanes + 1) * sizeof(int);
-    static const int small_wgs = getenv("AEJ_DCT_SMALL_WGS") ? atoi(getenv("AEJ_DCT_SMALL_WGS")) : 0;      // tuning knob (tools/profiling): residency of the grid-stride kernels
+    const int small_wgs = t.dct_small_workgroups;      // tuning (aej_set_option): residency of the grid-stride kernels
     auto cap = [&](long long per_block, int hi) {
         long long b = (max_items + per_block - 1) / per_block;
         if (small_wgs > 0 && size <= 16) hi = small_wgs;
@@ -1434,7 +1434,7 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
         // its workgroups take a whole CU each (122 KiB LDS, 2 x 242 registers per SIMD lane): beside the kernels of other sub-batches it
         // waits for CUs to drain and then shares them with nobody -- the pipelined 64 x 4K step is 6.70 ms with it and 6.45 ms with the
         // four-wave kernel, whose workgroups are a third of a CU.  So the caller says whether the launch will have company.
-        static const bool force_four = getenv("AEJ_DCT64_FOUR_WAVES") != nullptr, force_wave = getenv("AEJ_DCT64_ONE_WAVE") != nullptr;
+        const bool force_four = t.dct64_kernel == 4, force_wave = t.dct64_kernel == 1;      // aej_set_option "dct64_kernel"
         if (wd || force_four || (a.crowded && !force_wave)) { AEJ_MFMA(64); }       // (the float32 DCT output, a debugging aid, stays with the four-wave kernel)
         else launch_dct64_wave<false>(st, g, q, a, max_items);
         break;

@@ -15,8 +15,6 @@
 namespace aej {
 
 constexpr int kSsimK = 11;               // window size
-constexpr int kSsimT = 32;               // output tile (square)
-constexpr int kSsimIn = kSsimT + kSsimK - 1;   // 42 input rows / columns per tile
 
 __device__ __forceinline__ double block_sum(double v, double *s_red)
 {
@@ -115,97 +113,13 @@ struct SsimArgs {
     float c1, c2;
     double *acc;              // [B][kMetricSlots]
     int slot;                 // first slot: channel c adds ss to slot + 2c, cs to slot + 2c + 1
-    int ntx;
 };
 
-template <bool INTERLEAVED>
-__global__ __launch_bounds__(256) void k_ssim_level(SsimArgs A)
-{
-    __shared__ float sx[kSsimIn][kSsimIn + 1], sy[kSsimIn][kSsimIn + 1];
-    __shared__ float hb[5][kSsimIn][kSsimT + 1];
-    __shared__ double s_red[4];
-    const int tid = threadIdx.x;
-    const int img = blockIdx.z;
-    const int ty = blockIdx.x / A.ntx, tx = blockIdx.x - ty * A.ntx;
-    const int x0 = tx * kSsimT, y0 = ty * kSsimT;
-    const int oh = A.h - (kSsimK - 1), ow = A.w - (kSsimK - 1);
-    // interleaved input: one workgroup walks the channels of its tile, so the 12-byte pixels are fetched from HBM once
-    const int c_begin = INTERLEAVED ? 0 : blockIdx.y, c_end = INTERLEAVED ? A.C : c_begin + 1;
-    for (int c = c_begin; c < c_end; c++) {
-    for (int idx = tid; idx < kSsimIn * kSsimIn; idx += 256) {
-        const int r = idx / kSsimIn, q = idx - r * kSsimIn;
-        const int gy = y0 + r, gx = x0 + q;
-        float va = 0.f, vb = 0.f;
-        if (gy < A.h && gx < A.w) {
-            const long long o = INTERLEAVED ? (((long long)img * A.h + gy) * A.w + gx) * A.C + c
-                                            : (((long long)img * A.C + c) * A.h + gy) * A.w + gx;
-            va = A.xa[o]; vb = A.xb[o];
-        }
-        sx[r][q] = va; sy[r][q] = vb;
-    }
-    __syncthreads();
-    // horizontal pass: 4 adjacent outputs per item share 14 staged values of a row
-    for (int item = tid; item < kSsimIn * (kSsimT / 4); item += 256) {
-        const int r = item / (kSsimT / 4), q0 = (item - r * (kSsimT / 4)) * 4;
-        float xv[kSsimK + 3], yv[kSsimK + 3];
-#pragma unroll
-        for (int k = 0; k < kSsimK + 3; k++) { xv[k] = sx[r][q0 + k]; yv[k] = sy[r][q0 + k]; }
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            float mx = 0.f, my = 0.f, mxx = 0.f, myy = 0.f, mxy = 0.f;
-#pragma unroll
-            for (int t = 0; t < kSsimK; t++) {
-                const float gw = A.g[t], x = xv[o + t], y = yv[o + t];
-                mx += gw * x; my += gw * y; mxx += gw * (x * x); myy += gw * (y * y); mxy += gw * (x * y);
-            }
-            hb[0][r][q0 + o] = mx; hb[1][r][q0 + o] = my; hb[2][r][q0 + o] = mxx; hb[3][r][q0 + o] = myy; hb[4][r][q0 + o] = mxy;
-        }
-    }
-    __syncthreads();
-    // vertical pass: thread = one column x 4 adjacent rows
-    const int q = tid & 31, r0 = (tid >> 5) * 4;
-    float res[5][4];
-#pragma unroll
-    for (int m = 0; m < 5; m++) {
-        float v[kSsimK + 3];
-#pragma unroll
-        for (int k = 0; k < kSsimK + 3; k++) v[k] = hb[m][r0 + k][q];
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            float s = 0.f;
-#pragma unroll
-            for (int t = 0; t < kSsimK; t++) s += A.g[t] * v[o + t];
-            res[m][o] = s;
-        }
-    }
-    double ss_sum = 0.0, cs_sum = 0.0;
-#pragma unroll
-    for (int o = 0; o < 4; o++) {
-        if (y0 + r0 + o < oh && x0 + q < ow) {
-            const float mu_x = res[0][o], mu_y = res[1][o];
-            const float mu_xx = mu_x * mu_x, mu_yy = mu_y * mu_y, mu_xy = mu_x * mu_y;
-            const float s_xx = res[2][o] - mu_xx, s_yy = res[3][o] - mu_yy, s_xy = res[4][o] - mu_xy;
-            const float cs = (2.f * s_xy + A.c2) / (s_xx + s_yy + A.c2);
-            const float ss = (2.f * mu_xy + A.c1) / (mu_xx + mu_yy + A.c1) * cs;
-            ss_sum += (double)ss; cs_sum += (double)cs;
-        }
-    }
-    ss_sum = block_sum(ss_sum, s_red);
-    cs_sum = block_sum(cs_sum, s_red);
-    if (tid == 0) {
-        double *acc = A.acc + (long long)img * kMetricSlots + A.slot + 2 * c;
-        atomicAdd(&acc[0], ss_sum);
-        atomicAdd(&acc[1], cs_sum);
-    }
-    __syncthreads();       // the staging arrays are rewritten for the next channel
-    }
-}
-
-// ---- the same scale as a sliding window (used for every scale; the tiled kernel above is kept as the small-image fallback) ----
+// ---- one scale as a sliding window ----
 // One WAVE owns a strip of 64 output columns x kStripRows output rows and walks down the input rows: a row's 74 values of x and y
 // go through a wave-private LDS row (no workgroup barrier anywhere), every lane forms the five horizontal sums of its column and
 // keeps the last 11 rows of them in registers (a ring addressed at compile time: the row loop is unrolled 11-fold), and the
-// vertical sums complete one output row per input row.  Same tap order as the tiled kernel, so the same float32 values.
+// vertical sums complete one output row per input row.
 constexpr int kStripRows = 64;
 
 template <bool INTERLEAVED>
@@ -401,14 +315,6 @@ void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const 
     A.c1 = (float)(0.01 * 0.01); A.c2 = (float)(0.03 * 0.03);
     A.acc = acc; A.slot = slot;
     const int oh = h - (kSsimK - 1), ow = w - (kSsimK - 1);
-    A.ntx = (ow + kSsimT - 1) / kSsimT;
-    const int nty = (oh + kSsimT - 1) / kSsimT;
-    if (getenv("AEJ_SSIM_TILED")) {              // diagnostic: the tiled kernel
-        dim3 grid(A.ntx * nty, interleaved ? 1 : C, B);
-        if (interleaved) hipLaunchKernelGGL(k_ssim_level<true>, grid, dim3(256), 0, st, A);
-        else hipLaunchKernelGGL(k_ssim_level<false>, grid, dim3(256), 0, st, A);
-        return;
-    }
     const int strips = ((ow + 63) / 64) * ((oh + kStripRows - 1) / kStripRows);
     dim3 grid((strips + 3) / 4, interleaved ? 1 : C, B);
     if (interleaved) hipLaunchKernelGGL(k_ssim_strip<true>, grid, dim3(256), 0, st, A);

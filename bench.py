@@ -58,10 +58,17 @@ ALGO_BYTES_PER_PX = {
     "quadtree": 1.5 * 1,                         # map in (leaf/state tables are < 0.1 B/px)
 }
 WHOLE_PATH_BYTES_PER_PX = 18.0                   # 12 B f32 RGB in + 4 B x 1.5 coefficients out
-KERNEL_OF_STAGE = {"color_planes": "k_color_planes", "clahe_blur": "k_clahe_blur", "sobel_nms": "k_sobel_nms", "hysteresis": "k_hyst_pass",
-                   "quadtree": "k_qt_", "dct4": "k_dct4", "dct8": "k_dct_small<8", "dct16": "k_dct16_mfma", "dct32": "k_dct_mfma<32",
-                   "dct64": "k_dct_mfma<64", "dct128": "k_dct_mfma<128", "dct2": "k_dct_small<2", "dct256": "k_dct_big<256", "dct512": "k_dct_big<512",
-                   "dct1024": "k_dct_big<1024"}
+# kernel-name prefixes (as rocprofv3 prints them, tools/profiling/pmc.py short()) of every stage; a stage may be served by more than one
+# kernel (hysteresis: pass 0 + the drain; 64 x 64 DCT: one-wave or four-wave kernel by company)
+KERNEL_OF_STAGE = {"color_planes": ("k_color_planes",), "clahe_blur": ("k_clahe_blur",), "sobel_nms": ("k_sobel_nms",), "hysteresis": ("k_hyst_",),
+                   "quadtree": ("k_qt_",), "dct2": ("k_dct_small<2",), "dct4": ("k_dct4",), "dct8": ("k_dct8_shfl",), "dct16": ("k_dct16_mfma",),
+                   "dct32": ("k_dct_mfma<32",), "dct64": ("k_dct_mfma<64", "k_dct64_wave"), "dct128": ("k_dct_mfma<128",),
+                   "dct256": ("k_dct_big<256",), "dct512": ("k_dct_big<512",), "dct1024": ("k_dct_big<1024",)}
+
+
+def kernels_of_stage(stage, profiled_names):
+    """Names in a PMC profile that belong to `stage`."""
+    return [k for k in profiled_names if any(p in k for p in KERNEL_OF_STAGE[stage])]
 
 
 def synth_batch(torch, B, H, W, seed, device):
@@ -139,7 +146,7 @@ def parse_args(argv=None):
                          "the image size (a labelled variant: textures change the leaf mix and the hysteresis pass count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle comparison")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for cpu_baseline; 0 = min(available cores, 16)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for cpu_baseline; 0 = min(cores this process may use, 64)")
     ap.add_argument("--graph", type=int, choices=[0, 1, 2], default=0,
                     help="aej_set_graph_mode: 0 never replay a captured hipGraph (the library default), 1 automatic (calls of at most 8 Mpx), 2 whenever possible")
     ap.add_argument("--sub-batches", type=int, default=0,
@@ -147,6 +154,8 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", type=int, choices=[1, 2, 3, 4], default=3,
                     help="contexts (each on its own stream, with its own output buffers and workspace) the timed steps rotate over: step i is "
                          "enqueued with aej_encode_batch_begin on context i %% n after the step that used it before has been ended; 1 = blocking calls")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="aej_set_option on every context (include/aej.h has the table), e.g. --option dct64_kernel=1; A / B runs only")
     ap.add_argument("--strict-speculation", action="store_true",
                     help="exit non-zero when any rank's hysteresis speculation missed inside the timed region (the miss is repaired and the "
                          "output correct either way; the line always reports the misses per rank)")
@@ -157,6 +166,43 @@ def parse_args(argv=None):
                     help="NO GPU work: run only the multi-rank control flow (rendezvous, per-rank seeds, barriers, reduction, rank-0 "
                          "JSON) with a sleep in place of the encode; used by the CPU gloo test, never a measurement")
     return ap.parse_args(argv)
+
+
+def spawn_ranks_if_asked(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.  The parent never imports torch or
+    touches the GPU; it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
+    args>` as a CHILD process (never exec), whose rank 0 prints the JSON line on the inherited stdout, and exits with the child's code.
+    The reference fans out the same way, from its own harness (test/analysis/metrics_computation.py:253).  Under an external launcher
+    (WORLD_SIZE set) nothing is spawned, but --gpus must agree with it."""
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world} of the launcher that started this process")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
+def build_oracle_once(dist, local_rank):
+    """The checker's shared object is git-ignored: on a fresh box it is compiled here, by ONE process per node, before anything is timed;
+    the other ranks wait at a barrier and only load it (oracle.build() itself also renames into place atomically)."""
+    from oracle import oracle as O
+    if local_rank == 0:
+        O.build()
+    if dist is not None:
+        dist.barrier()
+    O.build()          # (no-op when rank 0 of this node has just built it)
+    return O
 
 
 def rank_env():
@@ -250,7 +296,10 @@ def rehearse(args):
     dt_local = timed_loop.own_seconds
     px, dt = aggregate_throughput(dist, B * args.height * args.width * args.steps, dt, None)
     fake_bad = os.environ.get("AEJ_REHEARSE_BAD_RANK")            # the CPU test makes one rank report a failed oracle check
-    ranks = gather_rank_report(dist, local_rank, dt_local / args.steps * 1e3, 0, not (fake_bad is not None and int(fake_bad) == rank), None)
+    verdict = not (fake_bad is not None and int(fake_bad) == rank)
+    if os.environ.get("AEJ_REHEARSE_UNVERIFIED_RANK") is not None and int(os.environ["AEJ_REHEARSE_UNVERIFIED_RANK"]) == rank:
+        verdict = None                                            # ... or never reach its check
+    ranks = gather_rank_report(dist, local_rank, dt_local / args.steps * 1e3, 0, verdict, None)
     if rank == 0:
         print(json.dumps({"metric": "REHEARSAL of bench.py's multi-rank control flow (no GPU work, not a measurement)", "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "pixels_total": px,
@@ -263,6 +312,7 @@ def rehearse(args):
 
 def main():
     args = parse_args()
+    spawn_ranks_if_asked(args, sys.argv[1:])
     if args.rehearse_control_flow:
         return rehearse(args)
 
@@ -290,6 +340,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
 
     from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput, gather_rank_report
+    if not (args.no_verify and (args.no_cpu_baseline or rank != 0)) and not args.timed_only:
+        build_oracle_once(dist, int(os.environ.get("LOCAL_RANK", "0")))        # the checker exists before anything is timed (it is not used until after)
 
     H, W = args.height, args.width
     B, seed_a, seed_b, scaling = local_batch_and_seed(args, rank, world)
@@ -311,6 +363,8 @@ def main():
                 self.ctx = jpeg._bind()
                 self.ctx.set_graph_mode(args.graph)
                 self.ctx.set_sub_batches(args.sub_batches)
+                for kv in args.option:
+                    self.ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
                 self.plan = self.ctx.plan(B, H, W)
                 self.out = (self.ctx.empty((B * self.plan.coeff_stride,), torch.int32), self.ctx.empty((B * self.plan.leaf_stride, 4), torch.int32),
                             self.ctx.empty((B * self.plan.state_stride,), torch.uint8), self.ctx.empty((B, 3, 4), torch.int64))
@@ -388,7 +442,6 @@ def main():
     if not args.no_verify:                   # every rank checks its own outputs (rank 0's result goes into the line, all of them into `ranks`)
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
-        O.build()
         from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
         enc = EncodedBatch(last_pipe.plan, *last_pipe.out)
         picks = sorted({0, B - 1})
@@ -404,7 +457,7 @@ def main():
 
     # ---- first-contact evidence for N > 1: which ranks the collective saw, their own step times, misses and oracle checks ----
     ranks = gather_rank_report(dist, local_rank, own_ms_per_step, h1["misses"] - h0["misses"], None if verified is None else verified["ok"],
-                               dev if backend == "nccl" else None)
+                               dev if backend == "nccl" else None, require_verified=not args.no_verify)
 
     # ---- the same loop with the speculation off (verified hysteresis loop) ----
     # ---- strictly serial figure: blocking calls on one context, nothing in flight between them ----
@@ -458,11 +511,23 @@ def main():
     head = git_head()
     # HBM bytes and VALU instruction counts come from rocprofv3 PMC passes of this same command (profiles/, tools/profiling/pmc.py);
     # they cannot be collected inside a normal run, so the line says which profile they are from and for which commit
-    traffic_file = "r03_hbm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")) else "r02_hbm_traffic.json"
-    valu_file = "r03_pmc_valu.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_valu.json")) else "r02_pmc_valu.json"
+    def newest(suffix):
+        names = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix) and f[:1] == "r" and f[1:3].isdigit())
+        return names[-1] if names else suffix
+    traffic_file, valu_file = newest("_hbm_traffic.json"), newest("_pmc_valu.json")
     tj = load_profile_json(traffic_file)
     vj = load_profile_json(valu_file)
     src_hash = source_hash()
+    # every stage of this run must resolve to at least one kernel of the profile it is priced with (a renamed kernel would otherwise
+    # silently drop out of `traffic` / `valu`)
+    profile_gaps = {}
+    for fname, j in ((traffic_file, tj), (valu_file, vj)):
+        if j and j.get("kernels"):
+            missing = [st for st in KERNEL_OF_STAGE if (st in ("color_planes", "clahe_blur", "sobel_nms", "hysteresis", "quadtree") or
+                                                        (st.startswith("dct") and brange[0] <= int(st[3:]) <= brange[1]))
+                       and not kernels_of_stage(st, j["kernels"])]
+            if missing:
+                profile_gaps[fname] = missing
 
     def same_shape(j):
         return bool(j) and (j.get("batch"), j.get("height"), j.get("width")) == (B, H, W) and j.get("space", "YCbCr") == space and \
@@ -483,17 +548,17 @@ def main():
         achieved = algo[stage] / (kernels[stage] * 1e-3) / 1e9 if kernels[stage] > 0 else 0.0
         traffic, traffic_src = None, None
         if same_shape(tj):
-            hit = [v["hbm_bytes"] for k, v in tj["kernels"].items() if KERNEL_OF_STAGE[stage] in k]
+            hit = [tj["kernels"][k]["hbm_bytes"] for k in kernels_of_stage(stage, tj["kernels"])]
             if hit:
                 traffic = sum(hit)
                 traffic_src = src_of(tj, traffic_file)
-        r = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[stage].rstrip("<_") if stage != "quadtree" else "k_qt_upper+count+scan+emit",
+        r = {"bound": "hbm", "kernel": {"quadtree": "k_qt_upper+count+scan+emit", "hysteresis": "k_hyst_pass+k_hyst_drain"}.get(stage, KERNEL_OF_STAGE[stage][0]),
              "stage": stage, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
              "algorithmic_bytes_per_launch": algo[stage], "avg_launch_ms": round(kernels[stage], 4)}
         v = None
         if same_shape(vj):
-            hit = [x for k, x in vj["kernels"].items() if KERNEL_OF_STAGE[stage] in k]
+            hit = [vj["kernels"][k] for k in kernels_of_stage(stage, vj["kernels"])]
             if hit:
                 insts = sum(x["valu_insts_per_launch"] for x in hit)       # wave-level VALU instructions of one launch
                 plane_px = 1.5 * local_px
@@ -531,11 +596,13 @@ def main():
         "config": {"workload": f"{B} x {W}x{H} {'uint8' if args.ingest == 'u8' else 'float32'} RGB per GPU, {space}, blocks {brange[0]}-{brange[1]}, quality {qrange[0]}-{qrange[1]} "
                                + ("(BASELINE config 4: 512 4K images / 8 GPUs)" if (B, H, W, space, tuple(brange), args.data) == (64, H4K, W4K, "YCbCr", (4, 64), "synthetic") else "(not the headline workload)"),
                    "images_per_gpu": B, "height": H, "width": W, "color_space": space,
-                   "block_size_range": list(brange), "quality_range": list(qrange), "steps_in_flight": n_pipe},
+                   "block_size_range": list(brange), "quality_range": list(qrange), "steps_in_flight": n_pipe,
+                   "options": args.option or None},
         "roofline": roofline,
         "valu": valu,
         "runner_up": runner_up,
         "verified": verified,
+        "profile_gaps": profile_gaps or None,
         "ranks": ranks,
         "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "speculative_calls": h1["speculative"] - h0["speculative"],
                        "misses": h1["misses"] - h0["misses"], "passes_enqueued_last_call": h1["enqueued"],
@@ -589,29 +656,36 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
         from oracle import reference_structured as RS
-        O.build()
         try:
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        cores = max(1, min(args.cpu_threads or min(avail, 16), B))      # a 1-GPU box's CPU share is 16 cores
-        n_img = min(B, 2 * cores)                                       # about 10-20 s of CPU work
-        imgs = batches_f32[0][:n_img].cpu().numpy()
+        # "across all host cores" (BASELINE.md B2): one image per thread on min(cores this process may use, 64, B) threads -- 64 images are
+        # resident, each encode holds a few hundred MB -- and the 16-thread figure of rounds 1-3 beside it (a container's CPU quota can be
+        # smaller than its affinity mask: the better of the two is the baseline, with the thread count that produced it)
+        wide = max(1, min(args.cpu_threads or min(avail, 64), B))
+        imgs = batches_f32[0][:min(B, wide)].cpu().numpy()
         t0 = time.perf_counter()
         O.encode_image(imgs[0], space, qrange, brange)
         t1 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=cores) as ex:
-            list(ex.map(lambda im: O.encode_image(im, space, qrange, brange), [imgs[i] for i in range(n_img)]))
-        cdt = time.perf_counter() - t0
+
+        def port_rate(threads):
+            n = min(len(imgs), threads)
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                list(ex.map(lambda im: O.encode_image(im, space, qrange, brange), [imgs[i] for i in range(n)]))
+            dt_ = time.perf_counter() - t0
+            return {"threads": threads, "images": n, "seconds": round(dt_, 2), "MP/s": round(n * H * W / dt_ / 1e6, 2)}
+        runs = [port_rate(wide)] + ([port_rate(16)] if wide > 16 else [])
+        best = max(runs, key=lambda r: r["MP/s"])
         t0 = time.perf_counter()
         RS.encode_image(imgs[0], space, qrange, brange)
         t_rs = time.perf_counter() - t0
-        t_fan, n_fan = RS.fan_out(imgs[:cores], space, qrange, brange, cores)      # (ii): one image per worker process
-        out["cpu_baseline"] = {"value": round(n_img * H * W / cdt / 1e6, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-                               "sample": f"{n_img} of the {B} bench images ({W}x{H}) over {cores} threads (one image per call), whole path a-1..a-15 in the C oracle, "
-                                         f"{cdt:.1f} s; single core: 1 image in {t1:.1f} s",
-                               "single_core_value": round(H * W / t1 / 1e6, 2), "host_cpus": os.cpu_count(),
+        t_fan, n_fan = RS.fan_out(imgs[:wide], space, qrange, brange, wide)      # (ii): one image per worker process
+        out["cpu_baseline"] = {"value": best["MP/s"], "unit": "MP/s", "cores": best["threads"], "kind": "port",
+                               "sample": f"{best['images']} of the {B} bench images ({W}x{H}), one image per thread on {best['threads']} threads, whole path a-1..a-15 in "
+                                         f"the C oracle, {best['seconds']} s; single core: 1 image in {t1:.1f} s",
+                               "runs": runs, "single_core_value": round(H * W / t1 / 1e6, 2), "host_cpus": os.cpu_count(), "usable_cpus": avail,
                                "reference_structured": {"value": round(H * W / t_rs / 1e6, 2), "unit": "MP/s", "cores": 1, "kind": "port",
                                                         "sample": f"1 bench image ({W}x{H}), {t_rs:.1f} s: the reference's control structure (one Python thread, "
                                                                   "per-node quadtree tests, per-leaf pad / DCT / quantise / zigzag loops) with the C oracle standing in for "

@@ -118,9 +118,21 @@ AEJ_API int aej_set_sub_batches(aej_ctx *ctx, int n);
  * 1 when fewer than 8 queues force the two-sub-batch schedule for a call the 4-sub-batch one would serve better, reserved }. */
 AEJ_API int aej_set_hw_queues(aej_ctx *ctx, int n);
 AEJ_API int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int32_t *out_host);
-/* TEST INSTRUMENTATION (tests/ only): the next whole-path call fails with AEJ_ERR_STATE right after it has enqueued stage `stage`
- * (an AEJ_STAGE_* value; -1 disarms) of its first part, i.e. with work in flight -- the error paths must drain it.  One-shot. */
-AEJ_API int aej_test_fail_after_stage(aej_ctx *ctx, int stage);
+/* Tuning and A / B options of one context.  The library reads NO environment variable: whatever changes which kernel or launch shape
+ * serves a stage is said here, by the caller, per context (and reported back by aej_get_option).  Every option leaves the results
+ * bit-identical; the defaults are the measured best on MI355X.  Unknown name or value outside the range: AEJ_ERR_ARG.
+ *   name                    values             meaning
+ *   "color_strip"           0 | 1 (default 1)  0: never the persistent strip colour kernel (the 128 x 16 kernel instead)
+ *   "color_strip_rows"      0 | 16..64 (0)     strip height of that kernel; 0 = automatic
+ *   "color_workgroups"      0..65536 (0)       workgroups of its persistent launch; 0 = automatic (256 for the matrix spaces)
+ *   "planes_row_major"      0 | 1 (0)          1: normalised planes row-major in the workspace (default: 4 x 4 blocks where possible)
+ *   "dct64_kernel"          0 | 1 | 4 (0)      64 x 64 DCT: 0 = by company (one wave per leaf alone, four beside other work), 1 / 4 force
+ *   "dct_small_workgroups"  0..65536 (0)       cap on the grids of the 4 / 8 / 16 DCT kernels; 0 = automatic
+ *   "sobel_lds"             0 | 1 (0)          1: the LDS-tiled Sobel / NMS kernel for every shape (default: register kernel when w % 4 == 0)
+ *   "sub_chain"             -1..3 (-1)         which stage of the previously enqueued part a part's colour stage waits for: 0 none, 1 colour,
+ *                                              2 blur, 3 Sobel; -1 = 1 between sub-batches of one call, 2 between whole calls */
+AEJ_API int aej_set_option(aej_ctx *ctx, const char *name, int64_t value);
+AEJ_API int aej_get_option(aej_ctx *ctx, const char *name, int64_t *value_host);
 /* The two halves of aej_encode_batch / aej_encode_batch_u8 (same arguments; rgb_is_u8 selects the ingest): _begin enqueues the whole
  * call and returns without waiting, _end waits for it, checks the device-side counters and repairs a speculation miss.  One call may
  * be in flight per context; until _end returns, the context's other entry points, the workspace and the output buffers must not be

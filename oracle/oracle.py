@@ -60,8 +60,16 @@ def build(force=False, sanitize=False):
     so = _SO_ASAN if sanitize else _SO
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [_SRC] + hdrs):
         extra = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"] if sanitize else ["-O2"]
-        subprocess.check_call(["gcc"] + extra + ["-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
-                               "-fvisibility=hidden", "-mfma", "-mavx2", "-I", _HERE, "-o", so, _SRC, "-lm"])
+        # compiled to a private temporary and renamed into place: several ranks of one node may build at once (bench.py), and a
+        # reader must never dlopen a half-written file
+        tmp = f"{so}.{os.getpid()}.tmp"
+        try:
+            subprocess.check_call(["gcc"] + extra + ["-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                                   "-fvisibility=hidden", "-mfma", "-mavx2", "-I", _HERE, "-o", tmp, _SRC, "-lm"])
+            os.replace(tmp, so)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return so
 
 

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The test process is an application of the library: it asks (explicitly, before torch / HIP is loaded) for a hardware queue per stream,
+# as bench.py does -- the package itself never writes the environment (adaptive_edge_aware_jpeg_amd/_lib.py).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def pytest_configure(config):

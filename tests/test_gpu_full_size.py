@@ -51,14 +51,17 @@ def test_single_full_size_image_matches_oracle(env, oracle, H, W, space, br):
     assert min(sizes) == br[0] and max(sizes) == br[1], sizes          # the whole block range occurs in the image
 
 
-@pytest.mark.parametrize("B,H,W", [(8, 2160, 3840), (64, 1080, 1920)], ids=["8x4K", "64x1080p"])
-def test_batched_layout_matches_oracle(env, oracle, B, H, W):
+@pytest.mark.parametrize("B,H,W,space,br", [(8, 2160, 3840, "YCbCr", (4, 64)), (64, 1080, 1920, "YCbCr", (4, 64)), (8, 4320, 7680, "OKLAB", (4, 128))],
+                         ids=["8x4K", "64x1080p", "8x8K-OKLAB-4-128"])
+def test_batched_layout_matches_oracle(env, oracle, B, H, W, space, br):
+    """The batched layouts of BASELINE configs 3-5 (config 5's per-GPU share is the 8 x 7680x4320 OKLAB 4-128 case: images 0 and 7 against
+    the oracle, about 11 s each on two threads)."""
     torch, A, bench = env
-    space, qr, br = "YCbCr", (40, 80), (4, 64)
+    qr = (40, 80)
     x = bench.synth_batch(torch, B, H, W, 20250718, torch.device("cuda", 0))
     codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
     enc = codec.compress_batch(x)
-    picks = sorted({0, B // 2, B - 1})
+    picks = sorted({0, B // 2, B - 1}) if H < 4320 else [0, B - 1]
     with ThreadPoolExecutor(max_workers=len(picks)) as ex:         # ctypes releases the GIL inside the C oracle
         refs = list(ex.map(lambda b: oracle.encode_image(x[b].cpu().numpy(), space, qr, br), picks))
     for b, ref in zip(picks, refs):
@@ -194,9 +197,18 @@ def test_graph_replay_path_matches_oracle(env, oracle):
             check_image(EncodedBatch(plan, *out), 0, refs[which], f"graph call {it}")
         g1 = ctx.graph_stats()
         assert g1["captures"] - g0["captures"] == 1 and g1["launches"] - g0["launches"] >= 3, (g0, g1)
-        # a replay whose pass count is too small (needs the per-pass hysteresis, i.e. more than kHystFinishTiles tiles: 6 images):
-        # the miss is detected after the replay and repaired eagerly; outputs equal the eager path's
-        B = 6
+        _graph_miss_is_repaired(torch, bench, oracle, codec, ctx, dev, 6, H, W, space, qr, br)
+        # a shape whose workspace planes are kept in 4 x 4 blocks (3 x 4K float32 YCbCr: strips of 32 rows) -- capture,
+        # replay and the miss repair must agree on the layout
+        _graph_miss_is_repaired(torch, bench, oracle, codec, ctx, dev, 3, 2160, 3840, space, qr, br)
+    finally:
+        ctx.set_graph_mode(0)
+
+
+def _graph_miss_is_repaired(torch, bench, oracle, codec, ctx, dev, B, H, W, space, qr, br):
+    """a replay whose pass count is too small (needs the per-pass hysteresis, i.e. more than kHystFinishTiles tiles): the miss is
+    detected after the replay and repaired eagerly; outputs equal the eager path's, and image 0 the oracle's"""
+    if True:
         xb = bench.synth_batch(torch, B, H, W, 5, dev)
         planb = ctx.plan(B, H, W)
         def outs():
@@ -224,8 +236,8 @@ def test_graph_replay_path_matches_oracle(env, oracle):
                         and torch.equal(got[2][s0_:s0_ + ns], want[2][s0_:s0_ + ns]), f"graph miss call {it}: image {im} layer {l}"
         assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 3
         assert ctx.graph_stats()["launches"] - g2["launches"] >= 2
-    finally:
-        ctx.set_graph_mode(0)
+        from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+        check_image(EncodedBatch(planb, *got), 0, oracle.encode_image(xb[0].cpu().numpy(), space, qr, br), f"graph miss {B} x {W}x{H}: image 0")
 
 
 def _encode_raw(torch, ctx, codec, x, plan):
@@ -366,18 +378,20 @@ def test_randomised_parity_sweep(env, oracle):
         assert np.array_equal(dec, want, equal_nan=True), tag + " decode"
 
 
-def test_bench_configuration_64x4k_two_contexts(env, oracle):
-    """The exact configuration bench.py times (BASELINE config 4's per-GPU share): B = 64 x 3840x2160, two contexts on two streams
-    with aej_encode_batch_begin / _end, automatic sub-batching, two different input batches; images 0, B/2 and B-1 of BOTH calls in
-    flight are compared with the oracle, and every image's counters are checked for consistency."""
+def test_bench_configuration_64x4k_three_contexts(env, oracle):
+    """The exact configuration bench.py times (BASELINE config 4's per-GPU share): B = 64 x 3840x2160, THREE contexts on three streams
+    with aej_encode_batch_begin / _end (bench.py --pipeline 3), automatic sub-batching, two different input batches rotated with the
+    bench's own input_of(); images 0, B/2 and B-1 of EACH context's last call are compared with the oracle, and every image's counters
+    are checked for consistency."""
     torch, A, bench = env
     from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
     dev = torch.device("cuda", 0)
     space, qr, br = "YCbCr", (40, 80), (4, 64)
     B, H, W = 64, 2160, 3840
+    n_pipe, n_steps = 3, 9
     codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
     xs = [bench.synth_batch(torch, B, H, W, seed, dev) for seed in (20250718, 20250718 + 1_000_000)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
     ctxs, outs = [], []
     for s in streams:
         with torch.cuda.stream(s):
@@ -388,31 +402,35 @@ def test_bench_configuration_64x4k_two_contexts(env, oracle):
             outs.append((c.empty((B * plan.coeff_stride,), torch.int32), c.empty((B * plan.leaf_stride, 4), torch.int32),
                          c.empty((B * plan.state_stride,), torch.uint8), c.empty((B, 3, 4), torch.int64)))
     torch.cuda.synchronize()
-    # the bench process starts HIP with 16 hardware queues and says so; this test process may not have (pytest initialised HIP first), so
-    # state 16 to get the schedule the bench times -- with fewer real queues the streams share queues, which is slower but equally correct
+    # the test process asks for 16 hardware queues before HIP starts (tests/conftest.py), as bench.py does; state it in case the
+    # process was started otherwise -- with fewer real queues the streams share queues, which is slower but equally correct
     for c in ctxs:
         c.check(c.lib.aej_set_hw_queues(c.handle, 16))
-    sched = ctxs[0].schedule(B, H, W)
-    assert sched["sub_batches"] == 4
+    assert ctxs[0].schedule(B, H, W)["sub_batches"] == 4
+
+    def input_of(i):                              # bench.py's rotation
+        return (i // n_pipe + i) & 1
+
     picks = [0, B // 2, B - 1]
     with ThreadPoolExecutor(max_workers=6) as ex:
         futs = {(w, b): ex.submit(oracle.encode_image, xs[w][b].cpu().numpy(), space, qr, br) for w in (0, 1) for b in picks}
-        # three rounds as the bench does: step i on context i % 2, inputs alternating on every context
         split0 = [c.split_calls() for c in ctxs]
-        for i in range(6):
-            k, which = i % 2, (i // 2 + i) & 1
-            if i >= 2:
+        last = {}
+        for i in range(n_steps):
+            k, which = i % n_pipe, input_of(i)
+            if i >= n_pipe:
                 with torch.cuda.stream(streams[k]):
                     codec.encode_end(ctxs[k])
             with torch.cuda.stream(streams[k]):
                 codec.encode_begin(ctxs[k], xs[which], plan, *outs[k])
-            last = {**(last if i else {}), k: which}
-        for k in (0, 1):
+            last[k] = which
+        for k in range(n_pipe):
             with torch.cuda.stream(streams[k]):
                 codec.encode_end(ctxs[k])
         torch.cuda.synchronize()
-        assert all(c.split_calls() - s0 == 3 for c, s0 in zip(ctxs, split0)), "the calls were expected to run as sub-batches"
-        for k in (0, 1):
+        assert sorted(last.values()) in ([0, 0, 1], [0, 1, 1]), "both input batches must be among the contexts' last calls"
+        assert all(c.split_calls() - s0 == n_steps // n_pipe for c, s0 in zip(ctxs, split0)), "the calls were expected to run as sub-batches"
+        for k in range(n_pipe):
             enc = EncodedBatch(plan, *outs[k])
             for b in picks:
                 check_image(enc, b, futs[(last[k], b)].result(), f"context {k}, batch {last[k]}, image {b} of {B}")
@@ -515,65 +533,34 @@ def test_schedule_report_follows_the_stated_hardware_queues(env):
         ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, n))
 
 
-def test_both_64x64_dct_kernels_agree():
+def test_both_64x64_dct_kernels_and_both_plane_layouts_match_the_oracle(env, oracle):
     """launch_dct picks the one-wave 64 x 64 kernel for calls that have the device to themselves and the four-wave kernel for sub-batched /
-    pipelined ones (DctArgs::crowded).  The choice is read once per process, so each kernel is forced in a process of its own
-    (AEJ_DCT64_ONE_WAVE / AEJ_DCT64_FOUR_WAVES) on an image whose plane heights clip the last row of 64 x 64 leaves: same bytes."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prog = ("import hashlib, torch, bench, adaptive_edge_aware_jpeg_amd as A\n"
-            "x = bench.synth_batch(torch, 2, 1000, 1480, 7, torch.device('cuda', 0))\n"
-            "enc = A.Jpeg(A.JpegCompressionSettings('YCbCr', (40, 80), (4, 64))).compress_batch(x)\n"
-            "h = hashlib.sha256()\n"
-            "n64 = 0\n"
-            "for b in range(2):\n"
-            "    for l in range(3):\n"
-            "        d = enc.layer(b, l)\n"
-            "        h.update(d['coeffs'].tobytes()); h.update(d['leaves'].tobytes())\n"
-            "        n64 += int((d['leaves'][:, 2] == 64).sum())\n"
-            "print('RESULT', h.hexdigest(), n64)\n")
-    out = {}
-    for knob in ("AEJ_DCT64_ONE_WAVE", "AEJ_DCT64_FOUR_WAVES"):
-        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        env[knob] = "1"
-        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600, cwd=root)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
-        assert r.returncode == 0 and line, r.stderr[-2000:]
-        out[knob] = line[0].split()[1:]
-    assert out["AEJ_DCT64_ONE_WAVE"] == out["AEJ_DCT64_FOUR_WAVES"]
-    assert int(out["AEJ_DCT64_ONE_WAVE"][1]) > 50, "the image must contain 64 x 64 leaves"
-
-
-def test_tiled_planes_give_the_same_bytes():
-    """The normalised planes of strip-kernel shapes are kept in 4 x 4 blocks (Geom::tiled: the colour kernel stages its rows in LDS and writes
-    whole blocks, every DCT kernel's loads change their addressing); AEJ_PLANES_ROW_MAJOR keeps them row-major.  Read once per process, so the
-    two layouts run in processes of their own: same bytes, for a batch large enough for the strip kernel's 32- / 64-row strips, in two of the matrix colour spaces (the ones that use it), with planes that clip 64 x 64 leaves and CLAHE tiles 4 (mod 8) rows high (chroma blocks split between half-waves)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prog = ("import hashlib, torch, bench, adaptive_edge_aware_jpeg_amd as A\n"
-            "x = bench.synth_batch(torch, 12, 1072, 1920, 11, torch.device('cuda', 0))      # 1072 / 4 = 268 = 4 (mod 8)\n"
-            "out = []\n"
-            "for space in ('YCbCr', 'YCoCg-R'):\n"
-            "    enc = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), (4, 64))).compress_batch(x)\n"
-            "    h = hashlib.sha256()\n"
-            "    for b in (0, 5, 11):\n"
-            "        for l in range(3):\n"
-            "            d = enc.layer(b, l)\n"
-            "            h.update(d['coeffs'].tobytes()); h.update(d['leaves'].tobytes())\n"
-            "    out.append(h.hexdigest())\n"
-            "print('RESULT', *out)\n")
-    res = {}
-    for tiled in (False, True):
-        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        env.pop("AEJ_PLANES_ROW_MAJOR", None)
-        if not tiled:
-            env["AEJ_PLANES_ROW_MAJOR"] = "1"
-        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600, cwd=root)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
-        assert r.returncode == 0 and line, r.stderr[-2000:]
-        res[tiled] = line[0].split()[1:]
-    assert res[False] == res[True]
+    pipelined ones (DctArgs::crowded); the normalised planes of strip-kernel shapes are kept in 4 x 4 blocks (Geom::tiled) unless the option
+    planes_row_major says otherwise.  Every pairing of the two choices (aej_set_option "dct64_kernel" = 1 / 4, "planes_row_major" = 0 / 1) is
+    compared with the ORACLE directly -- a batch large enough for the strip kernel's 32- / 64-row strips, planes that clip the last row of
+    64 x 64 leaves, CLAHE tiles 4 (mod 8) rows high (chroma blocks split between half-waves), in two of the matrix colour spaces."""
+    torch, A, bench = env
+    B, H, W = 12, 1072, 1920                     # 1072 / 4 = 268 = 4 (mod 8)
+    x = bench.synth_batch(torch, B, H, W, 11, torch.device("cuda", 0))
+    picks = (0, 5, 11)
+    for space in ("YCbCr", "YCoCg-R"):
+        codec = A.Jpeg(A.JpegCompressionSettings(space, (40, 80), (4, 64)))
+        refs = {b: oracle.encode_image(x[b].cpu().numpy(), space, (40, 80), (4, 64)) for b in picks}
+        assert sum(int((refs[b][l]["leaves"][:, 2] == 64).sum()) for b in picks for l in range(3)) > 50, "the images must contain 64 x 64 leaves"
+        ctx = codec._bind()
+        try:
+            for kernel in (1, 4):
+                for row_major in (0, 1):
+                    ctx.set_option("dct64_kernel", kernel)
+                    ctx.set_option("planes_row_major", row_major)
+                    assert ctx.get_option("dct64_kernel") == kernel and ctx.get_option("planes_row_major") == row_major
+                    enc = codec.compress_batch(x)
+                    for b in picks:
+                        check_image(enc, b, refs[b], f"{space} dct64_kernel={kernel} planes_row_major={row_major} image {b}")
+        finally:
+            ctx.set_option("dct64_kernel", 0)
+            ctx.set_option("planes_row_major", 0)
+    with pytest.raises(ValueError):
+        ctx.set_option("dct64_kernel", 2)
+    with pytest.raises(ValueError):
+        ctx.set_option("no_such_option", 1)

@@ -114,9 +114,9 @@ def test_image_container(tmp_path, lena):
 
 
 def test_cabi_library_exports_every_declared_symbol():
-    """No compute: the library loads and every function declared in include/aej.h resolves."""
+    """No compute: the library loads and every function declared in include/*.h (the boundary aej.h and the test-only aej_testing.h) resolves."""
     from adaptive_edge_aware_jpeg_amd import _lib
-    header = open(os.path.join(ROOT, "include", "aej.h")).read()
+    header = open(os.path.join(ROOT, "include", "aej.h")).read() + open(os.path.join(ROOT, "include", "aej_testing.h")).read()
     declared = set(re.findall(r"AEJ_API[^;(]*?\b(aej_\w+)\s*\(", header))
     assert len(declared) >= 20
     lib = _lib.load_library()
@@ -182,11 +182,12 @@ def test_compat_alias_packages_expose_the_reference_import_names():
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
 
 
-def test_hardware_queue_policy_trusts_only_what_is_certain():
-    """_lib.request_hw_queues: the library is told a queue count only when the package can be sure the HIP runtime
-    starts (or started) with it -- variable already in the environment, or package imported before torch; after torch it assumes 4."""
+def test_hardware_queue_policy_import_has_no_side_effect():
+    """_lib: importing the package never writes the environment; the library is told a queue count only
+    when the package can be sure the HIP runtime starts (or started) with it -- variable already in the environment, or the explicit
+    configure_hw_queues() before HIP is up; otherwise HIP's default of 4."""
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "AEJ_KEEP_HW_QUEUES")}
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
 
     def run(code, extra=None):
@@ -195,8 +196,10 @@ def test_hardware_queue_policy_trusts_only_what_is_certain():
         return r.stdout.strip().splitlines()[-1]
 
     probe = "import adaptive_edge_aware_jpeg_amd as A, os; print(A.hw_queues()[0], os.environ.get('GPU_MAX_HW_QUEUES'))"
-    assert run(probe) == "16 16"                                                    # before torch: asked for and trusted
-    assert run("import torch\n" + probe) == "4 16"                                # after torch: asked for, NOT trusted
+    assert run(probe) == "4 None"                                                   # import: environment untouched, HIP's default assumed
+    assert run("import torch\n" + probe) == "4 None"
     assert run("import torch\n" + probe, {"GPU_MAX_HW_QUEUES": "12"}) == "12 12"   # present at process start: trusted as it is
-    assert run(probe, {"AEJ_KEEP_HW_QUEUES": "1"}) == "4 None"                      # opt-out: environment untouched
+    opt_in = "import adaptive_edge_aware_jpeg_amd as A, os; A.configure_hw_queues(); print(A.hw_queues()[0], os.environ.get('GPU_MAX_HW_QUEUES'))"
+    assert run(opt_in) == "16 16"                                                   # explicit opt-in before torch: set and trusted
+    assert run(opt_in, {"GPU_MAX_HW_QUEUES": "8"}) == "8 8"                         # never overrides the launcher
     assert run("import adaptive_edge_aware_jpeg_amd as A; A.set_hw_queues(24); print(A.hw_queues()[0])") == "24"

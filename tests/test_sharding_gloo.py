@@ -94,6 +94,45 @@ def test_bench_multi_rank_control_flow_rehearsal(extra, scaling, images):
     assert rk["ms_per_step_by_rank"][1] > rk["ms_per_step_by_rank"][0] > 0 and rk["all_verified"] and not rk["any_miss"]
 
 
+def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with NO rank variables in the environment starts its two ranks itself (a child
+    `python -m torch.distributed.run`, never an exec), relays rank 0's JSON line and exits with the child's code; a --gpus that
+    disagrees with an external launcher's WORLD_SIZE fails loudly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env["AEJ_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-control-flow", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "3", "--height", "64", "--width", "96"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"]["n_ranks_seen"] == 2 and line["ranks"]["local_ranks_seen"] == [0, 1]
+    assert line["pixels_total"] == 2 * 3 * 64 * 96 * 2
+    # the child's failure is the parent's exit code
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-control-flow", "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--batch", "1", "--height", "64", "--width", "64"], env=dict(env, AEJ_REHEARSE_BAD_RANK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    # --gpus against a launcher's WORLD_SIZE
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-control-flow", "--gpus", "4"],
+                       env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr
+
+
+def test_a_rank_that_never_verified_fails_the_run():
+    """`all_verified` needs an explicit pass from EVERY rank; a rank that skipped or never reached its check (None) fails the
+    run unless verification was switched off for the whole run."""
+    from adaptive_edge_aware_jpeg_amd.sharding import gather_rank_report
+    r = gather_rank_report(None, 0, 1.0, 0, None)
+    assert not r["all_verified"] and r["unverified_ranks"] == [0]
+    assert gather_rank_report(None, 0, 1.0, 0, None, require_verified=False)["all_verified"]
+    assert not gather_rank_report(None, 0, 1.0, 0, False, require_verified=False)["all_verified"]
+
+
 def test_bench_fails_on_every_rank_when_one_rank_fails_its_oracle_check():
     """A rank whose outputs differ from the oracle's must fail the whole run: rank 1 reports a failed check (rehearsal switch), the
     all_gather carries it to rank 0, the JSON line shows it and BOTH processes exit non-zero."""
