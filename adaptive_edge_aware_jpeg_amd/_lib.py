@@ -121,7 +121,6 @@ SIGNATURES = {
     "aej_last_error": (ctypes.c_char_p, [_P]),
     "aej_synchronize": (_I, [_P]),
     "aej_set_stream": (_I, [_P, _P]),
-    "aej_set_hysteresis_speculation": (_I, [_P, _I]),
     "aej_get_hysteresis_stats": (_I, [_P, _P]),
     "aej_set_graph_mode": (_I, [_P, _I]),
     "aej_set_sub_batches": (_I, [_P, _I]),
@@ -134,8 +133,6 @@ SIGNATURES = {
     "aej_encode_batch_end": (_I, [_P]),
     "aej_get_split_calls": (ctypes.c_int64, [_P]),
     "aej_get_graph_stats": (_I, [_P, _P]),
-    "aej_last_hysteresis_passes": (_I, [_P]),
-    "aej_set_hysteresis_hint": (_I, [_P, _I, _I]),
     "aej_set_profiling": (_I, [_P, _I]),
     "aej_get_stage_ms": (_I, [_P, _P]),
     "aej_stage_name": (ctypes.c_char_p, [_I]),
@@ -247,10 +244,11 @@ class Context:
         return self._ws
 
     def hysteresis_stats(self):
-        """-> dict(calls, speculative, misses, enqueued) of aej_encode_batch on this context (include/aej.h)."""
-        buf = (ctypes.c_int64 * 4)()
+        """-> dict(calls, queued): whole-path calls on this context, tiles that went through the device-side hysteresis work queue
+        in the last completed call (include/aej.h)."""
+        buf = (ctypes.c_int64 * 2)()
         self.check(self.lib.aej_get_hysteresis_stats(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
-        return {"calls": int(buf[0]), "speculative": int(buf[1]), "misses": int(buf[2]), "enqueued": int(buf[3])}
+        return {"calls": int(buf[0]), "queued": int(buf[1])}
 
     def set_canny_params(self, params=None):
         """aej_set_canny_params: (low_ratio, high_ratio, clip_limit, sigma_color, sigma_space, use_l2) or None for the defaults"""
@@ -291,9 +289,6 @@ class Context:
         buf = (ctypes.c_int64 * 3)()
         self.check(self.lib.aej_get_graph_stats(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
         return {"launches": int(buf[0]), "captures": int(buf[1]), "cached": int(buf[2])}
-
-    def set_speculation(self, on):
-        self.check(self.lib.aej_set_hysteresis_speculation(self.handle, 1 if on else 0))
 
     def to_device(self, arr, dtype):
         t = self.torch

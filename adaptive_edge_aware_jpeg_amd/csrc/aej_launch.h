@@ -31,9 +31,9 @@ struct CannyBuffers {
     int *thr;               // [B][3][2]
     unsigned long long *weak;    // [B][bpstride] NMS candidates (bit-plane)
     unsigned long long *strong;  // [B][bpstride] strong edges, grown by the hysteresis passes -> final edge map
-    int *hflags;            // [2][B * tiles] "already queued" flags, one parity per pass
-    int *hlist;             // [2][B * tiles] work lists of dirty tiles
-    int *pass_count;        // [kMaxHystPasses + 1] tiles queued for pass p (pass 0 = every tile)
+    int *hflags;            // [B * tiles] 1 while the tile is in the hysteresis work queue
+    int *hlist;             // [hyst_ring_slots()] the queue: a ring of tile + 1 (0 = empty slot)
+    int *pass_count;        // [kHystCounters] queue counters tail / head / done, 128 bytes apart (canny.hip kQTail ...)
     const float *space_w;   // [13]
     const float *color_w;   // [256]
     // run-time hyper-parameters of EdgeDetection.canny (edge_detection.py:31-40; aej_set_canny_params)
@@ -43,16 +43,15 @@ struct CannyBuffers {
     // optional stage dumps (stand-alone entry point only)
     unsigned char *dump_clahe, *dump_gauss;
 };
-constexpr int kMaxHystPasses = 4096;
+constexpr int kHystCounters = 128;
 long long hyst_tiles_per_image(const Geom &g);
+int hyst_ring_slots(const Geom &g);
 void launch_clahe_pad_hist(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_clahe_lut(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb);
 void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, const Tuning &t);
-void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass);
-void launch_hyst_finish(hipStream_t st, const Geom &g, const CannyBuffers &cb, int first_pass);   // one workgroup: passes first_pass .. fix-point
-constexpr long long kHystFinishTiles = 4096;   // problems of at most this many 64x64 tiles finish their hysteresis inside one launch
+void launch_hysteresis(hipStream_t st, const Geom &g, const CannyBuffers &cb);      // pass over every tile + device-side drain of the work queue
 void launch_zero(hipStream_t st, void *p16, size_t bytes_multiple_of_16);
 void launch_bits_to_edge(hipStream_t st, const Geom &g, const unsigned long long *strong, unsigned char *edge01);
 void launch_bits_to_map(hipStream_t st, const Geom &g, const unsigned long long *weak, const unsigned long long *strong, unsigned char *map);

@@ -18,6 +18,7 @@
 using namespace aej;
 
 struct aej_pending;
+constexpr int kFlagWords = 16;       // [0] quadtree overflow flag, [1] hysteresis queue entries (diagnostic)
 struct aej_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -32,24 +33,18 @@ struct aej_ctx {
     const float *d_space_w = nullptr, *d_color_w = nullptr;
     float *d_bilateral = nullptr;      // [16 + 256] space / colour weights of the bilateral filter (own allocation: aej_set_canny_params rebuilds it)
     aej_canny_params canny = { 0.10, 0.30, 0.75, 75.0, 75.0, 1 };     // edge_detection.py:31-40 defaults
-    int *h_flag = nullptr;             // pinned host word for counter read-backs
-    int last_hyst_passes = 0;
-    int hyst_hint = 0;                 // passes the previous encode needed (speculative enqueue, verified at the end of the call)
-    int hyst_margin = 3;               // extra passes enqueued on top of the hint: shrinks to 2 while calls keep converging early, grows by 2 after a miss
-                                       // (round 3: 3 / streak of 4, was 4 / 8 -- every spare pass is a launch in the part's chain: 64 x 4K 6.58 -> 6.49 ms at margin 2)
-    int hyst_streak = 0;               // consecutive calls that converged with at least 2 spare passes
-    int hyst_enqueued = 0;             // passes enqueued speculatively by the current call (0 = verified path)
+    int *h_flag = nullptr;             // pinned host words for counter read-backs (kFlagWords)
+    long long last_hyst_queued = 0;    // tiles that went through the hysteresis work queue in the last whole-path call (diagnostic)
     bool capturing = false;            // the stream is being captured into a hipGraph: kernel nodes only (zero-fill by kernel, no copies)
-    bool hyst_speculate = true;        // aej_set_hysteresis_speculation: false = every whole-path call runs the verified loop
-    long long n_encode_calls = 0, n_spec_calls = 0, n_spec_misses = 0;   // aej_get_hysteresis_stats
-    // launch-latency path (aej_set_graph_mode): the whole speculative launch sequence of one encode call captured in a hipGraph,
+    long long n_encode_calls = 0;      // aej_get_hysteresis_stats
+    // launch-latency path (aej_set_graph_mode): the whole launch sequence of one encode call captured in a hipGraph,
     // keyed by everything its kernel arguments depend on, and replayed on a private stream
     int graph_mode = 0;                // 0 off (default: measured slower than eager launches), 1 automatic (small batches only), 2 always when possible
     hipStream_t gstream = nullptr;
     hipEvent_t gevent = nullptr;
     struct GraphEntry {
         const void *rgb; void *coeffs, *leaves, *states, *counts, *dct, *ws;
-        int batch, H, W, in_u8, passes;
+        int batch, H, W, in_u8;
         hipGraphExec_t exec;
         unsigned long long last_use;
     };
@@ -320,12 +315,12 @@ static void carve_canny(Carver &c, const Geom &g, CannyWs &w)
     w.cb.strong = c.take<unsigned long long>((long long)g.B * g.bpstride);
     w.cb.lut = c.take<unsigned char>((long long)g.B * 3 * 16 * 256);
     w.cb.thr = c.take<int>((long long)g.B * 3 * 2);
-    w.cb.hlist = c.take<int>(2 * tiles);
     w.zero_begin = reinterpret_cast<char *>(c.take<int>(0));
+    w.cb.hlist = c.take<int>(hyst_ring_slots(g));
     w.cb.tile_hist = c.take<int>((long long)g.B * 3 * 16 * 256);
     w.cb.blur_hist = c.take<int>((long long)g.B * 3 * 256);
-    w.cb.pass_count = c.take<int>(kMaxHystPasses + 1);
-    w.cb.hflags = c.take<int>(2 * tiles);
+    w.cb.pass_count = c.take<int>(kHystCounters);
+    w.cb.hflags = c.take<int>(tiles);
     c.take<int>(0);
     w.zero_end = c.base ? c.base + c.off : nullptr;
 }
@@ -368,7 +363,7 @@ extern "C" aej_ctx *aej_create(int device, void *hip_stream)
     aej_ctx *ctx = new aej_ctx();
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flag), kFlagWords * sizeof(int), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -553,47 +548,9 @@ extern "C" int aej_set_canny_params(aej_ctx *ctx, const aej_canny_params *p)
 }
 
 // ---- Canny chain on a prepared uint8 buffer (cb.u8a) ------------------------------------------------------
-// Hysteresis passes.  Verified mode: groups of 8 passes, one counter read-back per group until a pass queues nothing.
-// Speculative mode (whole-path encode, after a first call): enqueue as many passes as the previous call needed plus a
-// margin WITHOUT reading anything back -- a pass whose work list is empty is a ~2 us no-op -- and let the caller verify
-// pass_count[n] == 0 together with its final synchronisation (finish_hysteresis).
-static bool hyst_small(const Geom &g) { return hyst_tiles_per_image(g) * g.B <= kHystFinishTiles; }
-
-static int run_hysteresis(aej_ctx *ctx, const Geom &g, CannyWs &w, bool speculate = false, int first_pass = 0)
-{
-    hipStream_t st = ctx->stream;
-    const int group = 8;
-    int pass = first_pass;
-    ctx->hyst_enqueued = 0;
-    if (first_pass == 0 && hyst_small(g)) {
-        // small problem: pass 0 over every tile, then one workgroup iterates to the fix-point inside a single launch
-        // (k_hyst_finish) -- nothing to speculate on, nothing to read back
-        launch_hyst_pass(st, g, w.cb, 0);
-        launch_hyst_finish(st, g, w.cb, 1);
-        ctx->last_hyst_passes = 2;
-        return 0;
-    }
-    if (speculate && ctx->hyst_speculate && ctx->hyst_hint > 0 && first_pass == 0) {
-        int n = ctx->hyst_hint + ctx->hyst_margin;
-        if (n > kMaxHystPasses - group) n = kMaxHystPasses - group;
-        for (int i = 0; i < n; i++) launch_hyst_pass(st, g, w.cb, pass++);
-        ctx->hyst_enqueued = n;
-        ctx->last_hyst_passes = n;
-        return 0;
-    }
-    for (;;) {
-        for (int i = 0; i < group; i++) launch_hyst_pass(st, g, w.cb, pass++);
-        AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.cb.pass_count + pass, sizeof(int), hipMemcpyDeviceToHost, st));
-        AEJ_HIP_CHECK(hipStreamSynchronize(st));
-        if (*ctx->h_flag == 0) break;
-        if (pass + group > kMaxHystPasses) return fail(ctx, AEJ_ERR_STATE, "hysteresis did not converge in %d passes", pass);
-    }
-    ctx->last_hyst_passes = pass;
-    ctx->hyst_hint = pass;
-    return 0;
-}
-
-static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool speculate)
+// The hysteresis is two launches whatever the image holds: a pass over every tile, then the queue of dirtied tiles drained to the
+// fix-point on the device (canny.hip k_hyst_drain) -- no pass count for the host to guess, nothing to read back, nothing to repair.
+static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w)
 {
     hipStream_t st = ctx->stream;
     launch_clahe_pad_hist(st, g, w.cb);
@@ -611,8 +568,7 @@ static int run_canny_chain(aej_ctx *ctx, const Geom &g, CannyWs &w, bool specula
     launch_sobel_nms(st, g, w.cb, ctx->tune);
     mark(ctx, AEJ_STAGE_SOBEL_NMS);
     if (ctx->chain_hook == 3) publish();
-    int rc = run_hysteresis(ctx, g, w, speculate);
-    if (rc) return rc;
+    launch_hysteresis(st, g, w.cb);
     mark(ctx, AEJ_STAGE_HYSTERESIS);
     AEJ_HIP_CHECK(hipGetLastError());
     return 0;
@@ -804,64 +760,24 @@ static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &
     return 0;
 }
 
-// the counters one call reads back: the quadtree's overflow flag and, when the hysteresis passes were enqueued speculatively,
-// their work-list sizes
-static int enqueue_readback(aej_ctx *ctx, EncodeWs &w, int n_spec)
+// the counters one call reads back: the quadtree's overflow flag and (a diagnostic) how many tiles went through the hysteresis queue
+static int enqueue_readback(aej_ctx *ctx, EncodeWs &w)
 {
     AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, w.qt.qb.overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (n_spec > 0) AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag + 1, w.canny.cb.pass_count, (size_t)(n_spec + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag + 1, w.canny.cb.pass_count + 32 /* kQTail */, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return 0;
-}
-
-// after the final synchronisation of a speculative call: did the edge map reach its fix-point within the n passes whose work-list
-// sizes are pc[0..n]?  -> passes actually needed, or -1 (the hysteresis has to be finished and quadtree + DCT redone)
-static int speculation_used(const int *pc, int n)
-{
-    if (pc[n] != 0) return -1;
-    int used = n;
-    while (used > 1 && pc[used - 1] == 0) used--;
-    return used;
-}
-
-// hint / margin for the next call from this call's outcome: `used` = passes needed (the largest over the sub-batches), or -1 = miss
-static void speculation_update(aej_ctx *ctx, int n, int used)
-{
-    ctx->n_spec_calls++;
-    if (used >= 0) {                        // converged within the speculative passes: remember how many were needed
-        ctx->hyst_hint = used;
-        ctx->last_hyst_passes = used;
-        if (n - used >= 2) {
-            if (++ctx->hyst_streak >= 4 && ctx->hyst_margin > 2) { ctx->hyst_margin--; ctx->hyst_streak = 0; }
-        } else {
-            ctx->hyst_streak = 0;
-        }
-        return;
-    }
-    ctx->hyst_streak = 0;
-    ctx->n_spec_misses++;
-    if (ctx->hyst_margin < 8) ctx->hyst_margin += 2;
-}
-
-static bool speculation_missed(aej_ctx *ctx, int n)
-{
-    const int used = speculation_used(ctx->h_flag + 1, n);
-    speculation_update(ctx, n, used);
-    return used < 0;
 }
 
 constexpr long long kGraphAutoPixels = 8LL << 20;      // automatic graph mode: calls of at most 8 Mpx (launch latency matters there)
 constexpr size_t kMaxGraphs = 8;
 
-// Launch-latency path: the speculative sequence (about 25 launches for 4-64 blocks) as ONE hipGraphLaunch.  The graph is captured
+// Launch-latency path: the whole sequence (about 20 launches for 4-64 blocks) as ONE hipGraphLaunch.  The graph is captured
 // on a private stream (the caller's may be the legacy null stream, which cannot be captured) ordered behind the caller's stream
-// by an event, and cached under every pointer / shape / pass count its kernel arguments contain.
+// by an event, and cached under every pointer / shape its kernel arguments contain.
 static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g, const QtGeom &q, EncodeWs &w, int32_t *coeffs, int32_t *leaves,
                         uint8_t *states, int64_t *counts, float *dct_f32, void *workspace, bool &used)
 {
     used = false;
-    const bool small = hyst_small(g);               // hysteresis = pass 0 + one finishing launch, no pass count to guess (n = -1)
-    int n = small ? -1 : ctx->hyst_hint + ctx->hyst_margin;
-    if (n > kMaxHystPasses - 8) n = kMaxHystPasses - 8;
     if (!ctx->gstream) {
         AEJ_HIP_CHECK(hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking));
         AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->gevent, hipEventDisableTiming));
@@ -869,7 +785,7 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
     aej_ctx::GraphEntry *hit = nullptr;
     for (auto &e : ctx->graphs)
         if (e.rgb == rgb && e.coeffs == coeffs && e.leaves == leaves && e.states == states && e.counts == counts && e.dct == dct_f32 && e.ws == workspace &&
-            e.batch == g.B && e.H == g.H && e.W == g.W && e.in_u8 == (int)in_u8 && e.passes == n) { hit = &e; break; }
+            e.batch == g.B && e.H == g.H && e.W == g.W && e.in_u8 == (int)in_u8) { hit = &e; break; }
     hipStream_t user = ctx->stream;
     if (!hit) {
         // first sight of this combination of buffers: only remember it and let the caller run the ordinary path -- a caller that
@@ -880,7 +796,7 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
             if (ctx->graphs[lru].exec) (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
             ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
         }
-        ctx->graphs.push_back({ rgb, coeffs, leaves, states, counts, dct_f32, workspace, g.B, g.H, g.W, (int)in_u8, n, nullptr, ++ctx->graph_clock });
+        ctx->graphs.push_back({ rgb, coeffs, leaves, states, counts, dct_f32, workspace, g.B, g.H, g.W, (int)in_u8, nullptr, ++ctx->graph_clock });
         return 0;
     }
     if (!hit->exec) {
@@ -898,12 +814,7 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
             launch_clahe_blur(st, g, w.canny.cb);
             launch_thresholds(st, g, w.canny.cb);
             launch_sobel_nms(st, g, w.canny.cb, ctx->tune);
-            if (small) {
-                launch_hyst_pass(st, g, w.canny.cb, 0);
-                launch_hyst_finish(st, g, w.canny.cb, 1);
-            } else {
-                for (int i = 0; i < n; i++) launch_hyst_pass(st, g, w.canny.cb, i);
-            }
+            launch_hysteresis(st, g, w.canny.cb);
             rc = enqueue_back(ctx, g, q, w, coeffs, dct_f32);
         }
         hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(ctx->gstream, &graph) : hipSuccess;
@@ -927,13 +838,11 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
     AEJ_HIP_CHECK(hipGraphLaunch(hit->exec, ctx->gstream));
     // the counter read-back stays outside the graph (ordinary copies behind it on the same stream): kernel nodes only, see clear_canny_ws
     ctx->stream = ctx->gstream;
-    const int rb = enqueue_readback(ctx, w, small ? 0 : n);
+    const int rb = enqueue_readback(ctx, w);
     ctx->stream = user;
     if (rb) return rb;
     AEJ_HIP_CHECK(hipStreamSynchronize(ctx->gstream));
     ctx->n_graph_launches++;
-    ctx->hyst_enqueued = small ? 0 : n;
-    ctx->last_hyst_passes = small ? 2 : n;
     used = true;
     return 0;
 }
@@ -941,11 +850,10 @@ static int encode_graph(aej_ctx *ctx, const void *rgb, bool in_u8, const Geom &g
 // ---- sub-batch pipelining ------------------------------------------------------------------------------------
 // How many sub-batches a call is cut into (automatic mode: by call size and by how many hardware queues the process has, below;
 // smaller calls have too few workgroups per kernel to share the chip).  Never for profiled calls (the
-// stage timings describe the serial chain), graph replay, the verified (host-synchronising) hysteresis loop, or shapes that need the
-// host-built INTER_AREA tables.
+// stage timings describe the serial chain), graph replay, or shapes that need the host-built INTER_AREA tables.
 static int sub_batches(const aej_ctx *ctx, const Geom &g, int hw_queues, bool as_if_unprofiled = false)
 {
-    if (ctx->sub_mode == 1 || (ctx->profiling && !as_if_unprofiled) || ctx->graph_mode == 2 || !planes_fast_ok(g) || !ctx->hyst_speculate) return 1;
+    if (ctx->sub_mode == 1 || (ctx->profiling && !as_if_unprofiled) || ctx->graph_mode == 2 || !planes_fast_ok(g)) return 1;
     int n = ctx->sub_mode;
     if (n == 0) {
         const long long px = (long long)g.B * g.H * g.W;
@@ -981,9 +889,9 @@ static unsigned long long sub_ws_bytes(Geom g, const QtGeom &q, int nsub)
     return encode_ws_bytes(g, q);
 }
 
-// One call in flight: everything aej_encode_batch_end needs to verify (and, after a speculation miss, repair) what
-// aej_encode_batch_begin enqueued.  Part 0 is the whole batch on the context's stream, or parts 0..n-1 are the sub-batches.
-struct EncodePart { Geom g; EncodeWs w; bool whole_call = false; int n_spec = 0; int32_t *coeffs = nullptr; float *dct = nullptr; hipStream_t stream = nullptr; int *flag = nullptr; bool used = false; };
+// One call in flight: everything aej_encode_batch_end needs to complete and check what aej_encode_batch_begin enqueued.  Part 0 is the
+// whole batch on the context's stream, or parts 0..n-1 are the sub-batches.
+struct EncodePart { Geom g; EncodeWs w; bool whole_call = false; int32_t *coeffs = nullptr; float *dct = nullptr; hipStream_t stream = nullptr; int *flag = nullptr; bool used = false; };
 struct aej_pending {
     bool active = false, complete = false;     // complete: already synchronised and verified (graph replay)
     QtGeom q;
@@ -1000,8 +908,8 @@ static aej_pending &pending_of(aej_ctx *ctx)
     return *ctx->pending;
 }
 
-// the launch sequence of one part on ctx->stream / ctx->h_flag (both set by the caller): clear, colour planes, Canny chain with the
-// speculative hysteresis, quadtree, DCT, counter read-back.  `after` / `done`: sub-batch staggering (null for the unsplit call).
+// the launch sequence of one part on ctx->stream / ctx->h_flag (both set by the caller): clear, colour planes, Canny chain, quadtree,
+// DCT, counter read-back.  `after` / `done`: sub-batch staggering (null for the unsplit call).
 static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void *rgb, bool in_u8, hipEvent_t done)
 {
     int rc;
@@ -1030,13 +938,12 @@ static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void
     struct HookGuard { aej_ctx *c; ~HookGuard() { c->chain_hook = 0; } } hook_guard{ ctx };
     ctx->chain_hook = (chain && chain_mode > 1) ? chain_mode : 0;
     ctx->chain_event = done;
-    if ((rc = run_canny_chain(ctx, p.g, p.w.canny, true))) return rc;      // first call (no hint yet): verified loop, synchronises this stream
+    if ((rc = run_canny_chain(ctx, p.g, p.w.canny))) return rc;
     ctx->chain_hook = 0;
-    p.n_spec = ctx->hyst_enqueued;
     if ((rc = injected_failure(ctx, AEJ_STAGE_HYSTERESIS))) return rc;
     if ((rc = enqueue_back(ctx, p.g, q, p.w, p.coeffs, p.dct))) return rc;
     if ((rc = injected_failure(ctx, AEJ_STAGE_DCT_64))) return rc;
-    return enqueue_readback(ctx, p.w, p.n_spec);      // one read-back for the whole part
+    return enqueue_readback(ctx, p.w);      // one read-back for the whole part
 }
 
 static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batch, int H, int W, int32_t *coeffs, int32_t *leaves,
@@ -1070,7 +977,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
 
     if (nsub == 1) {
         EncodePart &p = pd.parts[0];
-        p.g = g; p.coeffs = coeffs; p.dct = dct_f32; p.stream = user; p.flag = user_flag; p.n_spec = 0; p.used = true; p.whole_call = true;
+        p.g = g; p.coeffs = coeffs; p.dct = dct_f32; p.stream = user; p.flag = user_flag; p.used = true; p.whole_call = true;
         p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8, ctx->tune);
         carve_encode(workspace, g, q, p.w);
         if (p.w.bytes > workspace_bytes) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small: need %llu bytes, got %llu", p.w.bytes, (unsigned long long)workspace_bytes);
@@ -1079,17 +986,17 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         p.w.qt.qb.states = states;
         p.w.qt.qb.counts = reinterpret_cast<long long *>(counts);
         bool graphed = false;
-        const bool want_graph = ctx->graph_mode != 0 && !ctx->profiling && (hyst_small(g) || (ctx->hyst_speculate && ctx->hyst_hint > 0)) && planes_fast_ok(g) &&
+        const bool want_graph = ctx->graph_mode != 0 && !ctx->profiling && planes_fast_ok(g) &&
                                 (ctx->graph_mode == 2 || (long long)batch * H * W <= kGraphAutoPixels);
         // (p.g, not g: capture, replay and a miss repair in encode_end_impl must share one plane layout -- Geom::tiled)
         if (want_graph && (rc = encode_graph(ctx, rgb, in_u8, p.g, q, p.w, coeffs, leaves, states, counts, dct_f32, workspace, graphed))) {
             if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);       // a replay whose read-back failed may still be running
             return rc;
         }
-        if (graphed) { p.n_spec = ctx->hyst_enqueued; pd.complete = true; }      // the replay path has synchronised its own stream
+        if (graphed) pd.complete = true;      // the replay path has synchronised its own stream
         else {
             if (!ctx->sub_color_done[0]) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->sub_color_done[0], hipEventDisableTiming));
-            rc = enqueue_part(ctx, p, q, rgb, in_u8, hyst_small(g) ? nullptr : ctx->sub_color_done[0]);      // (latency-sized calls stay out of the chain)
+            rc = enqueue_part(ctx, p, q, rgb, in_u8, hyst_tiles_per_image(g) * g.B <= 4096 ? nullptr : ctx->sub_color_done[0]);      // (latency-sized calls stay out of the chain)
         }
         // also after an error: whatever enqueue_part had already put on the stream is drained by the caller (encode_end_impl), exactly as
         // on the sub-batch path below
@@ -1107,7 +1014,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         if (!ctx->sub_color_done[i]) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->sub_color_done[i], hipEventDisableTiming));
         if (!ctx->sub_stream[i]) {
             AEJ_HIP_CHECK(hipStreamCreateWithFlags(&ctx->sub_stream[i], hipStreamNonBlocking));
-            AEJ_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->sub_flag[i]), (kMaxHystPasses + 16) * sizeof(int), hipHostMallocDefault));
+            AEJ_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->sub_flag[i]), kFlagWords * sizeof(int), hipHostMallocDefault));
         }
     }
     if (!ctx->sub_in) AEJ_HIP_CHECK(hipEventCreateWithFlags(&ctx->sub_in, hipEventDisableTiming));
@@ -1120,7 +1027,6 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
         p.g = g;
         p.g.B = b1 - b0;
         p.g.tiled = planes_fast_ok(p.g) && color_planes_can_tile(p.g, ctx->space, in_u8, ctx->tune);      // (decided per part: the strip height depends on the part's batch)
-        p.n_spec = 0;
         carve_encode(static_cast<char *>(workspace) + (size_t)i * slice, p.g, q, p.w);
         apply_canny_params(ctx, p.w.canny.cb);
         p.w.qt.qb.leaves = leaves + (long long)b0 * q.leaf_stride * 4;
@@ -1146,7 +1052,7 @@ static int encode_begin_impl(aej_ctx *ctx, const void *rgb, bool in_u8, int batc
 }
 
 // completion of the call in flight: every stream it used is drained (also after an error: nothing may still be running when the
-// caller sees the result), the counters are checked and a part whose speculative pass count was too small is repaired
+// caller sees the result) and the device-side counters are checked
 static int encode_end_impl(aej_ctx *ctx, int rc_begin)
 {
     if (!ctx) return AEJ_ERR_ARG;
@@ -1155,45 +1061,18 @@ static int encode_end_impl(aej_ctx *ctx, int rc_begin)
     pd.active = false;
     { std::lock_guard<std::mutex> lock(g_chain_mutex); if (g_calls_in_flight[ctx->device] > 0) g_calls_in_flight[ctx->device]--; }
     (void)hipSetDevice(ctx->device);
-    hipStream_t user = ctx->stream;
-    int *user_flag = ctx->h_flag;
-    const QtGeom &q = pd.q;
-    int rc = rc_begin, used_max = 0, n_spec = 0;
-    bool missed = false;
+    int rc = rc_begin;
+    long long queued = 0;
     for (EncodePart &p : pd.parts) {
         if (!p.used) continue;                    // not reached by a failed begin
-        ctx->stream = p.stream;
-        ctx->h_flag = p.flag;
-        hipError_t e = pd.complete ? hipSuccess : hipStreamSynchronize(ctx->stream);
+        hipError_t e = pd.complete ? hipSuccess : hipStreamSynchronize(p.stream);
         if (e != hipSuccess && !rc) rc = hip_fail(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
         if (rc) continue;
-        if (*ctx->h_flag) { rc = fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass"); continue; }
-        if (p.n_spec > 0) {
-            n_spec = p.n_spec;
-            const int used = speculation_used(ctx->h_flag + 1, p.n_spec);
-            if (used < 0) {
-                // rare: this part's edge map was not at its fix-point when its quadtree ran -- finish the hysteresis, redo what follows
-                missed = true;
-                if (!(rc = run_hysteresis(ctx, p.g, p.w.canny, false, p.n_spec)) && !(rc = enqueue_back(ctx, p.g, q, p.w, p.coeffs, p.dct)) &&
-                    !(rc = enqueue_readback(ctx, p.w, 0))) {
-                    e = hipStreamSynchronize(ctx->stream);
-                    if (e != hipSuccess) rc = hip_fail(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
-                    else if (*ctx->h_flag) rc = fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass");
-                }
-                used_max = std::max(used_max, ctx->last_hyst_passes);
-            } else {
-                used_max = std::max(used_max, used);
-            }
-        } else {
-            used_max = std::max(used_max, ctx->last_hyst_passes);     // verified loop / one-launch finish: run_hysteresis left the count there
-        }
+        if (p.flag[0]) { rc = fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass"); continue; }
+        queued += p.flag[1];
     }
-    ctx->stream = user;
-    ctx->h_flag = user_flag;
     if (rc) return rc;
-    if (n_spec > 0) speculation_update(ctx, n_spec, missed ? -1 : used_max);
-    if (used_max > 0) { ctx->last_hyst_passes = used_max; if (n_spec > 0) ctx->hyst_hint = used_max; }
-    ctx->hyst_enqueued = n_spec;
+    ctx->last_hyst_queued = queued;
     if (ctx->profiling) collect_marks(ctx);
     return 0;
 }
@@ -1304,7 +1183,7 @@ extern "C" int aej_canny(aej_ctx *ctx, const float *plane, int H, int W, uint8_t
     Geom ge = g;
     ge.pstride = n;   // uint8 outputs are exactly H*W
     if (stages) launch_bits_to_map(st, ge, w.cb.weak, w.cb.strong, stages + 4 * n);
-    if ((rc = run_hysteresis(ctx, g, w))) return rc;
+    launch_hysteresis(st, g, w.cb);
     launch_bits_to_edge(st, ge, w.cb.strong, edge);
     AEJ_HIP_CHECK(hipGetLastError());
     AEJ_HIP_CHECK(hipStreamSynchronize(st));
@@ -1621,32 +1500,11 @@ extern "C" int aej_metrics_batch(aej_ctx *ctx, const float *img_a, const float *
     return 0;
 }
 
-extern "C" int aej_last_hysteresis_passes(aej_ctx *ctx) { return ctx ? ctx->last_hyst_passes : -1; }
-
-extern "C" int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin)
-{
-    if (!ctx || passes < 0 || margin < 0) return AEJ_ERR_ARG;
-    ctx->hyst_hint = passes;       // 0 = next whole-path call runs in verified mode
-    ctx->hyst_margin = margin;
-    ctx->hyst_streak = 0;
-    return 0;
-}
-
-extern "C" int aej_set_hysteresis_speculation(aej_ctx *ctx, int enable)
-{
-    if (!ctx) return AEJ_ERR_ARG;
-    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
-    ctx->hyst_speculate = enable != 0;
-    return 0;
-}
-
 extern "C" int aej_get_hysteresis_stats(aej_ctx *ctx, int64_t *out_host)
 {
     if (!ctx || !out_host) return AEJ_ERR_ARG;
     out_host[0] = ctx->n_encode_calls;
-    out_host[1] = ctx->n_spec_calls;
-    out_host[2] = ctx->n_spec_misses;
-    out_host[3] = ctx->hyst_enqueued;
+    out_host[1] = ctx->last_hyst_queued;
     return 0;
 }
 

@@ -50,6 +50,14 @@ static long long tiles_per_image(const Geom &g, int TW, int TH)
     return n;
 }
 long long hyst_tiles_per_image(const Geom &g) { return tiles_per_image(g, kHystTile, kHystTile); }
+// slots of the hysteresis work queue: the largest power of two <= 2 x tiles (>= tiles: a tile is queued at most once at a time)
+int hyst_ring_slots(const Geom &g)
+{
+    const long long t2 = 2 * hyst_tiles_per_image(g) * g.B;
+    int p = 1;
+    while (2LL * p <= t2) p *= 2;
+    return p;
+}
 
 // ------------------------------------------------------------------------------------------------
 // CLAHE: histogram contribution of the REFLECT_101 padding (only when h%4 or w%4 != 0), clahe.cpp
@@ -1185,166 +1193,227 @@ __global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g,
 // pass 1 on the wave follows one of them itself, see CHASE below).  Strong bits only ever get set, so the global
 // fix-point is unique = OpenCV's stack flood fill.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed, unsigned long long open)
+// Kogge-Stone occluded fill along the rows: the bits of `seed` spread through runs of `open` bits, to the left and to the right.  The
+// masks "the next 1, 2, 4, ... bits are all open" do not depend on the seed: they are formed once per tile (RunMasks), so that a fill is
+// 6 x 2 x (shift, and, or).
+struct RunMasks { unsigned long long l1, l2, l4, l8, l16, l32, r1, r2, r4, r8, r16, r32; };
+__device__ __forceinline__ RunMasks run_masks(unsigned long long open)
 {
-    unsigned long long gL = seed, pL = open, gR = seed, pR = open;
-    gL |= pL & (gL << 1);  pL &= pL << 1;   gR |= pR & (gR >> 1);  pR &= pR >> 1;
-    gL |= pL & (gL << 2);  pL &= pL << 2;   gR |= pR & (gR >> 2);  pR &= pR >> 2;
-    gL |= pL & (gL << 4);  pL &= pL << 4;   gR |= pR & (gR >> 4);  pR &= pR >> 4;
-    gL |= pL & (gL << 8);  pL &= pL << 8;   gR |= pR & (gR >> 8);  pR &= pR >> 8;
-    gL |= pL & (gL << 16); pL &= pL << 16;  gR |= pR & (gR >> 16); pR &= pR >> 16;
-    gL |= pL & (gL << 32);                  gR |= pR & (gR >> 32);
+    RunMasks m;
+    m.l1 = open;                 m.r1 = open;
+    m.l2 = m.l1 & (m.l1 << 1);   m.r2 = m.r1 & (m.r1 >> 1);
+    m.l4 = m.l2 & (m.l2 << 2);   m.r4 = m.r2 & (m.r2 >> 2);
+    m.l8 = m.l4 & (m.l4 << 4);   m.r8 = m.r4 & (m.r4 >> 4);
+    m.l16 = m.l8 & (m.l8 << 8);  m.r16 = m.r8 & (m.r8 >> 8);
+    m.l32 = m.l16 & (m.l16 << 16); m.r32 = m.r16 & (m.r16 >> 16);
+    return m;
+}
+__device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed, const RunMasks &m)
+{
+    unsigned long long gL = seed, gR = seed;
+    gL |= m.l1 & (gL << 1);    gR |= m.r1 & (gR >> 1);
+    gL |= m.l2 & (gL << 2);    gR |= m.r2 & (gR >> 2);
+    gL |= m.l4 & (gL << 4);    gR |= m.r4 & (gR >> 4);
+    gL |= m.l8 & (gL << 8);    gR |= m.r8 & (gR >> 8);
+    gL |= m.l16 & (gL << 16);  gR |= m.r16 & (gR >> 16);
+    gL |= m.l32 & (gL << 32);  gR |= m.r32 & (gR >> 32);
     return gL | gR;
 }
 
-// CHASE (passes >= 1, short work lists): when a tile's border changed, the wave does not queue ALL affected neighbours for the
-// next pass but processes one of them itself straight away (up to kChaseDepth tiles in a row), so a long thin contour advances
-// many tiles per pass instead of one and the number of (launch-latency-bound) passes drops.  Two waves may then work on the same
-// tile at the same time, so CHASE writes words with atomicOr and reads them with agent-scope (cache-bypassing) loads; a missed
-// update is always repaired because whoever changes a border re-queues or re-processes the neighbour behind it (after its own
-// writes have been acknowledged, see the s_waitcnt below).
+// The work queue of the hysteresis (CannyBuffers::hlist as a ring of `ring_mask + 1` slots, a power of two of at least the number of
+// tiles; a slot holds tile + 1, 0 = empty) and its three counters, kept 128 bytes apart in CannyBuffers::pass_count:
+//   tail = tickets handed to producers (entries pushed so far), head = tickets handed to consumers, done = entries completely processed.
+// A tile is in the queue at most once (CannyBuffers::hflags: 1 while queued), so at most `tiles` slots are ever occupied.
+constexpr int kQTail = 32, kQHead = 64, kQDone = 96;
 constexpr int kChaseDepth = 32;
 
-// One pass over the work list of `pass` by the waves [wave, wave + nwaves, ...).  FUSED = several passes run inside one launch
-// (k_hyst_finish): the list written by the previous pass of the same launch is then read with agent-scope loads, because a
-// CU's vector L1 is not refreshed by other waves' stores (between launches the kernel boundary does that).
-template <bool CHASE, bool FUSED>
-__device__ __forceinline__ void hyst_pass_body(const Geom &g, const CannyBuffers &cb, int pass, long long tiles_per_img, long long total_tiles,
-                                               long long wave, long long nwaves, long long n)
+// (wave-uniform address: the first lane's value, so that what depends on it is scalar control flow)
+__device__ __forceinline__ int ld_agent(const int *p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ int ld_agent_lane(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Queue tile nT unless it is queued already.  Called by single lanes; the caller has drained the stores / atomics that made the tile dirty.
+__device__ __forceinline__ void hyst_push(const CannyBuffers &cb, long long nT, int ring_mask)
 {
-    const int lane = threadIdx.x & 63;
-    int *flags_cur = cb.hflags + (long long)(pass & 1) * total_tiles;
-    int *flags_nxt = cb.hflags + (long long)((pass + 1) & 1) * total_tiles;
-    const int *list_cur = cb.hlist + (long long)(pass & 1) * total_tiles;
-    int *list_nxt = cb.hlist + (long long)((pass + 1) & 1) * total_tiles;
+    if (atomicExch(&cb.hflags[nT], 1) != 0) return;
+    const int t = atomicAdd(&cb.pass_count[kQTail], 1);
+    int *slot = &cb.hlist[t & ring_mask];
+    // (the slot of ticket t - ring size was handed out at most `tiles` queue entries ago: its consumer has long emptied it; wait if not)
+    while (ld_agent_lane(slot) != 0) __builtin_amdgcn_s_sleep(2);
+    __hip_atomic_store(slot, (int)nT + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One 64 x 64 tile to its fix-point for the halo it sees now.  ATOMIC: other waves may work on neighbouring tiles -- or on this one --
+// at the same time (queue phase): strong words are read with agent-scope loads and written with atomicOr, and the writes are drained
+// before the function returns, so that whoever is told about them afterwards sees them.  Strong bits only ever get set, so the
+// fix-point does not depend on the interleaving.  Returns the set of in-bounds neighbours that now see a new pixel next to them
+// (bit order: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1)), 0 when nothing changed or T is not a tile.
+struct HystTile { int b, tx, ty, ntx, tbase; };
+template <bool ATOMIC>
+__device__ __forceinline__ unsigned hyst_tile(const Geom &g, const CannyBuffers &cb, long long T, long long tiles_per_img, int lane, HystTile &ht)
+{
     auto ldw = [](const unsigned long long *p) -> unsigned long long {
-        if constexpr (CHASE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (ATOMIC) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else return *p;
     };
+    const int b = (int)(T / tiles_per_img);
+    int l, tx, ty, ntx, nty, tbase;
+    if (!locate_tile(g, kHystTile, kHystTile, (int)(T - (long long)b * tiles_per_img), l, tx, ty, ntx, nty, tbase)) return 0;
+    ht.b = b; ht.tx = tx; ht.ty = ty; ht.ntx = ntx; ht.tbase = tbase;
+    const int h = g.h[l], wpr = g.wpr[l];
+    unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
+    const unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
+    const int y = ty * 64 + lane;
+    const bool valid = y < h;
+    // tile-major layout: this tile's 64 row-words are contiguous; the left / right tiles are +-64 words away.
+    // All ten loads are unconditional (addresses clamped into the plane, results masked afterwards) so that they are in
+    // flight together: a wave pays one memory latency per tile instead of one per halo piece.
+    const int yc = valid ? y : h - 1;
+    const int xl = tx > 0 ? tx - 1 : 0, xr = tx + 1 < wpr ? tx + 1 : wpr - 1;
+    const int yt = ty > 0 ? ty * 64 - 1 : 0, yb = ty * 64 + 64 < h ? ty * 64 + 64 : h - 1;
+    const long long o = bp_index(ty * 64, tx, wpr) + lane;
+    unsigned long long S = ldw(&sg[bp_index(yc, tx, wpr)]), W = wk[bp_index(yc, tx, wpr)];
+    unsigned long long SLw = ldw(&sg[bp_index(yc, xl, wpr)]), SRw = ldw(&sg[bp_index(yc, xr, wpr)]);
+    unsigned long long Tm = ldw(&sg[bp_index(yt, tx, wpr)]), Tlw = ldw(&sg[bp_index(yt, xl, wpr)]), Trw = ldw(&sg[bp_index(yt, xr, wpr)]);
+    unsigned long long Bm = ldw(&sg[bp_index(yb, tx, wpr)]), Blw = ldw(&sg[bp_index(yb, xl, wpr)]), Brw = ldw(&sg[bp_index(yb, xr, wpr)]);
+    if (!valid) { S = 0; W = 0; SLw = 0; SRw = 0; }
+    const bool hasL = tx > 0, hasR = tx + 1 < wpr, hasT = ty > 0, hasB = ty * 64 + 64 < h;
+    unsigned long long SL = hasL ? SLw >> 63 : 0ull, SR = hasR ? SRw & 1ull : 0ull;
+    unsigned long long Tl = (hasT && hasL) ? Tlw >> 63 : 0ull, Tr = (hasT && hasR) ? Trw & 1ull : 0ull;
+    unsigned long long Bl = (hasB && hasL) ? Blw >> 63 : 0ull, Br = (hasB && hasR) ? Brw & 1ull : 0ull;
+    if (!hasT) Tm = 0;
+    if (!hasB) Bm = 0;
+    W &= ~S;                             // candidates still to be decided
+    if (!__any(W != 0ull)) return 0;     // no undecided candidate pixel in the tile: nothing can change here
+    const unsigned long long S0 = S;
+    // the rows above / below come from the neighbouring lanes by DPP whole-wave shifts (one vector instruction per 32 bits; lane 0 /
+    // 63 keep the `old` operand = the halo row) instead of `__shfl` (ds_bpermute: an LDS round trip in the loop's dependence chain);
+    // the left / right halo columns do not change inside the loop, so their part of the mask is formed once
+    auto row_above = [&](unsigned long long v, unsigned long long halo) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)halo, (int)(unsigned)v, 0x138, 0xf, 0xf, false);          // wave_shr:1
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(halo >> 32), (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto row_below = [&](unsigned long long v, unsigned long long halo) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)halo, (int)(unsigned)v, 0x130, 0xf, 0xf, false);          // wave_shl:1
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(halo >> 32), (int)(unsigned)(v >> 32), 0x130, 0xf, 0xf, false);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    const unsigned long long edge = (SL | row_above(SL, Tl) | row_below(SL, Bl)) | ((SR | row_above(SR, Tr) | row_below(SR, Br)) << 63);
+    // W keeps every candidate (decided ones included: a run may be entered through them), S grows
+    const unsigned long long Wall = W | S;
+    const RunMasks rm = run_masks(Wall);
+    for (;;) {
+        // one sweep: the 8-neighbourhood of everything strong seeds the rows' runs ...
+        unsigned long long m = S | row_above(S, Tm) | row_below(S, Bm);
+        unsigned long long nS = S | fill_runs(Wall & (m | (m << 1) | (m >> 1) | edge), rm);
+        // ... and two cheap vertical steps follow (a new pixel promotes the three candidates below / above it: 4 DPP moves + 10 logic
+        // operations against the ~90 of a sweep), so that contours that run down the rows advance three rows per sweep instead of one
+        unsigned long long u = row_above(nS, Tm), d = row_below(nS, Bm);
+        nS |= Wall & (u | (u << 1) | (u >> 1) | d | (d << 1) | (d >> 1));
+        u = row_above(nS, Tm); d = row_below(nS, Bm);
+        nS |= Wall & (u | (u << 1) | (u >> 1) | d | (d << 1) | (d >> 1));
+        const bool ch = nS != S;
+        S = nS;
+        if (!__any(ch)) break;
+    }
+    const unsigned long long diff = S ^ S0;
+    if (diff && valid) {
+        if constexpr (ATOMIC) atomicOr(&sg[o], S);
+        else sg[o] = S;
+    }
+    // ATOMIC: the caller may now process a neighbour itself and read, as that tile's halo, the very words just OR-ed, or tell another
+    // wave about them through the queue.  Drain the atomics first (they execute at the L2 / memory side, which also serves the
+    // agent-scope loads), so that neither can overtake them.
+    if constexpr (ATOMIC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // which of the 8 neighbours see a changed pixel next to them: new bits in the first / last valid row (and their end
+    // columns for the diagonal neighbours), in the first / last column
+    const int last_row = min(63, h - 1 - ty * 64);
+    const unsigned long long dtop = __shfl(diff, 0), dbot = __shfl(diff, last_row);
+    const bool dl = __any((diff & 1ull) != 0), dr = __any((diff >> 63) != 0);
+    unsigned dirs = 0;
+    if (dtop) dirs |= 2u | ((dtop & 1ull) ? 1u : 0u) | ((dtop >> 63) ? 4u : 0u);
+    if (dbot) dirs |= 64u | ((dbot & 1ull) ? 32u : 0u) | ((dbot >> 63) ? 128u : 0u);
+    if (dl) dirs |= 8u;
+    if (dr) dirs |= 16u;
+    unsigned inb = 0;
+    if (ty > 0) inb |= 2u | (tx > 0 ? 1u : 0u) | (tx + 1 < ntx ? 4u : 0u);
+    if (ty + 1 < nty) inb |= 64u | (tx > 0 ? 32u : 0u) | (tx + 1 < ntx ? 128u : 0u);
+    if (tx > 0) inb |= 8u;
+    if (tx + 1 < ntx) inb |= 16u;
+    return dirs & inb;
+}
 
-    for (long long item = wave; item < n; item += nwaves) {
-        long long T = pass == 0 ? item : (long long)(FUSED ? __hip_atomic_load(&list_cur[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list_cur[item]);
-        if (lane == 0) flags_cur[T] = 0;
-        for (int depth = 0;; depth++) {
-            const int b = (int)(T / tiles_per_img);
-            int l, tx, ty, ntx, nty, tbase;
-            if (!locate_tile(g, kHystTile, kHystTile, (int)(T - (long long)b * tiles_per_img), l, tx, ty, ntx, nty, tbase)) break;
-            const int h = g.h[l], wpr = g.wpr[l];
-            unsigned long long *sg = cb.strong + (long long)b * g.bpstride + g.bpoff[l];
-            const unsigned long long *wk = cb.weak + (long long)b * g.bpstride + g.bpoff[l];
-            const int y = ty * 64 + lane;
-            const bool valid = y < h;
-            // tile-major layout: this tile's 64 row-words are contiguous; the left / right tiles are +-64 words away.
-            // All ten loads are unconditional (addresses clamped into the plane, results masked afterwards) so that they are in
-            // flight together: a wave pays one memory latency per tile instead of one per halo piece.
-            const int yc = valid ? y : h - 1;
-            const int xl = tx > 0 ? tx - 1 : 0, xr = tx + 1 < wpr ? tx + 1 : wpr - 1;
-            const int yt = ty > 0 ? ty * 64 - 1 : 0, yb = ty * 64 + 64 < h ? ty * 64 + 64 : h - 1;
-            const long long o = bp_index(ty * 64, tx, wpr) + lane;
-            unsigned long long S = ldw(&sg[bp_index(yc, tx, wpr)]), W = wk[bp_index(yc, tx, wpr)];
-            unsigned long long SLw = ldw(&sg[bp_index(yc, xl, wpr)]), SRw = ldw(&sg[bp_index(yc, xr, wpr)]);
-            unsigned long long Tm = ldw(&sg[bp_index(yt, tx, wpr)]), Tlw = ldw(&sg[bp_index(yt, xl, wpr)]), Trw = ldw(&sg[bp_index(yt, xr, wpr)]);
-            unsigned long long Bm = ldw(&sg[bp_index(yb, tx, wpr)]), Blw = ldw(&sg[bp_index(yb, xl, wpr)]), Brw = ldw(&sg[bp_index(yb, xr, wpr)]);
-            if (!valid) { S = 0; W = 0; SLw = 0; SRw = 0; }
-            const bool hasL = tx > 0, hasR = tx + 1 < wpr, hasT = ty > 0, hasB = ty * 64 + 64 < h;
-            unsigned long long SL = hasL ? SLw >> 63 : 0ull, SR = hasR ? SRw & 1ull : 0ull;
-            unsigned long long Tl = (hasT && hasL) ? Tlw >> 63 : 0ull, Tr = (hasT && hasR) ? Trw & 1ull : 0ull;
-            unsigned long long Bl = (hasB && hasL) ? Blw >> 63 : 0ull, Br = (hasB && hasR) ? Brw & 1ull : 0ull;
-            if (!hasT) Tm = 0;
-            if (!hasB) Bm = 0;
-            if (!__any(W != 0ull)) break;        // no candidate pixel in the tile: nothing can change here
-            const unsigned long long S0 = S;
-            // the rows above / below come from the neighbouring lanes by DPP whole-wave shifts (one vector instruction per 32 bits; lane 0 /
-            // 63 keep the `old` operand = the halo row) instead of `__shfl` (ds_bpermute: an LDS round trip in the loop's dependence chain);
-            // the left / right halo columns do not change inside the loop, so their part of the mask is formed once
-            auto row_above = [&](unsigned long long v, unsigned long long halo) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)halo, (int)(unsigned)v, 0x138, 0xf, 0xf, false);          // wave_shr:1
-                const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(halo >> 32), (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
-                return ((unsigned long long)hi << 32) | lo;
-            };
-            auto row_below = [&](unsigned long long v, unsigned long long halo) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)halo, (int)(unsigned)v, 0x130, 0xf, 0xf, false);          // wave_shl:1
-                const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(halo >> 32), (int)(unsigned)(v >> 32), 0x130, 0xf, 0xf, false);
-                return ((unsigned long long)hi << 32) | lo;
-            };
-            const unsigned long long edge = (SL | row_above(SL, Tl) | row_below(SL, Bl)) | ((SR | row_above(SR, Tr) | row_below(SR, Br)) << 63);
-            for (;;) {
-                const unsigned long long up = row_above(S, Tm), dn = row_below(S, Bm);
-                unsigned long long m = S | up | dn;
-                unsigned long long mm = m | (m << 1) | (m >> 1) | edge;
-                unsigned long long seed = W & mm & ~S;
-                unsigned long long f = fill_runs(seed, W);
-                unsigned long long nS = S | f;
-                bool ch = nS != S;
-                S = nS;
-                if (!__any(ch)) break;
-            }
-            const unsigned long long diff = S ^ S0;
-            if (diff && valid) {
-                if constexpr (CHASE) atomicOr(&sg[o], S);
-                else sg[o] = S;
-            }
-            // CHASE: this wave may now process a neighbour itself and read, as that tile's halo, the very words it has just
-            // OR-ed -- without queueing the neighbour for anyone else.  Drain the atomics first (they execute at the L2 /
-            // memory side, which also serves the agent-scope loads), so that those loads cannot overtake them.
-            if constexpr (CHASE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // which of the 8 neighbours see a changed pixel next to them: new bits in the first / last valid row (and their end
-            // columns for the diagonal neighbours), in the first / last column
-            const int last_row = min(63, h - 1 - ty * 64);
-            const unsigned long long dtop = __shfl(diff, 0), dbot = __shfl(diff, last_row);
-            const bool dl = __any((diff & 1ull) != 0), dr = __any((diff >> 63) != 0);
-            unsigned dirs = 0;       // bit order: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1)
-            if (dtop) dirs |= 2u | ((dtop & 1ull) ? 1u : 0u) | ((dtop >> 63) ? 4u : 0u);
-            if (dbot) dirs |= 64u | ((dbot & 1ull) ? 32u : 0u) | ((dbot >> 63) ? 128u : 0u);
-            if (dl) dirs |= 8u;
-            if (dr) dirs |= 16u;
-            // keep the in-bounds ones
-            const int ox[8] = { -1, 0, 1, -1, 1, -1, 0, 1 }, oy[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
-            unsigned inb = 0;
-#pragma unroll
-            for (int d = 0; d < 8; d++) {
-                const int nx = tx + ox[d], ny = ty + oy[d];
-                if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty) inb |= 1u << d;
-            }
-            dirs &= inb;
-            if (dirs == 0) break;
-            int chase = -1;
-            if (CHASE && depth < kChaseDepth) {
-                // prefer a side neighbour over a corner: 4 (right), 3 (left), 6 (down), 1 (up), then the corners
-                const unsigned pref = (dirs & 16u) ? 4u : (dirs & 8u) ? 3u : (dirs & 64u) ? 6u : (dirs & 2u) ? 1u : (unsigned)(__ffs((int)dirs) - 1);
-                chase = (int)pref;
-            }
-            if (lane < 8 && ((dirs >> lane) & 1u) && lane != chase) {
-                const int nx = tx + ox[lane], ny = ty + oy[lane];
-                long long nT = (long long)b * tiles_per_img + tbase + (long long)ny * ntx + nx;
-                if (atomicExch(&flags_nxt[nT], 1) == 0) list_nxt[atomicAdd(&cb.pass_count[pass + 1], 1)] = (int)nT;
-            }
-            if (chase < 0) break;
-            T = (long long)b * tiles_per_img + tbase + (long long)(ty + oy[chase]) * ntx + (tx + ox[chase]);
-        }
+__device__ __forceinline__ long long hyst_neighbour(const HystTile &ht, long long tiles_per_img, int d)
+{
+    const int ox = d == 0 || d == 3 || d == 5 ? -1 : (d == 1 || d == 6 ? 0 : 1), oy = d < 3 ? -1 : (d < 5 ? 0 : 1);
+    return (long long)ht.b * tiles_per_img + ht.tbase + (long long)(ht.ty + oy) * ht.ntx + (ht.tx + ox);
+}
+
+// Launch 1 of 2: every tile once, plain loads and stores (a wave sees its neighbours as they were or as they become: whoever changes a
+// border queues the neighbour behind it, so nothing is lost).
+__global__ __launch_bounds__(256) void k_hyst_pass0(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int ring_mask)
+{
+    const int lane = threadIdx.x & 63;
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long T = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); T < total_tiles; T += nwaves) {
+        HystTile ht;
+        const unsigned dirs = hyst_tile<false>(g, cb, T, tiles_per_img, lane, ht);
+        if (dirs == 0) continue;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the tile's stores before the queue entries that announce them
+        if (lane < 8 && ((dirs >> lane) & 1u)) hyst_push(cb, hyst_neighbour(ht, tiles_per_img, lane), ring_mask);
     }
 }
 
-template <bool CHASE>
-__global__ __launch_bounds__(256) void k_hyst_pass(Geom g, CannyBuffers cb, int pass, long long tiles_per_img, long long total_tiles)
+// Launch 2 of 2: the queue is drained to the fix-point by however many waves the launch has -- no pass structure, no barrier, nothing
+// for the host to guess or to read back.  A wave takes a ticket (head), waits for the entry of that ticket, clears the tile's "queued"
+// flag BEFORE it reads the tile (a change that arrives later finds the flag clear and queues the tile again), brings the tile to its
+// fix-point and CHASES the contour: of the neighbours it has dirtied it processes one itself straight away (up to kChaseDepth tiles in
+// a row) and queues the others, so a long thin contour costs a chain of tiles on one wave instead of a queue round trip per tile.
+// Termination: entries are only ever pushed by a wave that is processing an entry, and `done` counts entries whose processing -- pushes
+// included -- is complete; done == tail (done read first) therefore means that nothing is queued, nothing is running and nothing can be
+// pushed any more.  Every wave reaches that state or an entry of its own: a wave never waits for another wave to be scheduled, only for
+// a running one to finish its tile, so the launch needs no co-residency.
+__global__ __launch_bounds__(256) void k_hyst_drain(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int ring_mask)
 {
-    const long long n = pass == 0 ? total_tiles : (long long)cb.pass_count[pass];
-    hyst_pass_body<CHASE, false>(g, cb, pass, tiles_per_img, total_tiles, (long long)blockIdx.x * 4 + (threadIdx.x >> 6), (long long)gridDim.x * 4, n);
-}
-
-// Small problems (a single image, a few images): after pass 0, ONE workgroup of 16 waves runs every further pass to the fix-point
-// inside one launch -- the work lists of passes >= 1 hold tens to hundreds of tiles, so a launch per pass is pure launch latency
-// (8 launches x 10 us for one 1080p image), and because the kernel itself iterates until a pass queues nothing, the caller needs
-// neither a speculative pass count nor a read-back.  Every wave reaches every barrier (the loop bound is wave-uniform).
-constexpr int kFinishThreads = 1024;
-__global__ __launch_bounds__(kFinishThreads) void k_hyst_finish(Geom g, CannyBuffers cb, int first_pass, long long tiles_per_img, long long total_tiles)
-{
-    for (int pass = first_pass; pass < kMaxHystPasses; pass++) {
-        const long long n = (long long)__hip_atomic_load(&cb.pass_count[pass], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n == 0) break;
-        hyst_pass_body<true, true>(g, cb, pass, tiles_per_img, total_tiles, (long long)(threadIdx.x >> 6), kFinishThreads / 64, n);
-        __syncthreads();               // s_waitcnt vmcnt(0) + barrier: this pass's stores and atomics have been performed at the L2
-        // (the pass bound cannot be reached in practice; if it were, the last counter stays non-zero and the host reports it)
+    const int lane = threadIdx.x & 63;
+    int *q = cb.pass_count;
+    for (;;) {
+        int my = 0;
+        if (lane == 0) my = atomicAdd(&q[kQHead], 1);
+        my = __builtin_amdgcn_readfirstlane(my);
+        bool have = false;
+        for (;;) {
+            if (my - ld_agent(&q[kQTail]) < 0) { have = true; break; }
+            const int done = ld_agent(&q[kQDone]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // `done` is read before `tail`
+            const int tail = ld_agent(&q[kQTail]);
+            if (my - tail < 0) { have = true; break; }
+            if (done == tail) break;                                       // quiescent: this ticket will never be served
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (!have) return;
+        int *slot = &cb.hlist[my & ring_mask];
+        int e;
+        while ((e = ld_agent(slot)) == 0) __builtin_amdgcn_s_sleep(2);     // (the producer holds the ticket and is about to write)
+        long long T = e - 1;
+        if (lane == 0) {
+            __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)atomicExch(&cb.hflags[T], 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // flag cleared (performed at the L2) before the tile is read
+        for (int depth = 0;; depth++) {
+            HystTile ht;
+            const unsigned dirs = hyst_tile<true>(g, cb, T, tiles_per_img, lane, ht);
+            if (dirs == 0) break;
+            int chase = -1;
+            // prefer a side neighbour over a corner: 4 (right), 3 (left), 6 (down), 1 (up), then the corners
+            if (depth < kChaseDepth) chase = (dirs & 16u) ? 4 : (dirs & 8u) ? 3 : (dirs & 64u) ? 6 : (dirs & 2u) ? 1 : __ffs((int)dirs) - 1;
+            if (lane < 8 && ((dirs >> lane) & 1u) && lane != chase) hyst_push(cb, hyst_neighbour(ht, tiles_per_img, lane), ring_mask);
+            if (chase < 0) break;
+            T = hyst_neighbour(ht, tiles_per_img, chase);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this entry's pushes (tail tickets, slots) before it counts as done
+        if (lane == 0) atomicAdd(&q[kQDone], 1);
     }
 }
 
@@ -1488,21 +1557,19 @@ void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, con
     else hipLaunchKernelGGL(k_sobel_nms<false>, grid, dim3(256), 0, st, g, cb, strip);
 }
 
-void launch_hyst_finish(hipStream_t st, const Geom &g, const CannyBuffers &cb, int first_pass)
+// the two launches of the hysteresis: every tile once, then the queue of dirtied tiles drained to the fix-point on the device
+void launch_hysteresis(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
-    long long t = hyst_tiles_per_image(g);
-    hipLaunchKernelGGL(k_hyst_finish, dim3(1), dim3(kFinishThreads), 0, st, g, cb, first_pass, t, t * g.B);
-}
-
-void launch_hyst_pass(hipStream_t st, const Geom &g, const CannyBuffers &cb, int pass)
-{
-    long long t = hyst_tiles_per_image(g);
-    long long total = t * g.B;
-    long long blocks = pass == 0 ? (total + 3) / 4 : 512;
+    const long long t = hyst_tiles_per_image(g), total = t * g.B;
+    if (total <= 0) return;
+    const int ring_mask = hyst_ring_slots(g) - 1;
+    long long blocks = (total + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    if (blocks < 1) blocks = 1;
-    if (pass == 0) hipLaunchKernelGGL(k_hyst_pass<false>, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, pass, t, total);
-    else hipLaunchKernelGGL(k_hyst_pass<true>, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, pass, t, total);
+    hipLaunchKernelGGL(k_hyst_pass0, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, t, total, ring_mask);
+    // consumers: a wave per 16 tiles, at most 1024 waves (the queue starts with a few per cent of the tiles and shrinks geometrically)
+    long long drain = (total + 63) / 64;
+    if (drain > 256) drain = 256;
+    hipLaunchKernelGGL(k_hyst_drain, dim3((unsigned)drain), dim3(256), 0, st, g, cb, t, total, ring_mask);
 }
 
 static int expand_blocks(const Geom &g)

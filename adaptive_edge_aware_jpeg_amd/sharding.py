@@ -26,25 +26,25 @@ def aggregate_throughput(dist, pixels_local: int, seconds_local: float, device=N
     return int(round(px.item())), float(sec.item())
 
 
-def gather_rank_report(dist, local_rank: int, ms_per_step: float, misses: int, verified_ok, device=None, require_verified: bool = True) -> dict:
+def gather_rank_report(dist, local_rank: int, ms_per_step: float, images: int, verified_ok, device=None, require_verified: bool = True) -> dict:
     """First-contact evidence for the multi-GPU run (all_gather of four numbers per rank, after the timed region): which local ranks
-    the collective really saw, every rank's own ms per step, its speculation misses inside the timed region and whether its
+    the collective really saw, every rank's own ms per step, how many images it encodes per step (its shard) and whether its
     post-timing check against the CPU oracle passed (None = the rank did not verify).  `all_verified` needs ok == True on EVERY rank
     -- a rank that never reached its check counts as a failure -- unless the run was asked not to verify (`require_verified=False`:
     then only an explicit False fails).  Every rank gets the same dict."""
     ok = -1.0 if verified_ok is None else (1.0 if verified_ok else 0.0)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        rows = [[float(local_rank), float(ms_per_step), float(misses), ok]]
+        rows = [[float(local_rank), float(ms_per_step), float(images), ok]]
         world = 1
     else:
         import torch
         world = dist.get_world_size()
-        mine = torch.tensor([float(local_rank), float(ms_per_step), float(misses), ok], dtype=torch.float64, device=device)
+        mine = torch.tensor([float(local_rank), float(ms_per_step), float(images), ok], dtype=torch.float64, device=device)
         got = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(got, mine)
         rows = [g.cpu().tolist() for g in got]
     return {"world_size": world, "n_ranks_seen": len(rows), "local_ranks_seen": [int(r[0]) for r in rows],
-            "ms_per_step_by_rank": [round(r[1], 3) for r in rows], "speculation_misses_by_rank": [int(r[2]) for r in rows],
+            "ms_per_step_by_rank": [round(r[1], 3) for r in rows], "images_per_step_by_rank": [int(r[2]) for r in rows],
             "verified_ok_by_rank": [None if r[3] < 0 else bool(r[3]) for r in rows],
             "unverified_ranks": [i for i, r in enumerate(rows) if r[3] < 0],
-            "all_verified": all((r[3] == 1.0) if require_verified else (r[3] != 0.0) for r in rows), "any_miss": any(r[2] > 0 for r in rows)}
+            "all_verified": all((r[3] == 1.0) if require_verified else (r[3] != 0.0) for r in rows)}

@@ -14,14 +14,13 @@ What the timed region does and does not contain:
 * the K steps rotate over `--pipeline` (default 3; round 2 used 2 -- with the colour stage off the critical path a third call in flight
   fills what the other two leave idle: 64 x 4K 6.7 -> 6.45 ms, four: 6.85) contexts, each on its own stream with its own output buffers and workspace:
   step i is enqueued with aej_encode_batch_begin on context i % n after the step that used that context before has been ended
-  (aej_encode_batch_end: waited for, device counters checked, a speculation miss repaired).  Two calls in flight let the HBM-bound
+  (aej_encode_batch_end: waited for, device counters checked).  Two calls in flight let the HBM-bound
   stages of one (colour planes, DCT) run beside the issue-bound stages of the other (blur, Sobel / NMS, quadtree); the library
   keeps them one stage apart.  All K steps are complete inside the timed region (sync() ends every call in flight before the
   clock stops).  `pipeline.serial_ms_per_step` is the same K steps as blocking aej_encode_batch calls on one context.
-* TWO different device-resident batches (different seeds) alternate across the steps, so the data-dependent speculation of the
-  hysteresis stage (pass count learnt from the previous call) is exercised on changing inputs; `hysteresis` in the JSON line
-  reports how many timed calls were speculative and how many missed, and `verified_mode_ms_per_step` is the same loop with the
-  speculation switched off (one counter read-back per 8 passes).
+* TWO different device-resident batches (different seeds) alternate across the steps, so nothing data-dependent can be remembered
+  from one call to the next (round 4: nothing is -- the hysteresis completes on the device; `hysteresis` in the JSON line reports
+  how many tiles went through its work queue).
 * no profiling events: stage times come from separate, untimed steps afterwards.
 * after the timed region the outputs of the LAST timed step are compared with the CPU oracle for the first and the last image
   of the batch (`"verified"`), so the number is tied to correct output.
@@ -156,9 +155,6 @@ def parse_args(argv=None):
                          "enqueued with aej_encode_batch_begin on context i %% n after the step that used it before has been ended; 1 = blocking calls")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aej_set_option on every context (include/aej.h has the table), e.g. --option dct64_kernel=1; A / B runs only")
-    ap.add_argument("--strict-speculation", action="store_true",
-                    help="exit non-zero when any rank's hysteresis speculation missed inside the timed region (the miss is repaired and the "
-                         "output correct either way; the line always reports the misses per rank)")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiler runs (tools/profiling/*.sh): only the W warm-up and K timed steps, so every kernel is launched a known "
                          "number of times; prints value / ms_per_step only")
@@ -299,7 +295,7 @@ def rehearse(args):
     verdict = not (fake_bad is not None and int(fake_bad) == rank)
     if os.environ.get("AEJ_REHEARSE_UNVERIFIED_RANK") is not None and int(os.environ["AEJ_REHEARSE_UNVERIFIED_RANK"]) == rank:
         verdict = None                                            # ... or never reach its check
-    ranks = gather_rank_report(dist, local_rank, dt_local / args.steps * 1e3, 0, verdict, None)
+    ranks = gather_rank_report(dist, local_rank, dt_local / args.steps * 1e3, B, verdict, None)
     if rank == 0:
         print(json.dumps({"metric": "REHEARSAL of bench.py's multi-rank control flow (no GPU work, not a measurement)", "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "pixels_total": px,
@@ -411,7 +407,7 @@ def main():
         tot = {}
         for p in pipes:
             for k, v in p.ctx.hysteresis_stats().items():
-                tot[k] = (tot.get(k, 0) + v) if k != "enqueued" else max(tot.get(k, 0), v)
+                tot[k] = (tot.get(k, 0) + v) if k != "queued" else max(tot.get(k, 0), v)
         return tot
 
     # ---- the measurement: W warm-up steps, then exactly K timed steps on alternating inputs, profiling off ----
@@ -432,7 +428,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch", "value": round(value, 1), "unit": "MP/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-                              "encode_calls": args.steps + n_warm, "hysteresis_misses": h1["misses"] - h0["misses"], "timed_only": True}), flush=True)
+                              "encode_calls": args.steps + n_warm, "timed_only": True}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -455,20 +451,14 @@ def main():
         verified = {"ok": bool(ok), "images": picks, "of_batch": "A" if last_batch == 0 else "B",
                     "what": "quadtree states, leaf table and quantised zigzag coefficients of all 3 layers, bit-exact vs the CPU oracle"}
 
-    # ---- first-contact evidence for N > 1: which ranks the collective saw, their own step times, misses and oracle checks ----
-    ranks = gather_rank_report(dist, local_rank, own_ms_per_step, h1["misses"] - h0["misses"], None if verified is None else verified["ok"],
+    # ---- first-contact evidence for N > 1: which ranks the collective saw, their own step times and oracle checks ----
+    ranks = gather_rank_report(dist, local_rank, own_ms_per_step, B, None if verified is None else verified["ok"],
                                dev if backend == "nccl" else None, require_verified=not args.no_verify)
 
-    # ---- the same loop with the speculation off (verified hysteresis loop) ----
     # ---- strictly serial figure: blocking calls on one context, nothing in flight between them ----
     serial_step(0); serial_step(1)
     dt_s = timed_loop(torch, dist, serial_step, args.steps, sync)
     _, dt_s = aggregate_throughput(dist, 0, dt_s, dev if backend == "nccl" else None)
-    ctx.set_speculation(False)
-    serial_step(0); serial_step(1)
-    dt_v = timed_loop(torch, dist, serial_step, args.steps, sync)
-    _, dt_v = aggregate_throughput(dist, 0, dt_v, dev if backend == "nccl" else None)
-    ctx.set_speculation(True)
 
     # ---- per-stage times: separate, untimed, profiled steps (HIP events on the launch stream inside the library) ----
     ctx.set_profiling(True)
@@ -604,15 +594,15 @@ def main():
         "verified": verified,
         "profile_gaps": profile_gaps or None,
         "ranks": ranks,
-        "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "speculative_calls": h1["speculative"] - h0["speculative"],
-                       "misses": h1["misses"] - h0["misses"], "passes_enqueued_last_call": h1["enqueued"],
-                       "passes_needed_last_call": int(ctx.lib.aej_last_hysteresis_passes(ctx.handle))},
+        "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "launches_per_part": 2,
+                       "tiles_through_the_work_queue_last_call": h1["queued"], "tiles": int(B * sum(-(-plan.layer_h[l] // 64) * -(-plan.layer_w[l] // 64) for l in range(3))),
+                       "what": "a pass over every 64 x 64 tile, then a device-side work queue of dirtied tiles drained to the fix-point by one persistent "
+                               "launch: no pass count guessed by the host, nothing read back, nothing to repair"},
         "pipeline": {"contexts": n_pipe, "what": "timed step i is enqueued (aej_encode_batch_begin) on context i % n, each context on its own stream with its own "
                                                   "output buffers and workspace, after the step that used that context before has been ended (aej_encode_batch_end: "
                                                   "waited for and verified); all K steps are complete inside the timed region",
                      "serial_ms_per_step": round(dt_s / args.steps * 1e3, 3),
                      "serial_note": "the same K steps as blocking aej_encode_batch calls on one context (nothing in flight between calls)"},
-        "verified_mode_ms_per_step": round(dt_v / args.steps * 1e3, 3),
         "graph": dict(ctx.graph_stats(), mode=args.graph),
         "sub_batches": {"mode": args.sub_batches, "split_calls": sum(p.ctx.split_calls() for p in pipes),
                         "note": "timed steps run as sub-batches on private streams when split_calls > 0; the per-stage times below come from separate, "
@@ -697,15 +687,10 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    # a rank whose outputs differ from the oracle's makes the whole run fail (every rank has the same `ranks` dict); a speculation
-    # miss inside the timed region is correct output at a slower step -- it is reported per rank (`speculation_misses_by_rank`) and
-    # fails the run only under --strict-speculation
+    # a rank whose outputs differ from the oracle's makes the whole run fail (every rank has the same `ranks` dict)
     if not ranks["all_verified"]:
         sys.stderr.write(f"bench.py: oracle check failed on rank(s) {[i for i, v in enumerate(ranks['verified_ok_by_rank']) if v is False]}\n")
         raise SystemExit(3)
-    if args.strict_speculation and ranks["any_miss"]:
-        sys.stderr.write(f"bench.py: speculation misses in the timed region: {ranks['speculation_misses_by_rank']}\n")
-        raise SystemExit(4)
 
 
 if __name__ == "__main__":

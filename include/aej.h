@@ -15,8 +15,8 @@
  *     except aej_set_settings() (tables) -- the caller owns inputs, outputs and the workspace;
  *   - a context is bound to one HIP device and one stream and is NOT thread-safe (like the
  *     reference's stateful Jpeg object, jpeg.py:256-259); distinct contexts are independent;
- *   - work is enqueued on the context's stream; calls that must read a device counter
- *     (aej_canny / aej_encode_batch: hysteresis convergence) synchronise that stream internally.
+ *   - work is enqueued on the context's stream; the blocking calls synchronise it once, at their end (aej_encode_batch_begin
+ *     returns without waiting); nothing inside a call depends on a value read back from the device.
  */
 #ifndef AEJ_H
 #define AEJ_H
@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AEJ_ABI_VERSION 1
+#define AEJ_ABI_VERSION 2   /* 2: the hysteresis completes on the device -- the speculation entry points of version 1 are gone; aej_set_option */
 
 #if defined(__GNUC__)
 #define AEJ_API __attribute__((visibility("default")))
@@ -77,7 +77,6 @@ AEJ_API int aej_synchronize(aej_ctx *ctx);
 /* Re-binds the context to another stream of its device (the Python host follows torch's current stream with it, so
  * that the library's kernels are ordered behind whatever produced the caller's tensors); drains the stream it leaves. */
 AEJ_API int aej_set_stream(aej_ctx *ctx, void *hip_stream);
-AEJ_API int aej_last_hysteresis_passes(aej_ctx *ctx); /* diagnostic: passes enqueued by the last Canny run */
 
 /* Stage timing of aej_encode_batch: HIP events recorded on the context's stream around every stage of the
  * last call (measurement only; used by bench.py for the roofline figures). */
@@ -87,18 +86,13 @@ enum {
     AEJ_STAGE_DCT_16, AEJ_STAGE_DCT_32, AEJ_STAGE_DCT_64, AEJ_STAGE_DCT_128, AEJ_STAGE_DCT_256, AEJ_STAGE_DCT_512, AEJ_STAGE_DCT_1024,
     AEJ_N_STAGES
 };
-/* Diagnostic: aej_encode_batch enqueues (passes + margin) hysteresis passes without reading back and verifies convergence
- * with its final synchronisation (falling back to the verified loop and redoing quadtree + DCT when they were too few).
- * `passes` is normally learnt from the previous call; 0 forces the verified mode for the next call. */
-AEJ_API int aej_set_hysteresis_hint(aej_ctx *ctx, int passes, int margin);
-/* enable = 0: every aej_encode_batch runs the verified loop (one counter read-back per 8 passes, nothing speculative). */
-AEJ_API int aej_set_hysteresis_speculation(aej_ctx *ctx, int enable);
-/* out_host[4] = { aej_encode_batch calls, calls that enqueued their passes speculatively, speculative calls whose pass
- * count turned out too small (hysteresis finished in the verified loop, quadtree + DCT redone), passes enqueued
- * speculatively by the last call } since aej_create. */
+/* Diagnostic.  The hysteresis of cv.Canny (edge_detection.py:85) is two launches whatever the image holds: a pass over every 64 x 64 tile,
+ * then a device-side work queue of the tiles whose neighbourhood changed, drained to the fix-point by one persistent launch -- the host
+ * guesses no pass count and reads nothing back.  out_host[2] = { whole-path calls since aej_create, tiles that went through that queue
+ * in the last completed call }. */
 AEJ_API int aej_get_hysteresis_stats(aej_ctx *ctx, int64_t *out_host);
-/* Launch-latency path: aej_encode_batch can replay its whole speculative launch sequence (about 25 kernel launches) as one
- * captured hipGraph, cached per (buffers, shape, pass count).  mode 0 = never (the default: on MI355X / ROCm 7.2 the replay of one 1080p encode measured 0.287 ms against 0.274 ms for
+/* Launch-latency path: aej_encode_batch can replay its whole launch sequence (about 20 kernel launches) as one
+ * captured hipGraph, cached per (buffers, shape).  mode 0 = never (the default: on MI355X / ROCm 7.2 the replay of one 1080p encode measured 0.287 ms against 0.274 ms for
  * the eager launches), 1 = automatic (calls of at most 8 Mpx), 2 = whenever possible.  The graph runs on a private stream ordered behind the context's
  * stream; results are identical.  out_host[3] = { graph launches, graph captures, graphs cached }. */
 AEJ_API int aej_set_graph_mode(aej_ctx *ctx, int mode);
@@ -134,7 +128,7 @@ AEJ_API int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int32_t
 AEJ_API int aej_set_option(aej_ctx *ctx, const char *name, int64_t value);
 AEJ_API int aej_get_option(aej_ctx *ctx, const char *name, int64_t *value_host);
 /* The two halves of aej_encode_batch / aej_encode_batch_u8 (same arguments; rgb_is_u8 selects the ingest): _begin enqueues the whole
- * call and returns without waiting, _end waits for it, checks the device-side counters and repairs a speculation miss.  One call may
+ * call and returns without waiting, _end waits for it and checks the device-side counters.  One call may
  * be in flight per context; until _end returns, the context's other entry points, the workspace and the output buffers must not be
  * used.  Two contexts on two streams, each with its own buffers, keep the GPU busy across calls: while one call drains (hysteresis
  * tail, DCT) the other's colour stage runs (bench.py times this pipeline; the strictly serial figure is reported beside it). */

@@ -86,8 +86,8 @@ def digest(enc, B):
 
 
 def test_encode_is_deterministic_in_process(env):
-    """the chase passes of the hysteresis write with atomics while other waves read; the result must not depend on
-    the interleaving.  Same device-resident batch, three encodes (first verified, then speculative), identical digests."""
+    """the waves that drain the hysteresis work queue write with atomics while other waves read; the result must not depend
+    on the interleaving.  Same device-resident batch, three encodes, identical digests."""
     torch, A, bench = env
     B, H, W = 8, 2160, 3840
     x = bench.synth_batch(torch, B, H, W, 4242, torch.device("cuda", 0))
@@ -96,31 +96,24 @@ def test_encode_is_deterministic_in_process(env):
     assert d[0] == d[1] == d[2]
 
 
-def test_speculation_on_off_and_stats(env, oracle):
-    """The speculative hysteresis enqueue and the verified loop give the same bytes; the miss counter counts."""
+def test_hysteresis_queue_statistics(env, oracle):
+    """The hysteresis completes on the device (a pass over every tile, then the work queue drained by one persistent launch): repeated
+    calls give the same bytes, and the context reports how many tiles went through the queue -- some, but a small fraction."""
     torch, A, bench = env
     from adaptive_edge_aware_jpeg_amd._lib import get_context
-    B, H, W = 6, 1080, 1920                              # > kHystFinishTiles 64x64 tiles: the per-pass (speculative) hysteresis, not the one-launch finish
+    B, H, W = 6, 1080, 1920
     dev = torch.device("cuda", 0)
     x1 = bench.synth_batch(torch, B, H, W, 1, dev)
     codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
     ctx = get_context()
     s0 = ctx.hysteresis_stats()
-    a = digest(codec.compress_batch(x1), B)             # may be verified (first call) or speculative
-    b = digest(codec.compress_batch(x1), B)             # speculative: hint learnt
-    ctx.set_speculation(False)
-    try:
-        c = digest(codec.compress_batch(x1), B)
-        s1 = ctx.hysteresis_stats()
-    finally:
-        ctx.set_speculation(True)
-    assert a == b == c
-    assert s1["calls"] - s0["calls"] == 3 and s1["speculative"] - s0["speculative"] >= 1
-    # force a miss: a 1-pass hint with no margin on an image whose contours cross many tiles
-    ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
-    d = digest(codec.compress_batch(x1), B)
-    s2 = ctx.hysteresis_stats()
-    assert d == a and s2["misses"] - s1["misses"] == 1
+    a = digest(codec.compress_batch(x1), B)
+    b = digest(codec.compress_batch(x1), B)
+    s1 = ctx.hysteresis_stats()
+    assert a == b and s1["calls"] - s0["calls"] == 2
+    tiles = B * (17 * 30 + 2 * 9 * 15)
+    assert 0 < s1["queued"] < tiles, (s1, tiles)
+    check_image(codec.compress_batch(x1), B - 1, oracle.encode_image(x1[B - 1].cpu().numpy(), "YCbCr", (40, 80), (4, 64)), "last image")
 
 
 def test_contexts_follow_the_current_stream(env, oracle):
@@ -171,8 +164,8 @@ def test_xyz_helper_space_and_float64_input(env, oracle):
 
 def test_graph_replay_path_matches_oracle(env, oracle):
     """Launch-latency path (BASELINE config 2, one 1920x1080 image): from the third call with the same buffers on, the whole launch
-    sequence is one captured hipGraph; its outputs are the oracle's, also when the input changes between replays and when the
-    speculative pass count is too small (miss -> eager completion)."""
+    sequence is one captured hipGraph; its outputs are the oracle's, also when the input changes between replays, for batches and for
+    shapes whose workspace planes are tiled."""
     torch, A, bench = env
     from adaptive_edge_aware_jpeg_amd._lib import get_context
     dev = torch.device("cuda", 0)
@@ -197,47 +190,39 @@ def test_graph_replay_path_matches_oracle(env, oracle):
             check_image(EncodedBatch(plan, *out), 0, refs[which], f"graph call {it}")
         g1 = ctx.graph_stats()
         assert g1["captures"] - g0["captures"] == 1 and g1["launches"] - g0["launches"] >= 3, (g0, g1)
-        _graph_miss_is_repaired(torch, bench, oracle, codec, ctx, dev, 6, H, W, space, qr, br)
-        # a shape whose workspace planes are kept in 4 x 4 blocks (3 x 4K float32 YCbCr: strips of 32 rows) -- capture,
-        # replay and the miss repair must agree on the layout
-        _graph_miss_is_repaired(torch, bench, oracle, codec, ctx, dev, 3, 2160, 3840, space, qr, br)
+        _graph_replay_equals_eager(torch, bench, oracle, codec, ctx, dev, 6, H, W, space, qr, br)
+        # a shape whose workspace planes are kept in 4 x 4 blocks (3 x 4K float32 YCbCr: strips of 32 rows) -- capture
+        # and replay must agree on the layout (the speculation-miss repair that could disagree with them no longer exists: the
+        # hysteresis completes on the device)
+        _graph_replay_equals_eager(torch, bench, oracle, codec, ctx, dev, 3, 2160, 3840, space, qr, br)
     finally:
         ctx.set_graph_mode(0)
 
 
-def _graph_miss_is_repaired(torch, bench, oracle, codec, ctx, dev, B, H, W, space, qr, br):
-    """a replay whose pass count is too small (needs the per-pass hysteresis, i.e. more than kHystFinishTiles tiles): the miss is
-    detected after the replay and repaired eagerly; outputs equal the eager path's, and image 0 the oracle's"""
-    if True:
-        xb = bench.synth_batch(torch, B, H, W, 5, dev)
-        planb = ctx.plan(B, H, W)
-        def outs():
-            return (ctx.empty((B * planb.coeff_stride,), torch.int32), ctx.empty((B * planb.leaf_stride, 4), torch.int32),
-                    ctx.empty((B * planb.state_stride,), torch.uint8), ctx.empty((B, 3, 4), torch.int64))
-        ctx.set_graph_mode(0)
-        want = outs()
-        codec.encode_into(ctx, xb, planb, *want)
+def _graph_replay_equals_eager(torch, bench, oracle, codec, ctx, dev, B, H, W, space, qr, br):
+    """a batch replayed through the graph gives the eager path's outputs, and image 0 the oracle's"""
+    xb = bench.synth_batch(torch, B, H, W, 5, dev)
+    planb = ctx.plan(B, H, W)
+
+    def outs():
+        return (ctx.empty((B * planb.coeff_stride,), torch.int32), ctx.empty((B * planb.leaf_stride, 4), torch.int32),
+                ctx.empty((B * planb.state_stride,), torch.uint8), ctx.empty((B, 3, 4), torch.int64))
+    ctx.set_graph_mode(0)
+    want = outs()
+    codec.encode_into(ctx, xb, planb, *want)
+    torch.cuda.synchronize()
+    ctx.set_graph_mode(2)
+    got = outs()
+    g2 = ctx.graph_stats()
+    for it in range(3):                              # 1st: remembered, 2nd: captured + replayed, 3rd: replayed
+        for t in got:
+            t.zero_()
+        codec.encode_into(ctx, xb, planb, *got)
         torch.cuda.synchronize()
-        ctx.set_graph_mode(2)
-        got = outs()
-        s0, g2 = ctx.hysteresis_stats(), ctx.graph_stats()
-        for it in range(3):                              # 1st: remembered, 2nd: captured + replayed, 3rd: replayed
-            ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
-            for t in got:
-                t.zero_()
-            codec.encode_into(ctx, xb, planb, *got)
-            torch.cuda.synchronize()
-            assert torch.equal(got[3], want[3]), f"graph miss call {it}: counts"
-            for im in range(B):
-                for l in range(3):
-                    nc, nl, ns, _ = (int(v) for v in want[3][im, l])
-                    c0, l0, s0_ = im * planb.coeff_stride + planb.coeff_off[l], im * planb.leaf_stride + planb.leaf_off[l], im * planb.state_stride + planb.state_off[l]
-                    assert torch.equal(got[0][c0:c0 + nc], want[0][c0:c0 + nc]) and torch.equal(got[1][l0:l0 + nl], want[1][l0:l0 + nl]) \
-                        and torch.equal(got[2][s0_:s0_ + ns], want[2][s0_:s0_ + ns]), f"graph miss call {it}: image {im} layer {l}"
-        assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 3
-        assert ctx.graph_stats()["launches"] - g2["launches"] >= 2
-        from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
-        check_image(EncodedBatch(planb, *got), 0, oracle.encode_image(xb[0].cpu().numpy(), space, qr, br), f"graph miss {B} x {W}x{H}: image 0")
+        _assert_same_encoding(torch, planb, got, want, B, f"graph call {it}, {B} x {W}x{H}")
+    assert ctx.graph_stats()["launches"] - g2["launches"] >= 2
+    from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
+    check_image(EncodedBatch(planb, *got), 0, oracle.encode_image(xb[0].cpu().numpy(), space, qr, br), f"graph replay {B} x {W}x{H}: image 0")
 
 
 def _encode_raw(torch, ctx, codec, x, plan):
@@ -263,12 +248,11 @@ def _assert_same_encoding(torch, plan, got, want, B, what):
 
 def test_sub_batch_pipelining_is_invisible(env, oracle):
     """aej_set_sub_batches: a call cut into sub-batches on private streams (the throughput path of the 64 x 4K bench) returns what the
-    unsplit call returns -- even and uneven splits, float and 8-bit ingest, speculative hysteresis hit and miss inside sub-batches --
-    and image 0 / the last image equal the oracle."""
+    unsplit call returns -- even and uneven splits, float and 8-bit ingest -- and image 0 / the last image equal the oracle."""
     torch, A, bench = env
     dev = torch.device("cuda", 0)
     space, qr, br = "YCbCr", (40, 80), (4, 64)
-    B, H, W = 14, 1080, 1920                               # 2 sub-batches of 7 images = 5460 hysteresis tiles each: the per-pass (speculative) scheme
+    B, H, W = 14, 1080, 1920
     x = bench.synth_batch(torch, B, H, W, 31, dev)
     codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
     ctx = codec._bind()
@@ -276,8 +260,8 @@ def test_sub_batch_pipelining_is_invisible(env, oracle):
     try:
         ctx.set_sub_batches(1)
         want = _encode_raw(torch, ctx, codec, x, plan)
-        want2 = _encode_raw(torch, ctx, codec, x, plan)     # second call: speculative
-        _assert_same_encoding(torch, plan, want2, want, B, "unsplit, speculative")
+        want2 = _encode_raw(torch, ctx, codec, x, plan)
+        _assert_same_encoding(torch, plan, want2, want, B, "unsplit, second call")
         from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
         for im in (0, B - 1):
             check_image(EncodedBatch(plan, *want), im, oracle.encode_image(x[im].cpu().numpy(), space, qr, br), f"unsplit image {im}")
@@ -292,16 +276,6 @@ def test_sub_batch_pipelining_is_invisible(env, oracle):
         x8 = (x * 255.0).round().to(torch.uint8)
         got = _encode_raw(torch, ctx, codec, x8, plan)
         _assert_same_encoding(torch, plan, got, want, B, "3 sub-batches, uint8 ingest")
-        # a speculative pass count that is too small inside the sub-batches: detected per sub-batch and repaired
-        ctx.set_sub_batches(2)
-        s0 = ctx.hysteresis_stats()
-        ctx.check(ctx.lib.aej_set_hysteresis_hint(ctx.handle, 1, 0))
-        got = _encode_raw(torch, ctx, codec, x, plan)
-        _assert_same_encoding(torch, plan, got, want, B, "2 sub-batches, forced miss")
-        assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 1
-        got = _encode_raw(torch, ctx, codec, x, plan)       # the hint has recovered
-        _assert_same_encoding(torch, plan, got, want, B, "2 sub-batches after the miss")
-        assert ctx.hysteresis_stats()["misses"] - s0["misses"] == 1
     finally:
         ctx.set_sub_batches(0)
 
@@ -460,7 +434,6 @@ def test_failed_begin_drains_what_it_enqueued(env, oracle):
         try:
             ctx.set_sub_batches(1)
             want = _encode_raw(torch, ctx, codec, x, plan)
-            want = _encode_raw(torch, ctx, codec, x, plan)          # (speculative from here on)
             stages = {"color_planes": 1, "hysteresis": 6, "dct64": 13}
             for nsub in (1, 2):
                 ctx.set_sub_batches(nsub)

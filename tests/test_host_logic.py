@@ -123,7 +123,7 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.aej_abi_version() == 1
+    assert lib.aej_abi_version() == 2
     # host-only geometry helpers (no device needed)
     lc, sc, cc = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     assert lib.aej_quadtree_capacity(2160, 3840, 4, 64, ctypes.byref(lc), ctypes.byref(sc), ctypes.byref(cc)) == 0
