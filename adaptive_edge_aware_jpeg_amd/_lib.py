@@ -246,7 +246,7 @@ class Context:
     def hysteresis_stats(self):
         """-> dict(calls, queued): whole-path calls on this context, tiles that went through the device-side hysteresis work queue
         in the last completed call (include/aej.h)."""
-        buf = (ctypes.c_int64 * 2)()
+        buf = (ctypes.c_int64 * 4)()      # (4: round 3 libraries, loaded through AEJ_LIBRARY for A / B runs, wrote four)
         self.check(self.lib.aej_get_hysteresis_stats(self.handle, ctypes.cast(buf, ctypes.c_void_p)))
         return {"calls": int(buf[0]), "queued": int(buf[1])}
 

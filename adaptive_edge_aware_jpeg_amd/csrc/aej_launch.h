@@ -31,9 +31,9 @@ struct CannyBuffers {
     int *thr;               // [B][3][2]
     unsigned long long *weak;    // [B][bpstride] NMS candidates (bit-plane)
     unsigned long long *strong;  // [B][bpstride] strong edges, grown by the hysteresis passes -> final edge map
-    int *hflags;            // [B * tiles] 1 while the tile is in the hysteresis work queue
-    int *hlist;             // [hyst_ring_slots()] the queue: a ring of tile + 1 (0 = empty slot)
-    int *pass_count;        // [kHystCounters] queue counters tail / head / done, 128 bytes apart (canny.hip kQTail ...)
+    int *hflags;            // [2][B * tiles] "look at this tile again" / "queued" flags, one parity per launch of the hysteresis
+    int *hlist;             // [hyst_ring_slots()] the work queue of the last launch: a ring of tile + 1 (0 = empty slot)
+    int *pass_count;        // [kHystCounters] the queue's tail / head / done counters (canny.hip kQTail ...)
     const float *space_w;   // [13]
     const float *color_w;   // [256]
     // run-time hyper-parameters of EdgeDetection.canny (edge_detection.py:31-40; aej_set_canny_params)

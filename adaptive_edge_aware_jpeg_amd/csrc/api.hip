@@ -18,7 +18,7 @@
 using namespace aej;
 
 struct aej_pending;
-constexpr int kFlagWords = 16;       // [0] quadtree overflow flag, [1] hysteresis queue entries (diagnostic)
+constexpr int kFlagWords = 16;       // [0] quadtree overflow flag, [1] entries that went through the hysteresis work queue (diagnostic)
 struct aej_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -320,7 +320,7 @@ static void carve_canny(Carver &c, const Geom &g, CannyWs &w)
     w.cb.tile_hist = c.take<int>((long long)g.B * 3 * 16 * 256);
     w.cb.blur_hist = c.take<int>((long long)g.B * 3 * 256);
     w.cb.pass_count = c.take<int>(kHystCounters);
-    w.cb.hflags = c.take<int>(tiles);
+    w.cb.hflags = c.take<int>(2 * tiles);
     c.take<int>(0);
     w.zero_end = c.base ? c.base + c.off : nullptr;
 }

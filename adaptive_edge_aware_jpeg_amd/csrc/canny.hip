@@ -1220,26 +1220,47 @@ __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed,
     return gL | gR;
 }
 
-// The work queue of the hysteresis (CannyBuffers::hlist as a ring of `ring_mask + 1` slots, a power of two of at least the number of
-// tiles; a slot holds tile + 1, 0 = empty) and its three counters, kept 128 bytes apart in CannyBuffers::pass_count:
-//   tail = tickets handed to producers (entries pushed so far), head = tickets handed to consumers, done = entries completely processed.
-// A tile is in the queue at most once (CannyBuffers::hflags: 1 while queued), so at most `tiles` slots are ever occupied.
+// What a launch of the hysteresis hands to the next one.  Large batches: nothing but FLAGS -- hflags + (k & 1) * tiles, 1 = "look at this
+// tile again", set with plain stores and scanned by the next launch (a list would need a counter that every dirtied tile increments:
+// same-address atomics retire at about 5 ns each on this chip, and natural images dirty three quarters of their tiles in the first
+// launch: 0.7 ms of atomics).  The last launch but one fills a WORK QUEUE instead: CannyBuffers::hlist as a ring of `ring_mask + 1` slots
+// (a power of two >= tiles; an entry is tile + 1, 0 = empty slot), de-duplicated by the flags of the other parity (1 = queued), with
+// three counters kept 128 bytes apart in pass_count:
+//   tail = entries pushed so far, head = tickets handed to consumers, done = entries completely processed.
+// A tile is in the queue at most once at a time, so at most `tiles` slots are ever occupied.
 constexpr int kQTail = 32, kQHead = 64, kQDone = 96;
 constexpr int kChaseDepth = 32;
+struct HystOut { int *flags; int *ring; int *tail; int ring_mask; };      // ring == nullptr: flags only
+__device__ __forceinline__ HystOut hyst_out(const CannyBuffers &cb, int parity, bool ring, long long total_tiles, int ring_mask)
+{
+    HystOut q;
+    q.flags = cb.hflags + (long long)parity * total_tiles;
+    q.ring = ring ? cb.hlist : nullptr;
+    q.tail = cb.pass_count + kQTail;
+    q.ring_mask = ring_mask;
+    return q;
+}
 
 // (wave-uniform address: the first lane's value, so that what depends on it is scalar control flow)
 __device__ __forceinline__ int ld_agent(const int *p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ int ld_agent_lane(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Queue tile nT unless it is queued already.  Called by single lanes; the caller has drained the stores / atomics that made the tile dirty.
-__device__ __forceinline__ void hyst_push(const CannyBuffers &cb, long long nT, int ring_mask)
+// Tile nT has a new pixel next to it: flag it for the next launch, or queue it unless it is queued already.  Called by single lanes; the
+// caller has drained the stores / atomics that made the tile dirty.
+template <bool RING>
+__device__ __forceinline__ void hyst_push(const HystOut &q, long long nT)
 {
-    if (atomicExch(&cb.hflags[nT], 1) != 0) return;
-    const int t = atomicAdd(&cb.pass_count[kQTail], 1);
-    int *slot = &cb.hlist[t & ring_mask];
-    // (the slot of ticket t - ring size was handed out at most `tiles` queue entries ago: its consumer has long emptied it; wait if not)
-    while (ld_agent_lane(slot) != 0) __builtin_amdgcn_s_sleep(2);
-    __hip_atomic_store(slot, (int)nT + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (!RING) {
+        q.flags[nT] = 1;
+    } else {
+        if (atomicExch(&q.flags[nT], 1) != 0) return;
+        const int t = atomicAdd(q.tail, 1);
+        int *slot = &q.ring[t & q.ring_mask];
+        // (second lap of the ring: the slot of ticket t - ring size was handed out at least `tiles` entries ago, its consumer has long
+        // emptied it; wait if not)
+        if (t > q.ring_mask) while (ld_agent_lane(slot) != 0) __builtin_amdgcn_s_sleep(2);
+        __hip_atomic_store(slot, (int)nT + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // One 64 x 64 tile to its fix-point for the halo it sees now.  ATOMIC: other waves may work on neighbouring tiles -- or on this one --
@@ -1349,71 +1370,120 @@ __device__ __forceinline__ long long hyst_neighbour(const HystTile &ht, long lon
     return (long long)ht.b * tiles_per_img + ht.tbase + (long long)(ht.ty + oy) * ht.ntx + (ht.tx + ox);
 }
 
-// Launch 1 of 2: every tile once, plain loads and stores (a wave sees its neighbours as they were or as they become: whoever changes a
-// border queues the neighbour behind it, so nothing is lost).
+// First launch: every tile once, plain loads and stores (a wave sees its neighbours as they were or as they become: whoever changes a
+// border flags / queues the neighbour behind it, so nothing is lost).
+template <bool RING>
 __global__ __launch_bounds__(256) void k_hyst_pass0(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int ring_mask)
 {
     const int lane = threadIdx.x & 63;
     const long long nwaves = (long long)gridDim.x * 4;
+    const HystOut dst = hyst_out(cb, 0, RING, total_tiles, ring_mask);
     for (long long T = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); T < total_tiles; T += nwaves) {
         HystTile ht;
         const unsigned dirs = hyst_tile<false>(g, cb, T, tiles_per_img, lane, ht);
         if (dirs == 0) continue;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the tile's stores before the queue entries that announce them
-        if (lane < 8 && ((dirs >> lane) & 1u)) hyst_push(cb, hyst_neighbour(ht, tiles_per_img, lane), ring_mask);
+        if constexpr (RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile's stores before the queue entries that announce them
+        if (lane < 8 && ((dirs >> lane) & 1u)) hyst_push<RING>(dst, hyst_neighbour(ht, tiles_per_img, lane));
     }
 }
 
-// Launch 2 of 2: the queue is drained to the fix-point by however many waves the launch has -- no pass structure, no barrier, nothing
-// for the host to guess or to read back.  A wave takes a ticket (head), waits for the entry of that ticket, clears the tile's "queued"
-// flag BEFORE it reads the tile (a change that arrives later finds the flag clear and queues the tile again), brings the tile to its
-// fix-point and CHASES the contour: of the neighbours it has dirtied it processes one itself straight away (up to kChaseDepth tiles in
-// a row) and queues the others, so a long thin contour costs a chain of tiles on one wave instead of a queue round trip per tile.
+// A tile and the contour behind it: of the neighbours the tile has dirtied the wave processes one itself straight away (up to
+// kChaseDepth tiles in a row) and flags / queues the others, so a long thin contour costs a chain of tiles on one wave instead of a
+// round trip per tile.  Two waves may meet in a tile: hyst_tile<true> writes with atomicOr and reads with agent-scope loads.
+template <bool RING>
+__device__ __forceinline__ void hyst_chase(const Geom &g, const CannyBuffers &cb, long long T, long long tiles_per_img, int lane, const HystOut &dst)
+{
+    for (int depth = 0;; depth++) {
+        HystTile ht;
+        const unsigned dirs = hyst_tile<true>(g, cb, T, tiles_per_img, lane, ht);
+        if (dirs == 0) return;
+        int chase = -1;
+        // prefer a side neighbour over a corner: 4 (right), 3 (left), 6 (down), 1 (up), then the corners
+        if (depth < kChaseDepth) chase = (dirs & 16u) ? 4 : (dirs & 8u) ? 3 : (dirs & 64u) ? 6 : (dirs & 2u) ? 1 : __ffs((int)dirs) - 1;
+        if (lane < 8 && ((dirs >> lane) & 1u) && lane != chase) hyst_push<RING>(dst, hyst_neighbour(ht, tiles_per_img, lane));
+        if (chase < 0) return;
+        T = hyst_neighbour(ht, tiles_per_img, chase);
+    }
+}
+
+// Bulk launches (large batches only): a wave owns kBulkGroup consecutive tiles, reads their flags of parity k - 1 (complete when the launch
+// starts: the kernel boundary is the barrier -- no list, no counter, no polling), clears them and chases each flagged tile; what that
+// dirties is flagged in the other parity (k < last) or queued for the drain (k == last, de-duplicated by the other parity's flags, all
+// zero again by then).
+#ifndef AEJ_X_HYST_GROUP
+#define AEJ_X_HYST_GROUP 4
+#endif
+constexpr int kBulkGroup = AEJ_X_HYST_GROUP;
+template <bool RING>
+__global__ __launch_bounds__(256) void k_hyst_bulk(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int k, int ring_mask)
+{
+    const int lane = threadIdx.x & 63;
+    int *src = cb.hflags + (long long)((k - 1) & 1) * total_tiles;
+    const HystOut dst = hyst_out(cb, k & 1, RING, total_tiles, ring_mask);
+    const long long base = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kBulkGroup;
+    if (base >= total_tiles) return;
+    const bool mine = lane < kBulkGroup && base + lane < total_tiles;
+    const int f = mine ? src[base + lane] : 0;
+    unsigned m = (unsigned)__ballot(f != 0);
+    if (m == 0) return;
+    if (f) src[base + lane] = 0;
+    while (m) {
+        const int i = __ffs((int)m) - 1;
+        m &= m - 1;
+        hyst_chase<RING>(g, cb, base + i, tiles_per_img, lane, dst);
+    }
+}
+
+// Last launch: the work queue is drained to the fix-point by however many waves the launch has: no pass structure, no barrier,
+// nothing for the host to guess or to read back.  A wave claims a chunk of tickets (head), waits for the entries of those tickets,
+// clears the tiles' "queued" flags BEFORE it reads the tiles (a change that arrives later finds the flag clear and queues the tile
+// again), and chases each tile's contour, pushing to the same ring.
 // Termination: entries are only ever pushed by a wave that is processing an entry, and `done` counts entries whose processing -- pushes
 // included -- is complete; done == tail (done read first) therefore means that nothing is queued, nothing is running and nothing can be
 // pushed any more.  Every wave reaches that state or an entry of its own: a wave never waits for another wave to be scheduled, only for
-// a running one to finish its tile, so the launch needs no co-residency.
-__global__ __launch_bounds__(256) void k_hyst_drain(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int ring_mask)
+// a running one to finish its tile, so the launch needs no co-residency.  Waiting waves poll two counters: the launch is kept small
+// (more waves measured slower: 64 x 4K hysteresis stage 0.48 / 0.53 / 0.66 / 0.83 ms with 256 / 512 / 1024 / 2048 workgroups draining
+// everything the first launch dirtied), which is why large batches run two bulk launches first.
+#ifndef AEJ_X_HYST_CHUNK
+#define AEJ_X_HYST_CHUNK 4             // tickets a wave claims at once: one claim, one round of slot reads and one round of flag clears per chunk
+#endif
+__global__ __launch_bounds__(256) void k_hyst_drain(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int parity, int ring_mask)
 {
+    constexpr int K = AEJ_X_HYST_CHUNK;
     const int lane = threadIdx.x & 63;
-    int *q = cb.pass_count;
+    const HystOut q = hyst_out(cb, parity, true, total_tiles, ring_mask);
+    int *head = cb.pass_count + kQHead, *done_p = cb.pass_count + kQDone;
     for (;;) {
         int my = 0;
-        if (lane == 0) my = atomicAdd(&q[kQHead], 1);
+        if (lane == 0) my = atomicAdd(head, K);
         my = __builtin_amdgcn_readfirstlane(my);
-        bool have = false;
-        for (;;) {
-            if (my - ld_agent(&q[kQTail]) < 0) { have = true; break; }
-            const int done = ld_agent(&q[kQDone]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // `done` is read before `tail`
-            const int tail = ld_agent(&q[kQTail]);
-            if (my - tail < 0) { have = true; break; }
-            if (done == tail) break;                                       // quiescent: this ticket will never be served
-            __builtin_amdgcn_s_sleep(32);
+        int next = my;                         // first ticket of the chunk not served yet
+        while (next - (my + K) < 0) {
+            int tail = ld_agent(q.tail);
+            const int avail = (tail - (my + K) < 0 ? tail : my + K) - next;
+            if (avail <= 0) {
+                const int done = ld_agent(done_p);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // `done` is read before `tail`
+                tail = ld_agent(q.tail);
+                if (done == tail) return;                                  // quiescent: the rest of this chunk will never be served
+                if (tail - next <= 0) __builtin_amdgcn_s_sleep(100);
+                continue;
+            }
+            // lanes 0 .. avail-1 fetch one entry each: the slot (written, or about to be: its producer holds the ticket), then the tile's
+            // "queued" flag is cleared BEFORE the tile is read
+            int e = 0;
+            if (lane < avail) {
+                int *slot = &q.ring[(next + lane) & ring_mask];
+                while ((e = ld_agent_lane(slot)) == 0) __builtin_amdgcn_s_sleep(1);
+                __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)atomicExch(&q.flags[e - 1], 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // flags cleared (performed at the L2) before any of the tiles is read
+            for (int i = 0; i < avail; i++) hyst_chase<true>(g, cb, (long long)__shfl(e, i) - 1, tiles_per_img, lane, q);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // these entries' pushes (tail tickets, slots) before they count as done
+            if (lane == 0) atomicAdd(done_p, avail);
+            next += avail;
         }
-        if (!have) return;
-        int *slot = &cb.hlist[my & ring_mask];
-        int e;
-        while ((e = ld_agent(slot)) == 0) __builtin_amdgcn_s_sleep(2);     // (the producer holds the ticket and is about to write)
-        long long T = e - 1;
-        if (lane == 0) {
-            __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)atomicExch(&cb.hflags[T], 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // flag cleared (performed at the L2) before the tile is read
-        for (int depth = 0;; depth++) {
-            HystTile ht;
-            const unsigned dirs = hyst_tile<true>(g, cb, T, tiles_per_img, lane, ht);
-            if (dirs == 0) break;
-            int chase = -1;
-            // prefer a side neighbour over a corner: 4 (right), 3 (left), 6 (down), 1 (up), then the corners
-            if (depth < kChaseDepth) chase = (dirs & 16u) ? 4 : (dirs & 8u) ? 3 : (dirs & 64u) ? 6 : (dirs & 2u) ? 1 : __ffs((int)dirs) - 1;
-            if (lane < 8 && ((dirs >> lane) & 1u) && lane != chase) hyst_push(cb, hyst_neighbour(ht, tiles_per_img, lane), ring_mask);
-            if (chase < 0) break;
-            T = hyst_neighbour(ht, tiles_per_img, chase);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this entry's pushes (tail tickets, slots) before it counts as done
-        if (lane == 0) atomicAdd(&q[kQDone], 1);
     }
 }
 
@@ -1557,19 +1627,38 @@ void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, con
     else hipLaunchKernelGGL(k_sobel_nms<false>, grid, dim3(256), 0, st, g, cb, strip);
 }
 
-// the two launches of the hysteresis: every tile once, then the queue of dirtied tiles drained to the fix-point on the device
+// The launches of the hysteresis: every tile once; for large batches two bulk launches over the tiles flagged by the launch before
+// (synthetic bench batch: a tenth of the tiles, then a fifth of that; natural images: three quarters, then a quarter); then the rest
+// drained to the fix-point on the device by one small persistent launch.
+#ifndef AEJ_X_HYST_DRAIN_WGS
+#define AEJ_X_HYST_DRAIN_WGS 64
+#endif
+int hyst_bulk_launches(const Geom &g)
+{
+    const long long total = hyst_tiles_per_image(g) * g.B;
+#ifdef AEJ_X_HYST_BULK
+    return AEJ_X_HYST_BULK;
+#endif
+    return total > 32768 ? 2 : total > 8192 ? 1 : 0;
+}
 void launch_hysteresis(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
     const long long t = hyst_tiles_per_image(g), total = t * g.B;
     if (total <= 0) return;
-    const int ring_mask = hyst_ring_slots(g) - 1;
+    const int nbulk = hyst_bulk_launches(g), ring_mask = hyst_ring_slots(g) - 1;
     long long blocks = (total + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(k_hyst_pass0, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, t, total, ring_mask);
-    // consumers: a wave per 16 tiles, at most 1024 waves (the queue starts with a few per cent of the tiles and shrinks geometrically)
+    if (nbulk == 0) hipLaunchKernelGGL(k_hyst_pass0<true>, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, t, total, ring_mask);
+    else hipLaunchKernelGGL(k_hyst_pass0<false>, dim3((unsigned)blocks), dim3(256), 0, st, g, cb, t, total, ring_mask);
+    const unsigned bulk_blocks = (unsigned)((total + 4 * kBulkGroup - 1) / (4 * kBulkGroup));
+    for (int k = 1; k <= nbulk; k++) {
+        if (k == nbulk) hipLaunchKernelGGL(k_hyst_bulk<true>, dim3(bulk_blocks), dim3(256), 0, st, g, cb, t, total, k, ring_mask);
+        else hipLaunchKernelGGL(k_hyst_bulk<false>, dim3(bulk_blocks), dim3(256), 0, st, g, cb, t, total, k, ring_mask);
+    }
+    // consumers of the queue: a wave per 16 tiles, at most 4 x AEJ_X_HYST_DRAIN_WGS waves
     long long drain = (total + 63) / 64;
-    if (drain > 256) drain = 256;
-    hipLaunchKernelGGL(k_hyst_drain, dim3((unsigned)drain), dim3(256), 0, st, g, cb, t, total, ring_mask);
+    if (drain > AEJ_X_HYST_DRAIN_WGS) drain = AEJ_X_HYST_DRAIN_WGS;
+    hipLaunchKernelGGL(k_hyst_drain, dim3((unsigned)drain), dim3(256), 0, st, g, cb, t, total, nbulk & 1, ring_mask);
 }
 
 static int expand_blocks(const Geom &g)

@@ -232,89 +232,141 @@ __global__ __launch_bounds__(256) void k_dct_small(Geom g, QtGeom q, DctArgs a, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// 4 x 4 blocks (the most numerous leaves): one THREAD per leaf, everything in registers.  Four 16-byte row loads, both
-// products as the same k-ordered fma chains, 16 quotients, zigzag as a compile-time permutation, four 16-byte stores
-// (consecutive leaves of a Morton-ordered list have consecutive coefficient offsets, so a wave writes 4 KiB contiguously).
-// No LDS transpose, no barriers; 25 instead of 61 VALU instructions per pixel.
+// 4 x 4 blocks (the most numerous leaves -- half of the plane area of a natural image): FOUR LANES per leaf, registers and DPP only.
+// Lane r of a quad loads row r of X (16 bytes; with the planes in 4 x 4 blocks a leaf is one 64-byte run, so a quad makes one 64-byte
+// request and sixteen Morton-consecutive leaves a few contiguous lines).  T[r][.] = sum_k D[r][k] X[k][.] takes the other rows from the
+// quad's lanes by DPP quad_perm broadcasts (the k-ascending fma chain of the contract), Y[r][.] = T[r][.].D^T is lane-local; four
+// quotients per lane with the quantisers AND their reciprocals tabulated once per workgroup (v_rcp_f32 is the slowest instruction of
+// the float32 quantiser); the leaf's 64 bytes pass through a wave-private LDS slab at their zigzag positions (LDS operations of one
+// wave execute in order) and leave as one 16-byte store per lane: a wave writes 1 KiB contiguously.
+// A workgroup walks a CONTIGUOUS range of the item list, so a lane's plane index moves forward by a comparison per leaf instead of a
+// binary search, and what it reads and writes stays local.  (Round 3's kernel was one thread per leaf: 86 registers, 400 instructions per
+// leaf of which the quantiser and its range test were two thirds; natural images 0.97 ms.)
 // ------------------------------------------------------------------------------------------------
+template <int SEL>
+__device__ __forceinline__ float quad_bcast(float v)      // value of lane SEL of this lane's quad
+{
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), SEL * 0x55, 0xf, 0xf, true));      // quad_perm [SEL, SEL, SEL, SEL]
+}
+
+__device__ __forceinline__ int quantise_f32_rcp(float y, float qf, float rq)      // quantise_f32 with the reciprocal looked up (same instruction, same bits)
+{
+    const float k = __builtin_rintf(y * rq);
+    const float r = __builtin_fmaf(-k, qf, y);
+    const float h = 0.5f * qf, ar = __builtin_fabsf(r);
+    int ki = (int)k;
+    if (ar > h || (ar == h && (ki & 1))) ki += r > 0.f ? 1 : -1;
+    return ki;
+}
+
 template <bool WANT_DCT>
 __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long long max_items)
 {
-    __shared__ float sD[16];
-    __shared__ int sQm[3 * 16];
+    constexpr int LPB = 64;                   // leaves per workgroup and iteration
+    __shared__ float sQf[3 * 16], sQr[3 * 16];
+    __shared__ int sOut[4][16 * 16];          // per wave: 16 leaves x 16 coefficients
+    __shared__ int sSlowQ;
     __shared__ LayerTab lt;
     extern __shared__ int s_pref[];
     const int tid = threadIdx.x;
-    if (tid < 16) sD[tid] = a.D[tid];
-    if (tid < 48) sQm[tid] = a.qm[tid / 16] ? a.qm[tid / 16][tid % 16] : 1;
+    if (tid == 0) sSlowQ = 0;
+    __syncthreads();
+    if (tid < 48) {
+        const int qi = a.qm[tid / 16] ? a.qm[tid / 16][tid % 16] : 1;
+        sQf[tid] = (float)qi;
+        sQr[tid] = __builtin_amdgcn_rcpf((float)qi);
+        if (qi > (1 << 22)) sSlowQ = 1;      // (never with the codec's own tables: quantise_f32 needs q <= 2^22)
+    }
     dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
     long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
+    const bool slow_q = sSlowQ != 0;
     const long long wstride = q.work_stride[a.k];
-    float D[4][4];
+    const int lane = tid & 63, wv = tid >> 6, r = tid & 3, slot = tid >> 2;
+    float D[4][4], Dr[4];
 #pragma unroll
-    for (int i = 0; i < 16; i++) D[i >> 2][i & 3] = sD[i];
-    for (long long item = (long long)blockIdx.x * 256 + tid; item < count; item += (long long)gridDim.x * 256) {
-        const int4 cur = fetch_item(a, wstride, lt, s_pref, item);
-        const int b = cur.x / 3, layer = cur.x - b * 3;
-        const int w = lt.w[layer], h = lt.h[layer];
-        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
-        const int hc = min(4, h - cur.z), wc = min(4, w - cur.y);
-        float x[4][4];
-        if (hc == 4 && wc == 4 && (w & 3) == 0) {
+    for (int i = 0; i < 16; i++) D[i >> 2][i & 3] = a.D[i];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float4 v = *reinterpret_cast<const float4 *>(src + plane_elem(g.tiled, w, cur.z + r, cur.y));      // (tiled: the four rows are one 64-byte run)
-                x[r][0] = v.x; x[r][1] = v.y; x[r][2] = v.z; x[r][3] = v.w;
-            }
-        } else {                              // clipped at the plane border (np.pad reflect) or unaligned rows
+    for (int k = 0; k < 4; k++) Dr[k] = a.D[r * 4 + k];
+    int zz[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    x[r][c] = src[plane_elem(g.tiled, w, cur.z + reflect_pad_idx(r, hc), cur.y + reflect_pad_idx(c, wc))];
+    for (int c = 0; c < 4; c++) zz[c] = zigzag_pos<4>(r, c);
+    int *slab = sOut[wv] + (lane >> 2) * 16;
+    // this workgroup's contiguous share of the items, a multiple of LPB
+    const long long per = ((count + gridDim.x - 1) / gridDim.x + LPB - 1) / LPB * LPB;
+    const long long first = (long long)blockIdx.x * per, last = first + per < count ? first + per : count;
+    int p = 0;                                // plane of the lane's current item: largest p with s_pref[p] <= item
+    if (first + slot < last) {
+        int lo = 0, hi = a.nplanes;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)s_pref[mid] <= first + slot) lo = mid; else hi = mid;
         }
-        float T[4][4];                        // T[i][j] = sum_k D[i][k] X[k][j]
+        p = lo;
+    }
+    for (long long base = first; base < last; base += LPB) {
+        const long long item = base + slot;
+        const bool active = item < last;
+        float x[4] = { 0.f, 0.f, 0.f, 0.f };
+        int layer = 0, b = 0;
+        int4 cur = make_int4(0, 0, 0, 0);
+        if (active) {
+            while ((long long)s_pref[p + 1] <= item) p++;      // (item < count = s_pref[nplanes]: p + 1 <= nplanes)
+            b = p / 3;
+            layer = p - 3 * b;
+            cur = reinterpret_cast<const int4 *>(a.work)[(long long)b * wstride + lt.woff[layer] + (item - s_pref[p])];
+            const int w = lt.w[layer], h = lt.h[layer];
+            const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+            const int hc = min(4, h - cur.z), wc = min(4, w - cur.y);
+            if (hc == 4 && wc == 4 && (w & 3) == 0) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + plane_elem(g.tiled, w, cur.z + r, cur.y));      // (tiled: the quad reads one 64-byte run)
+                x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+            } else {                          // clipped at the plane border (np.pad reflect) or unaligned rows
+                const int y = cur.z + reflect_pad_idx(r, hc);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) acc = __builtin_fmaf(D[i][k], x[k][j], acc);
-                T[i][j] = acc;
+                for (int c = 0; c < 4; c++) x[c] = src[plane_elem(g.tiled, w, y, cur.y + reflect_pad_idx(c, wc))];
             }
-        const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + cur.w;
-        int out[16];
-        float Y[4][4], ymax = 0.f;
-        int qmax = 0;
+        }
+        // T[r][c] = sum_k D[r][k] X[k][c]: row k of X comes from lane k of the quad (all 64 lanes take part; inactive quads carry zeros)
+        float t[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int c = 0; c < 4; c++) {
+            float acc = 0.f;
+            acc = __builtin_fmaf(Dr[0], quad_bcast<0>(x[c]), acc);
+            acc = __builtin_fmaf(Dr[1], quad_bcast<1>(x[c]), acc);
+            acc = __builtin_fmaf(Dr[2], quad_bcast<2>(x[c]), acc);
+            acc = __builtin_fmaf(Dr[3], quad_bcast<3>(x[c]), acc);
+            t[c] = acc;
+        }
+        // Y[r][c] = sum_k T[r][k] D[c][k]
+        float y[4], ymax = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {   // Y[i][jj] = sum_k T[i][k] D[jj][k]
-                float acc = 0.f;
+        for (int c = 0; c < 4; c++) {
+            float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; k++) acc = __builtin_fmaf(T[i][k], D[jj][k], acc);
-                if (WANT_DCT) a.dct_f32[out_base + i * 4 + jj] = acc;
-                Y[i][jj] = acc;
-                ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
-                qmax = max(qmax, sQm[layer * 16 + i * 4 + jj]);
-            }
-        // one range test per leaf for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
-        if (!__any(qmax > (1 << 22) || !(ymax < 131072.0f))) {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) out[zigzag_pos<4>(i, jj)] = quantise_f32(Y[i][jj], (float)sQm[layer * 16 + i * 4 + jj]);
+            for (int k = 0; k < 4; k++) acc = __builtin_fmaf(t[k], D[c][k], acc);
+            y[c] = acc;
+            ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
+        }
+        const long long out_base = active ? (long long)b * q.coeff_stride + lt.coff[layer] + cur.w : 0;
+        if (WANT_DCT && active) *reinterpret_cast<float4 *>(a.dct_f32 + out_base + r * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        const float4 qf = *reinterpret_cast<const float4 *>(&sQf[layer * 16 + r * 4]), rq = *reinterpret_cast<const float4 *>(&sQr[layer * 16 + r * 4]);
+        // one range test per wave for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
+        if (!slow_q && !__any(!(ymax < 131072.0f))) {
+            slab[zz[0]] = quantise_f32_rcp(y[0], qf.x, rq.x);
+            slab[zz[1]] = quantise_f32_rcp(y[1], qf.y, rq.y);
+            slab[zz[2]] = quantise_f32_rcp(y[2], qf.z, rq.z);
+            slab[zz[3]] = quantise_f32_rcp(y[3], qf.w, rq.w);
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) out[zigzag_pos<4>(i, jj)] = quantise_f64(Y[i][jj], sQm[layer * 16 + i * 4 + jj]);
+            slab[zz[0]] = quantise_f64(y[0], (int)qf.x);
+            slab[zz[1]] = quantise_f64(y[1], (int)qf.y);
+            slab[zz[2]] = quantise_f64(y[2], (int)qf.z);
+            slab[zz[3]] = quantise_f64(y[3], (int)qf.w);
         }
-        int4 *dst = reinterpret_cast<int4 *>(a.coeffs + out_base);     // offsets are sums of squares of sizes >= 2: multiples of 4
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[r] = make_int4(out[4 * r], out[4 * r + 1], out[4 * r + 2], out[4 * r + 3]);
+        if (active) {
+            const int4 o = reinterpret_cast<const int4 *>(slab)[r];
+            reinterpret_cast<int4 *>(a.coeffs + out_base)[r] = o;      // coefficient offsets are multiples of 4
+        }
     }
 }
 
@@ -1417,8 +1469,8 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
     switch (size) {
     case 2: AEJ_SMALL(2, 128, 2048); break;
     case 4:
-        if (wd) hipLaunchKernelGGL((k_dct4<true>), dim3(cap(256, 8192)), dim3(256), pref, st, g, q, a, max_items);
-        else hipLaunchKernelGGL((k_dct4<false>), dim3(cap(256, 8192)), dim3(256), pref, st, g, q, a, max_items);
+        if (wd) hipLaunchKernelGGL((k_dct4<true>), dim3(cap(64 * 8, 8192)), dim3(256), pref, st, g, q, a, max_items);
+        else hipLaunchKernelGGL((k_dct4<false>), dim3(cap(64 * 8, 8192)), dim3(256), pref, st, g, q, a, max_items);
         break;
     case 8:
         if (wd) hipLaunchKernelGGL((k_dct8_shfl<true>), dim3(cap(32, 4096)), dim3(256), pref, st, g, q, a, max_items);
