@@ -70,6 +70,40 @@ __device__ __forceinline__ double dev_pow(double x, double y, const PowTabs &pt)
 }
 __device__ __forceinline__ double dev_pow(double x, double y) { return dev_pow(x, y, pow_tabs_global()); }
 
+// oklab.py:73 -- np.power(lms float32, 1 / 3) = x^t with t = (double)(float)(1 / 3) = 1/3 + 9.93e-9, as cbrt(x) * x^(t - 1/3): a float32
+// Newton iteration for x^(-1/3) from a bit-pattern seed (three steps: 2e-7), one float64 step (4e-14), and the excess exponent as
+// 1 + (t - 1/3) ln 2 * (bit-pattern estimate of log2 x).  |rel err| <= 3e-10; sixteen float32 + eleven float64 operations, no table, no
+// division.  The same sequence, operation for operation, as pow_third_f32 in the CPU restatement (round 4: the general dev_pow above
+// made the OKLAB colour stage of an 8K batch arithmetic-bound at twice its memory time).
+__device__ __forceinline__ float dev_pow_third_f32(float x, const PowTabs &pt)
+{
+    const double third = (double)(float)(1.0 / 3.0);
+    if (x == 0.0f) return 0.0f;
+    if (!(x > 0.0f)) return __uint_as_float(0x7FC00000u);
+    if (x < 1e-30f || x > 1e30f) return (float)dev_pow((double)x, third, pt);      // never produced by 8-bit images; keeps the seed in range
+    const unsigned ix = __float_as_uint(x);
+    float r = __uint_as_float(0x54a2fa8cu - ix / 3u);
+    const float x3 = x * 0x1.555556p-2f;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const float r2 = r * r;
+        const float r3 = r2 * r;
+        const float t = __builtin_fmaf(-x3, r3, 0x1.555556p+0f);
+        r = r * t;
+    }
+    const double xd = (double)x;
+    double rd = (double)r;
+    const double r2d = rd * rd;
+    const double r3d = r2d * rd;
+    const double td = fma(-(xd * 0x1.5555555555555p-2), r3d, 0x1.5555555555555p+0);
+    rd = rd * td;
+    double c = xd * rd;
+    c = c * rd;                                                   // cbrt(x)
+    const double L = fma((double)(int)ix, 0x1p-23, -0x1.fbd3f7ced9168p+6);      // ~ log2(x): bit pattern / 2^23 - 126.957
+    const double u = 0x1.d9303ff8f9009p-28 * L;                  // (t - 1/3) ln 2 * log2(x)
+    return (float)fma(c, u, c);
+}
+
 // ------------------------------------------------------------------------------------------------
 // matrices: float32(value) of the Python literals (numpy: np.array([...], dtype=np.float32))
 // ------------------------------------------------------------------------------------------------

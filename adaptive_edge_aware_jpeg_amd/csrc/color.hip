@@ -44,8 +44,7 @@ __device__ __forceinline__ void color_px_lin(float r, float g, float b, float &o
         float l = dot3(F(0.8189330101), F(0.3618667424), F(-0.1288597137), X, Y, Z);
         float m = dot3(F(0.0329845436), F(0.9293118715), F(0.0361456387), X, Y, Z);
         float s = dot3(F(0.0482003018), F(0.2643662691), F(0.6338517070), X, Y, Z);
-        const double third = (double)(float)(1.0 / 3.0);
-        float lp = (float)dev_pow((double)l, third, pt), mp = (float)dev_pow((double)m, third, pt), sp = (float)dev_pow((double)s, third, pt);
+        float lp = dev_pow_third_f32(l, pt), mp = dev_pow_third_f32(m, pt), sp = dev_pow_third_f32(s, pt);      // np.power(f32, 1 / 3)
         o0 = dot3(F(0.2104542553), F(0.7936177850), F(-0.0040720468), lp, mp, sp);
         o1 = dot3(F(1.9779984951), F(-2.4285922050), F(0.4505937099), lp, mp, sp);
         o2 = dot3(F(0.0259040371), F(0.7827717662), F(-0.8086757660), lp, mp, sp);

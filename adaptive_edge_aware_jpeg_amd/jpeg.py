@@ -238,24 +238,30 @@ class Jpeg:
         return len(mb).to_bytes(4, byteorder="big") + mb
 
     @staticmethod
-    def _layer_bytes(L) -> bytes:
-        """One layer record of the container (jpeg.py:561-595): state bits, root size, zlib-9 of the int32 coefficients."""
+    def _layer_bytes(L, zlib_level: int = 9) -> bytes:
+        """One layer record of the container (jpeg.py:561-595): state bits, root size, zlib-9 of the int32 coefficients
+        (``zlib_level`` other than the reference's 9 is an opt-in: any level gives a stream the reference's ``zlib.decompress`` reads)."""
         st = L["states"]
         bits_len = 2 * len(st)
         pad = (-len(st)) % 4
         quad = np.concatenate([st, np.zeros(pad, np.uint8)]).reshape(-1, 4)
         packed = ((quad[:, 0] << 6) | (quad[:, 1] << 4) | (quad[:, 2] << 2) | quad[:, 3]).astype(np.uint8)
-        comp = zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=9)
+        comp = zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=zlib_level)
         return b"".join((bits_len.to_bytes(4, byteorder="big"), int(L["root_size"]).to_bytes(4, byteorder="big"), packed.tobytes(),
                          len(comp).to_bytes(4, byteorder="big"), comp))
 
     def _entropy_encode(self, layers) -> bytes:
         return self._header_bytes(len(layers)) + b"".join(self._layer_bytes(L) for L in layers)
 
-    def compress_many(self, batch, extension: Optional[str] = None, workers: Optional[int] = None) -> List[bytes]:
+    def compress_many(self, batch, extension: Optional[str] = None, workers: Optional[int] = None, zlib_level: int = 9) -> List[bytes]:
         """``compress`` for a batch: one GPU pass (``compress_batch``), then the container of every image with the
         per-layer zlib-9 streams -- the part of ``compress`` that dominates end to end -- deflated on a thread pool (zlib
-        releases the GIL).  Each element equals ``compress(Image(batch[i]))`` byte for byte."""
+        releases the GIL).  Each element equals ``compress(Image(batch[i]))`` byte for byte.
+
+        ``zlib_level`` is an opt-in for throughput: with the hot path on the GPU, level 9 deflate of the int32 coefficients IS the
+        call (98 % of it on natural 4K images: 1.4 MP/s per host core against 80 000 MP/s for everything before it,
+        profiles/r04_bench_extra*.json); a lower level writes a larger container that ``Jpeg.decompress`` -- the reference's included,
+        jpeg.py:659 -- reads unchanged.  The default stays 9, the reference's (jpeg.py:590), so the bytes stay the reference's."""
         from concurrent.futures import ThreadPoolExecutor
         enc = self.compress_batch(batch)
         p = enc.plan
@@ -264,7 +270,7 @@ class Jpeg:
         header = self._header_bytes(3)
         jobs = [(b, l) for b in range(p.batch) for l in range(3)]
         with ThreadPoolExecutor(max_workers=workers or min(32, os.cpu_count() or 1)) as ex:
-            recs = list(ex.map(lambda bl: self._layer_bytes(enc.layer(bl[0], bl[1])), jobs))
+            recs = list(ex.map(lambda bl: self._layer_bytes(enc.layer(bl[0], bl[1]), zlib_level), jobs))
         return [header + b"".join(recs[3 * b:3 * b + 3]) for b in range(p.batch)]
 
     # ------------------------------------------------------------------ small helpers, reference names kept

@@ -68,6 +68,12 @@ def end_to_end(torch, bench, A, codec, args, dev, H, W):
     dt = time.perf_counter() - t0
     res["compress_many"] = {"s": round(dt, 3), "MP/s": round(mp / dt, 1), "workers": workers, "bytes_out": int(sum(len(b) for b in blobs)),
                             "bits_per_pixel": round(8.0 * sum(len(b) for b in blobs) / (n * H * W), 3)}
+    for level in (1, 6):                                      # opt-in: same container, lower deflate effort (the reference's decoder reads any level)
+        t0 = time.perf_counter()
+        alt = codec.compress_many(x, extension=".png", workers=workers, zlib_level=level)
+        dta = time.perf_counter() - t0
+        res[f"compress_many_zlib_level_{level}"] = {"s": round(dta, 3), "MP/s": round(mp / dta, 1), "bytes_out": int(sum(len(b) for b in alt)),
+                                                    "bits_per_pixel": round(8.0 * sum(len(b) for b in alt) / (n * H * W), 3)}
     img = A.Image.from_array(x[0].cpu().numpy(), (H, W, 3), ".png")
     codec.compress(img)
     t0 = time.perf_counter()

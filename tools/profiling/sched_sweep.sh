@@ -1,19 +1,10 @@
 #!/bin/bash
-# schedule sweep of the pipelined 64 x 4K bench (GPU box): sub-batches x contexts x stagger event
-run() { env $1 python3 bench.py --no-cpu-baseline --no-verify --steps 10 --warmup 3 $2 2>/dev/null | python3 -c "
+# schedule sweep of the pipelined bench: contexts (--pipeline) x sub-batches per call, optional library options
+#   bash tools/profiling/sched_sweep.sh "<pipelines>" "<sub-batch counts>" [extra bench args]
+pipes=${1:-"2 3 4"}; subs=${2:-"2 3 4 6 8"}; shift; shift
+for p in $pipes; do for s in $subs; do
+python3 bench.py --no-cpu-baseline --no-verify --steps 40 --warmup 6 --pipeline $p --sub-batches $s "$@" 2>/dev/null | python3 -c "
 import json,sys
 d=json.load(sys.stdin)
-print('[$1] [$2]:', d['ms_per_step'], 'ms/step; blocking', d['pipeline']['serial_ms_per_step'])"; }
-for rep in 0 1; do
-run "A=1" ""
-run "A=1" "--sub-batches 2"
-run "A=1" "--sub-batches 3"
-run "A=1" "--sub-batches 6"
-run "A=1" "--sub-batches 8"
-run "A=1" "--pipeline 3"
-run "A=1" "--pipeline 3 --sub-batches 2"
-run "AEJ_SUB_CHAIN=0" ""
-run "AEJ_SUB_CHAIN=1" ""
-run "AEJ_SUB_CHAIN=2" ""
-run "AEJ_SUB_CHAIN=3" ""
-done
+print('pipeline $p sub-batches $s $*:', d['ms_per_step'], 'ms/step; blocking', d['pipeline']['serial_ms_per_step'])"
+done; done
