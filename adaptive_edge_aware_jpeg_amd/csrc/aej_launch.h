@@ -120,6 +120,13 @@ int launch_idct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const 
 int launch_color_inverse(hipStream_t st, int space, const float *in, float *out, long long n);
 int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float *planes, float *rgb);
 
+// deflate.hip -- opt-in GPU entropy stage: the layers' int32 coefficients as zlib streams (jpeg.py:588-590, 659)
+unsigned long long deflate_stream_bound(unsigned long long raw_bytes);
+int deflate_max_chunks(long long max_coeffs);
+unsigned long long deflate_workspace_bytes(int streams, int max_chunks);
+void launch_deflate(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
+                    int max_chunks, unsigned char *out, unsigned long long stream_stride, long long *sizes, void *workspace);
+
 // metrics.hip
 void launch_metric_prep(hipStream_t st, const float *a, const float *b, int B, long long npx, double *acc, unsigned char *ga, unsigned char *gb);
 void launch_metric_pool_grey(hipStream_t st, const unsigned char *ga, const unsigned char *gb, int B, int H, int W, int f, int hp, int wp, float *xa,

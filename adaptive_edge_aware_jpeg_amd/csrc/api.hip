@@ -1405,6 +1405,51 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
     return 0;
 }
 
+// ---- opt-in GPU entropy stage (deflate.hip) -----------------------------------------------------------------------
+static int deflate_geometry(aej_ctx *ctx, int batch, int H, int W, QtGeom &q, int &max_chunks)
+{
+    int rc = check_encode_args(ctx, batch, H, W);
+    if (rc) return rc;
+    Geom g;
+    if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
+    if ((rc = make_qtgeom(ctx, g, ctx->bmin, ctx->bmax, q))) return rc;
+    long long cap = 0;
+    for (int l = 0; l < 3; l++) cap = std::max(cap, q.coeff_cap[l]);
+    max_chunks = deflate_max_chunks(cap);
+    return 0;
+}
+
+extern "C" uint64_t aej_deflate_stream_bound(uint64_t raw_bytes) { return deflate_stream_bound(raw_bytes); }
+
+extern "C" uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, int W)
+{
+    QtGeom q;
+    int max_chunks;
+    if (deflate_geometry(ctx, batch, H, W, q, max_chunks)) return 0;
+    return deflate_workspace_bytes(batch * 3, max_chunks);
+}
+
+extern "C" int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, uint8_t *streams,
+                                 uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes)
+{
+    QtGeom q;
+    int max_chunks;
+    int rc = deflate_geometry(ctx, batch, H, W, q, max_chunks);
+    if (rc) return rc;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
+    if (!coeffs || !counts || !streams || !sizes || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    if (workspace_bytes < deflate_workspace_bytes(batch * 3, max_chunks)) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
+    if (stream_stride < 16) return fail(ctx, AEJ_ERR_CAPACITY, "stream_stride too small");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    launch_deflate(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, max_chunks, streams,
+                   stream_stride, reinterpret_cast<long long *>(sizes), workspace);
+    AEJ_HIP_CHECK(hipGetLastError());
+    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, workspace, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));      // the error word is the workspace's first
+    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "a deflate stream does not fit stream_stride = %llu bytes (aej_deflate_stream_bound gives a safe size)", (unsigned long long)stream_stride);
+    return 0;
+}
+
 // ---- evaluation metrics (evaluation_metrics.py:50-89) ------------------------------------------------------------
 struct MetricsWs {
     double *acc;

@@ -8,7 +8,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "color.hip", "canny.hip", "quadtree.hip", "dct.hip", "decode.hip", "metrics.hip"]
+SOURCES = ["api.hip", "color.hip", "canny.hip", "quadtree.hip", "dct.hip", "decode.hip", "metrics.hip", "deflate.hip"]
 HEADERS = ["aej_common.h", "aej_launch.h", "aej_devmath.h", "inv_constants.h", "pow_tables.h", "aej_mfma.h", "aej_bigblock.h", os.path.join("..", "..", "include", "aej.h")]
 LIB = os.path.join(HERE, "..", "libaejpeg_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(7, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     lib = os.path.abspath(LIB)
     if jobs or _stale(lib, objs):

@@ -1,0 +1,312 @@
+// deflate.hip -- OPT-IN GPU entropy stage for the .ajpg container: every layer's int32 coefficient array as a zlib stream
+// (RFC 1950 / 1951) that the reference's decoder reads with zlib.decompress (src/jpeg/jpeg.py:659).  The reference writes these streams
+// with zlib.compress(level=9) on the host (jpeg.py:588-590); with the hot path on the GPU that call IS Jpeg.compress end to end
+// (98 % of compress_many on natural 4K images, 1.4 MP/s per host core: profiles/r04_bench_extra_natural.json).  This stage trades
+// compression ratio for five orders of magnitude of speed and is never the default: the default container stays byte-identical to the
+// reference's.
+//
+// Format.  A stream is cut into chunks of 32 KiB of input; a chunk is ONE fixed-Huffman block (BTYPE = 01, no code tables to build or
+// to transmit) followed by an empty stored block, which pads to a byte boundary (the Z_SYNC_FLUSH marker 00 00 FF FF), so chunks are
+// compressed independently and concatenated bytewise; a final empty block and the Adler-32 close the stream.  LZ77 matches are
+// restricted to distances 1 and 4 -- the previous byte and the same byte of the previous coefficient -- which is what an array of
+// mostly-zero, small-magnitude little-endian int32 values offers: zero runs (distance 1, up to 258 bytes per 12-13-bit token), the
+// three sign / zero bytes of a small coefficient behind another small coefficient (distance 4, length 3: 12 bits).  A thread parses 256
+// input bytes greedily; matches do not cross its sub-block (deflate's longest match is 258 bytes anyway).
+#include "aej_common.h"
+#include "aej_launch.h"
+
+namespace aej {
+
+constexpr int kDefSub = 256;                      // input bytes per thread
+constexpr int kDefThreads = 128;
+constexpr int kDefChunk = kDefSub * kDefThreads;  // 32 KiB of input per workgroup
+constexpr int kDefSubStride = kDefSub + 4;        // LDS stride of a sub-block: 65 dwords, so equal offsets of different threads fall into different banks
+constexpr int kDefOutWords = (kDefChunk * 9 / 8 + 64) / 4;      // a literal costs at most 9 bits
+constexpr unsigned kAdlerMod = 65521u;
+
+struct DeflateStreams {
+    const int *coeffs;            // [B][coeff_stride]
+    const long long *counts;      // [B][3][4]: n_coeffs first
+    long long coeff_stride, coeff_off[3];
+    unsigned char *out;           // [B * 3][stream_stride]
+    unsigned long long stream_stride;
+    long long *sizes;             // [B * 3] bytes of each finished stream
+    int *chunk_bytes;             // [B * 3][max_chunks] compressed bytes per chunk, then (after the scan) its exclusive offset
+    unsigned *chunk_adler;        // [B * 3][max_chunks][2] sum of bytes, sum of (len - i) * byte, both mod 65521
+    unsigned short *sub_bits;     // [B * 3][max_chunks][kDefThreads] bits of each thread's tokens
+    int *error;                   // [1] set when a stream does not fit its slot
+    int max_chunks;
+};
+
+// fixed-Huffman code of a literal / length symbol, bit-reversed for the LSB-first stream; returns the number of bits
+__device__ __forceinline__ int fixed_code(int sym, unsigned &code)
+{
+    int n;
+    unsigned c;
+    if (sym < 144) { c = 0x30u + (unsigned)sym; n = 8; }
+    else if (sym < 256) { c = 0x190u + (unsigned)(sym - 144); n = 9; }
+    else if (sym < 280) { c = (unsigned)(sym - 256); n = 7; }
+    else { c = 0xC0u + (unsigned)(sym - 280); n = 8; }
+    code = __brev(c) >> (32 - n);
+    return n;
+}
+
+struct BitSink {
+    unsigned *words;              // LDS, zeroed
+    unsigned long long acc;
+    int nacc;
+    unsigned w;
+    __device__ __forceinline__ void start(unsigned *base, unsigned bit_off) { words = base; w = bit_off >> 5; nacc = (int)(bit_off & 31u); acc = 0; }
+    __device__ __forceinline__ void put(unsigned v, int n)
+    {
+        acc |= (unsigned long long)v << nacc;
+        nacc += n;
+        if (nacc >= 32) { atomicOr(&words[w], (unsigned)acc); acc >>= 32; nacc -= 32; w++; }
+    }
+    __device__ __forceinline__ void finish() { if (nacc > 0 && (unsigned)acc) atomicOr(&words[w], (unsigned)acc); }
+};
+
+// Greedy parse of one sub-block of n bytes at stream position gpos: at every position the longer of the runs "equal to the byte one /
+// four positions back" (clipped to the sub-block and to 258) becomes a match when it is at least 3 long, else the byte is a literal.
+// EMIT = false: returns the number of bits; EMIT = true: also writes them.  `left4` holds the four bytes before the sub-block (byte k =
+// position k - 4).
+template <bool EMIT>
+__device__ __forceinline__ int deflate_parse(const unsigned char *sub, unsigned left4, int n, long long gpos, BitSink &sink)
+{
+    auto at = [&](int i) -> unsigned { return i >= 0 ? (unsigned)sub[i] : (left4 >> (8 * (i + 4))) & 0xffu; };      // i >= -4
+    int bits = 0, p = 0;
+    while (p < n) {
+        const unsigned b = sub[p];
+        int l1 = 0, l4 = 0;
+        if (gpos + p >= 1 && b == at(p - 1)) {
+            l1 = 1;
+            while (p + l1 < n && l1 < 258 && sub[p + l1] == b) l1++;
+        }
+        if (gpos + p >= 4 && l1 < 258 && b == at(p - 4)) {
+            l4 = 1;
+            while (p + l4 < n && l4 < 258 && sub[p + l4] == at(p + l4 - 4)) l4++;
+        }
+        const int L = l1 >= l4 ? l1 : l4;
+        if (L >= 3) {
+            const int l = L - 3;
+            int sym, e = 0;
+            unsigned extra = 0;
+            if (L == 258) sym = 285;
+            else if (l < 8) sym = 257 + l;
+            else { e = 29 - __clz(l); sym = 257 + 4 * (e + 1) + ((l >> e) & 3); extra = (unsigned)l & ((1u << e) - 1u); }
+            unsigned code;
+            const int nb = fixed_code(sym, code);
+            bits += nb + e + 5;
+            if (EMIT) {
+                sink.put(code | (extra << nb), nb + e);
+                sink.put(l1 >= l4 ? 0u : (__brev(3u) >> 27), 5);      // distance 1 = code 0, distance 4 = code 3 (five bits, reversed), no extra bits
+            }
+            p += L;
+        } else {
+            unsigned code;
+            const int nb = fixed_code((int)b, code);
+            bits += nb;
+            if (EMIT) sink.put(code, nb);
+            p++;
+        }
+    }
+    return bits;
+}
+
+// stage a chunk in LDS (coalesced 16-byte loads; sub-blocks at a stride of 65 dwords) with the four bytes before it
+__device__ __forceinline__ void deflate_stage(const unsigned char *src, long long n_bytes, long long c0, int len, unsigned char *sIn /* [4 + threads * stride] */)
+{
+    const int tid = threadIdx.x;
+    if (tid < 4) sIn[tid] = c0 >= 4 ? src[c0 - 4 + tid] : 0;
+    // coefficient arrays start on 256-byte boundaries, their capacities are multiples of 64 bytes and a chunk is 32 KiB: 16-byte loads are
+    // aligned and stay inside the layer's slot; what they bring beyond `len` is never looked at
+    for (int i = tid * 16; i < kDefChunk; i += kDefThreads * 16) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < len) v = *reinterpret_cast<const uint4 *>(src + c0 + i);
+        unsigned *dst = reinterpret_cast<unsigned *>(sIn + 4 + (i >> 8) * kDefSubStride + (i & 255));
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+
+// the four bytes before a thread's sub-block: the chunk's halo (sIn[0..3]) for thread 0, else the tail of the sub-block before it, which
+// ends four bytes short of this one (stride 260)
+__device__ __forceinline__ unsigned deflate_left4(const unsigned char *sIn, const unsigned char *sub, int tid)
+{
+    const unsigned char *q = tid == 0 ? sIn : sub - 8;
+    return (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
+}
+
+__device__ __forceinline__ const unsigned char *stream_of(const DeflateStreams &S, int s, long long &n_bytes)
+{
+    const int b = s / 3, l = s - 3 * b;
+    n_bytes = 4 * S.counts[(long long)s * 4];
+    return reinterpret_cast<const unsigned char *>(S.coeffs + (long long)b * S.coeff_stride + S.coeff_off[l]);
+}
+
+// Pass 1: bits per sub-block, compressed bytes and Adler-32 partial sums per chunk.
+__global__ __launch_bounds__(kDefThreads) void k_deflate_sizes(DeflateStreams S)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sIn[4 + kDefThreads * kDefSubStride + 12];
+    __shared__ unsigned sRed[3][kDefThreads / 64];
+    const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    long long n_bytes;
+    const unsigned char *src = stream_of(S, s, n_bytes);
+    const long long c0 = (long long)c * kDefChunk;
+    const long long slot = (long long)s * S.max_chunks + c;
+    if (c0 >= n_bytes) { if (tid == 0) S.chunk_bytes[slot] = 0; return; }
+    const int len = (int)(n_bytes - c0 < kDefChunk ? n_bytes - c0 : kDefChunk);
+    deflate_stage(src, n_bytes, c0, len, sIn);
+    __syncthreads();
+    const int n = min(kDefSub, len - tid * kDefSub);
+    const unsigned char *sub = sIn + 4 + tid * kDefSubStride;
+    BitSink none;
+    int bits = 0;
+    unsigned a = 0, m = 0;
+    if (n > 0) {
+        bits = deflate_parse<false>(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, none);
+        for (int j = 0; j < n; j++) { a += sub[j]; m += (unsigned)j * sub[j]; }
+    }
+    S.sub_bits[slot * kDefThreads + tid] = (unsigned short)bits;
+    // chunk totals: bits, sum of bytes, sum of (len - i) * byte = sum_t [(len - o_t) * a_t - m_t]
+    unsigned long long w = n > 0 ? (unsigned long long)(len - tid * kDefSub) * a - m : 0ull;
+    unsigned vb = (unsigned)bits, va = a, vw = (unsigned)(w % kAdlerMod);
+    for (int o = 32; o > 0; o >>= 1) { vb += __shfl_down(vb, o); va += __shfl_down(va, o); vw += __shfl_down(vw, o); }
+    if ((tid & 63) == 0) { sRed[0][tid >> 6] = vb; sRed[1][tid >> 6] = va; sRed[2][tid >> 6] = vw; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned tb = 0, ta = 0, tw = 0;
+        for (int k = 0; k < kDefThreads / 64; k++) { tb += sRed[0][k]; ta += sRed[1][k]; tw += sRed[2][k]; }
+        const unsigned total_bits = 3u + tb + 7u + 3u;             // block header, tokens, end of block, header of the empty stored block
+        S.chunk_bytes[slot] = (int)((total_bits + 7u) / 8u) + 4;    // ... padded to a byte, LEN = 0000, NLEN = FFFF
+        S.chunk_adler[slot * 2] = ta % kAdlerMod;
+        S.chunk_adler[slot * 2 + 1] = tw % kAdlerMod;
+    }
+}
+
+// Pass 2 (one workgroup per stream): offsets of the chunks, the stream's size, its zlib header, final block and Adler-32.
+__global__ __launch_bounds__(256) void k_deflate_scan(DeflateStreams S)
+{
+    __shared__ long long sCarry;
+    __shared__ int sWave[4];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    long long n_bytes;
+    (void)stream_of(S, s, n_bytes);
+    const int nchunks = (int)((n_bytes + kDefChunk - 1) / kDefChunk);
+    int *cb = S.chunk_bytes + (long long)s * S.max_chunks;
+    if (tid == 0) sCarry = 2;                       // the two header bytes
+    __syncthreads();
+    for (int base = 0; base < nchunks; base += 256) {
+        const int i = base + tid;
+        const int v = i < nchunks ? cb[i] : 0;
+        int inc = v;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) sWave[tid >> 6] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int k = 0; k < (tid >> 6); k++) wbase += sWave[k];
+        const long long carry = sCarry;
+        if (i < nchunks) cb[i] = (int)(carry + wbase + inc - v);      // exclusive offset inside the stream (streams are < 2 GiB)
+        __syncthreads();
+        if (tid == 255) sCarry = carry + wbase + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const long long body_end = sCarry;
+        const long long total = body_end + 2 + 4;
+        S.sizes[s] = total;
+        if ((unsigned long long)total > S.stream_stride) { *S.error = 1; return; }
+        unsigned char *out = S.out + (unsigned long long)s * S.stream_stride;
+        out[0] = 0x78; out[1] = 0x01;                // CMF: deflate, 32 KiB window; FLG: check bits, fastest level
+        out[body_end] = 0x03; out[body_end + 1] = 0x00;      // final block: BFINAL = 1, fixed Huffman, end of block
+        unsigned A = 1, B = 0;
+        const unsigned *ad = S.chunk_adler + (long long)s * S.max_chunks * 2;
+        for (int i = 0; i < nchunks; i++) {
+            const long long len = (long long)(i + 1) * kDefChunk <= n_bytes ? kDefChunk : n_bytes - (long long)i * kDefChunk;
+            B = (unsigned)((B + (unsigned long long)(len % kAdlerMod) * A + ad[2 * i + 1]) % kAdlerMod);
+            A = (A + ad[2 * i]) % kAdlerMod;
+        }
+        const unsigned adler = (B << 16) | A;
+        out[body_end + 2] = (unsigned char)(adler >> 24); out[body_end + 3] = (unsigned char)(adler >> 16);
+        out[body_end + 4] = (unsigned char)(adler >> 8);  out[body_end + 5] = (unsigned char)adler;
+    }
+}
+
+// Pass 3: the chunks' bit strings, assembled in LDS and copied to their place in the stream.
+__global__ __launch_bounds__(kDefThreads) void k_deflate_emit(DeflateStreams S)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sIn[4 + kDefThreads * kDefSubStride + 12];
+    __shared__ unsigned sOut[kDefOutWords];
+    __shared__ unsigned sWaveBits[kDefThreads / 64];
+    const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    long long n_bytes;
+    const unsigned char *src = stream_of(S, s, n_bytes);
+    const long long c0 = (long long)c * kDefChunk;
+    if (c0 >= n_bytes || *S.error) return;
+    const long long slot = (long long)s * S.max_chunks + c;
+    const int len = (int)(n_bytes - c0 < kDefChunk ? n_bytes - c0 : kDefChunk);
+    deflate_stage(src, n_bytes, c0, len, sIn);
+    for (int i = tid; i < kDefOutWords; i += kDefThreads) sOut[i] = 0u;
+    // bit offset of this thread's tokens: 3 header bits + the bits of the threads before it
+    const unsigned mine = S.sub_bits[slot * kDefThreads + tid];
+    unsigned inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) sWaveBits[tid >> 6] = inc;
+    __syncthreads();
+    unsigned off = 3u + inc - mine;
+    for (int k = 0; k < (tid >> 6); k++) off += sWaveBits[k];
+    const int n = min(kDefSub, len - tid * kDefSub);
+    if (n > 0) {
+        const unsigned char *sub = sIn + 4 + tid * kDefSubStride;
+        BitSink sink;
+        sink.start(sOut, tid == 0 ? 0u : off);
+        if (tid == 0) sink.put(2u, 3);              // BFINAL = 0, BTYPE = 01 (fixed Huffman)
+        (void)deflate_parse<true>(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, sink);
+        sink.finish();
+    }
+    __syncthreads();
+    // end of block (seven zero bits) and the empty stored block's header (three zero bits) are already there; pad, then 00 00 FF FF
+    unsigned total = 0;
+    for (int k = 0; k < kDefThreads / 64; k++) total += sWaveBits[k];
+    const unsigned body = (3u + total + 7u + 3u + 7u) / 8u;
+    unsigned char *ob = reinterpret_cast<unsigned char *>(sOut);
+    if (tid == 0) { ob[body + 2] = 0xFF; ob[body + 3] = 0xFF; }
+    __syncthreads();
+    const unsigned nout = body + 4u;
+    unsigned char *dst = S.out + (unsigned long long)s * S.stream_stride + S.chunk_bytes[slot];
+    for (unsigned i = tid; i < nout; i += kDefThreads) dst[i] = ob[i];
+}
+
+unsigned long long deflate_stream_bound(unsigned long long raw_bytes)
+{
+    const unsigned long long chunks = (raw_bytes + kDefChunk - 1) / kDefChunk;
+    return 2 + raw_bytes + raw_bytes / 8 + chunks * 8 + 16;
+}
+
+int deflate_max_chunks(long long max_coeffs) { return (int)((4 * max_coeffs + kDefChunk - 1) / kDefChunk); }
+
+unsigned long long deflate_workspace_bytes(int streams, int max_chunks)
+{
+    const unsigned long long n = (unsigned long long)streams * max_chunks;
+    return ((n * sizeof(int) + 255) & ~255ull) + ((n * 2 * sizeof(unsigned) + 255) & ~255ull) + ((n * kDefThreads * sizeof(unsigned short) + 255) & ~255ull) + 256;
+}
+
+void launch_deflate(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
+                    int max_chunks, unsigned char *out, unsigned long long stream_stride, long long *sizes, void *workspace)
+{
+    DeflateStreams S;
+    S.coeffs = coeffs; S.counts = counts; S.coeff_stride = coeff_stride;
+    for (int l = 0; l < 3; l++) S.coeff_off[l] = coeff_off[l];
+    S.out = out; S.stream_stride = stream_stride; S.sizes = sizes; S.max_chunks = max_chunks;
+    const unsigned long long n = (unsigned long long)batch * 3 * max_chunks;
+    char *w = static_cast<char *>(workspace);
+    S.error = reinterpret_cast<int *>(w); w += 256;
+    S.chunk_bytes = reinterpret_cast<int *>(w); w += (n * sizeof(int) + 255) & ~255ull;
+    S.chunk_adler = reinterpret_cast<unsigned *>(w); w += (n * 2 * sizeof(unsigned) + 255) & ~255ull;
+    S.sub_bits = reinterpret_cast<unsigned short *>(w);
+    (void)hipMemsetAsync(S.error, 0, 256, st);
+    if (max_chunks > 0) hipLaunchKernelGGL(k_deflate_sizes, dim3(max_chunks, batch * 3), dim3(kDefThreads), 0, st, S);
+    hipLaunchKernelGGL(k_deflate_scan, dim3(batch * 3), dim3(256), 0, st, S);
+    if (max_chunks > 0) hipLaunchKernelGGL(k_deflate_emit, dim3(max_chunks, batch * 3), dim3(kDefThreads), 0, st, S);
+}
+
+}  // namespace aej

@@ -238,7 +238,7 @@ class Jpeg:
         return len(mb).to_bytes(4, byteorder="big") + mb
 
     @staticmethod
-    def _layer_bytes(L, zlib_level: int = 9) -> bytes:
+    def _layer_bytes(L, zlib_level: int = 9, stream: Optional[bytes] = None) -> bytes:
         """One layer record of the container (jpeg.py:561-595): state bits, root size, zlib-9 of the int32 coefficients
         (``zlib_level`` other than the reference's 9 is an opt-in: any level gives a stream the reference's ``zlib.decompress`` reads)."""
         st = L["states"]
@@ -246,14 +246,40 @@ class Jpeg:
         pad = (-len(st)) % 4
         quad = np.concatenate([st, np.zeros(pad, np.uint8)]).reshape(-1, 4)
         packed = ((quad[:, 0] << 6) | (quad[:, 1] << 4) | (quad[:, 2] << 2) | quad[:, 3]).astype(np.uint8)
-        comp = zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=zlib_level)
+        comp = stream if stream is not None else zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=zlib_level)
         return b"".join((bits_len.to_bytes(4, byteorder="big"), int(L["root_size"]).to_bytes(4, byteorder="big"), packed.tobytes(),
                          len(comp).to_bytes(4, byteorder="big"), comp))
 
     def _entropy_encode(self, layers) -> bytes:
         return self._header_bytes(len(layers)) + b"".join(self._layer_bytes(L) for L in layers)
 
-    def compress_many(self, batch, extension: Optional[str] = None, workers: Optional[int] = None, zlib_level: int = 9) -> List[bytes]:
+    def deflate_batch(self, enc: EncodedBatch) -> List[List[bytes]]:
+        """OPT-IN GPU entropy stage (``aej_deflate_batch``, csrc/deflate.hip): the zlib stream of every layer of an encoded batch, written
+        on the GPU -- fixed-Huffman deflate with matches at distances 1 and 4, which ``zlib.decompress`` (the reference's decoder,
+        jpeg.py:659) reads like any other stream.  Only the compressed bytes cross to the host.  -> [image][layer] bytes."""
+        ctx = self._bind()
+        t = ctx.torch
+        p = enc.plan
+        cap = max((p.coeff_off[l + 1] if l < 2 else p.coeff_stride) - p.coeff_off[l] for l in range(3))
+        stride = int(ctx.lib.aej_deflate_stream_bound(ctypes.c_uint64(4 * cap)))
+        stride = (stride + 255) // 256 * 256
+        n = p.batch * 3
+        streams = ctx.empty((n, stride), t.uint8)
+        sizes = ctx.empty((n,), t.int64)
+        nbytes = int(ctx.lib.aej_deflate_workspace_bytes(ctx.handle, p.batch, p.H, p.W))
+        ws = ctx.workspace(nbytes)
+        ctx.check(ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W, streams.data_ptr(),
+                                            ctypes.c_uint64(stride), sizes.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes)))
+        sz = sizes.cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(sz)])
+        packed = ctx.empty((int(off[-1]),), t.uint8)              # compacted on the device: one device-to-host copy of the compressed bytes
+        for i in range(n):
+            packed[int(off[i]):int(off[i + 1])] = streams[i, :int(sz[i])]
+        host = packed.cpu().numpy()
+        return [[host[int(off[3 * b + l]):int(off[3 * b + l + 1])].tobytes() for l in range(3)] for b in range(p.batch)]
+
+    def compress_many(self, batch, extension: Optional[str] = None, workers: Optional[int] = None, zlib_level: int = 9,
+                      entropy: str = "host") -> List[bytes]:
         """``compress`` for a batch: one GPU pass (``compress_batch``), then the container of every image with the
         per-layer zlib-9 streams -- the part of ``compress`` that dominates end to end -- deflated on a thread pool (zlib
         releases the GIL).  Each element equals ``compress(Image(batch[i]))`` byte for byte.
@@ -261,13 +287,29 @@ class Jpeg:
         ``zlib_level`` is an opt-in for throughput: with the hot path on the GPU, level 9 deflate of the int32 coefficients IS the
         call (98 % of it on natural 4K images: 1.4 MP/s per host core against 80 000 MP/s for everything before it,
         profiles/r04_bench_extra*.json); a lower level writes a larger container that ``Jpeg.decompress`` -- the reference's included,
-        jpeg.py:659 -- reads unchanged.  The default stays 9, the reference's (jpeg.py:590), so the bytes stay the reference's."""
+        jpeg.py:659 -- reads unchanged.  ``entropy="gpu"`` goes further: the streams are written on the GPU (``deflate_batch``) and only
+        compressed bytes cross to the host.  The default stays host zlib level 9, the reference's (jpeg.py:590), so the bytes stay the
+        reference's."""
         from concurrent.futures import ThreadPoolExecutor
         enc = self.compress_batch(batch)
         p = enc.plan
         self.update_layer_shapes((p.H, p.W))
         self.extension = extension
         header = self._header_bytes(3)
+        if entropy == "gpu":
+            streams = self.deflate_batch(enc)
+            cnt = enc.counts_host
+            out = []
+            for b in range(p.batch):
+                recs = []
+                for l in range(3):
+                    so = b * p.state_stride + p.state_off[l]
+                    st = enc.states[so:so + int(cnt[b, l, 2])].cpu().numpy()
+                    recs.append(self._layer_bytes({"states": st, "root_size": int(cnt[b, l, 3])}, stream=streams[b][l]))
+                out.append(header + b"".join(recs))
+            return out
+        if entropy != "host":
+            raise ValueError("entropy must be 'host' or 'gpu'")
         jobs = [(b, l) for b in range(p.batch) for l in range(3)]
         with ThreadPoolExecutor(max_workers=workers or min(32, os.cpu_count() or 1)) as ex:
             recs = list(ex.map(lambda bl: self._layer_bytes(enc.layer(bl[0], bl[1]), zlib_level), jobs))

@@ -525,3 +525,40 @@ def test_unsupported_inputs_fail_loudly(A):
         A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (2, 512))).compress_batch(np.zeros((1, 64, 64, 3), np.float32))     # more than 8 sizes
     with pytest.raises(ValueError):
         codec.compress_batch(np.zeros((64, 64, 3), np.float32))
+
+
+# ------------------------------------------------------------------ opt-in GPU entropy stage (csrc/deflate.hip)
+def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
+    """aej_deflate_batch: every layer's stream must be a conforming zlib stream -- `zlib.decompress`, the call the reference's decoder
+    makes (jpeg.py:659), returns exactly the layer's int32 coefficients -- for smooth, noisy, natural and ragged images, a batch, and
+    sizes that leave partial 32 KiB chunks and partial 256-byte sub-blocks; the container built from them decodes to the same image as
+    the default (host zlib-9) container, with our decoder AND with the oracle's restatement of the reference's."""
+    import zlib
+    from conftest import golden_image
+    rng = np.random.default_rng(5)
+    cases = [("YCbCr", (40, 80), (4, 64), np.stack([synth(oracle, 200, 328, 3), synth(oracle, 200, 328, 4)])),
+             ("YCoCg", (5, 95), (2, 32), rng.random((1, 123, 77, 3), dtype=np.float32)),                      # noise: few zeros, many literals >= 144
+             ("YCbCr", (40, 80), (4, 64), golden_image("natural/baboon")[None]),
+             ("OKLAB", (40, 80), (8, 128), np.full((1, 256, 256, 3), 0.5, np.float32)),                          # flat: one long zero run per layer
+             ("YCbCr", (90, 99), (4, 4), golden_image("natural/peppers")[None, :300, :420])]
+    for space, qr, br, batch in cases:
+        codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
+        enc = codec.compress_batch(batch)
+        streams = codec.deflate_batch(enc)
+        for b in range(batch.shape[0]):
+            for l in range(3):
+                raw = enc.layer(b, l)["coeffs"].tobytes()
+                assert streams[b][l][:2] == b"\x78\x01"
+                assert zlib.decompress(streams[b][l]) == raw, f"{space} image {b} layer {l}: {len(raw)} bytes"
+        blobs_gpu = codec.compress_many(batch, extension=".png", entropy="gpu")
+        blobs_ref = codec.compress_many(batch, extension=".png")
+        for b in range(batch.shape[0]):
+            got = A.Jpeg(A.JpegCompressionSettings()).decompress(blobs_gpu[b]).data
+            want = A.Jpeg(A.JpegCompressionSettings()).decompress(blobs_ref[b]).data
+            assert np.array_equal(got, want)
+            assert np.array_equal(oracle.decode_image(blobs_gpu[b]), oracle.decode_image(blobs_ref[b]), equal_nan=True)
+    # an empty layer cannot occur in the codec, but the stream format must still close: one image of the smallest shape the settings allow
+    tiny = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (2, 2)))
+    enc = tiny.compress_batch(np.full((1, 4, 4, 3), 0.25, np.float32))
+    for l in range(3):
+        assert zlib.decompress(tiny.deflate_batch(enc)[0][l]) == enc.layer(0, l)["coeffs"].tobytes()
