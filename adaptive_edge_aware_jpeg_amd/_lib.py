@@ -153,7 +153,8 @@ SIGNATURES = {
     "aej_dct_quant_zigzag": (_I, [_P, _P, _I, _I, _I, _P, _I64, _P, _P]),
     "aej_deflate_stream_bound": (_U64, [_U64]),
     "aej_deflate_workspace_bytes": (_U64, [_P, _I, _I, _I]),
-    "aej_deflate_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _U64, _P, _P, _U64]),
+    "aej_deflate_histogram": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "aej_deflate_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _U64, _P, _P, _U64]),
     "aej_decode_workspace_bytes": (_U64, [_P, _I, _I, _I]),
     "aej_decode_batch": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _U64]),
     "aej_color_convert_inverse": (_I, [_P, _I, _P, _P, _I64]),

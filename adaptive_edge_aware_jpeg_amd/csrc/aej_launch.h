@@ -124,8 +124,11 @@ int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float 
 unsigned long long deflate_stream_bound(unsigned long long raw_bytes);
 int deflate_max_chunks(long long max_coeffs);
 unsigned long long deflate_workspace_bytes(int streams, int max_chunks);
+void launch_deflate_hist(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
+                         int max_chunks, int *hist /* [3][288] */);
 void launch_deflate(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
-                    int max_chunks, unsigned char *out, unsigned long long stream_stride, long long *sizes, void *workspace);
+                    int max_chunks, const unsigned *tables /* [3][385] or null */, unsigned char *out, unsigned long long stream_stride, long long *sizes,
+                    void *workspace);
 
 // metrics.hip
 void launch_metric_prep(hipStream_t st, const float *a, const float *b, int B, long long npx, double *acc, unsigned char *ga, unsigned char *gb);

@@ -1429,8 +1429,22 @@ extern "C" uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, 
     return deflate_workspace_bytes(batch * 3, max_chunks);
 }
 
-extern "C" int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, uint8_t *streams,
-                                 uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes)
+extern "C" int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, int32_t *hist)
+{
+    QtGeom q;
+    int max_chunks;
+    int rc = deflate_geometry(ctx, batch, H, W, q, max_chunks);
+    if (rc) return rc;
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
+    if (!coeffs || !counts || !hist) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    launch_deflate_hist(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, max_chunks, hist);
+    AEJ_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables,
+                                 uint8_t *streams, uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes)
 {
     QtGeom q;
     int max_chunks;
@@ -1441,7 +1455,7 @@ extern "C" int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int6
     if (workspace_bytes < deflate_workspace_bytes(batch * 3, max_chunks)) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
     if (stream_stride < 16) return fail(ctx, AEJ_ERR_CAPACITY, "stream_stride too small");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
-    launch_deflate(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, max_chunks, streams,
+    launch_deflate(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, max_chunks, tables, streams,
                    stream_stride, reinterpret_cast<long long *>(sizes), workspace);
     AEJ_HIP_CHECK(hipGetLastError());
     AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, workspace, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));      // the error word is the workspace's first

@@ -1449,7 +1449,8 @@ __global__ __launch_bounds__(256) void k_hyst_bulk(Geom g, CannyBuffers cb, long
 #endif
 __global__ __launch_bounds__(256) void k_hyst_drain(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int parity, int ring_mask)
 {
-    constexpr int K = AEJ_X_HYST_CHUNK;
+    // tickets per claim: latency-sized problems (a few images) have a short queue and plenty of waves: one entry per wave at a time
+    const int K = total_tiles <= 8192 ? 1 : AEJ_X_HYST_CHUNK;
     const int lane = threadIdx.x & 63;
     const HystOut q = hyst_out(cb, parity, true, total_tiles, ring_mask);
     int *head = cb.pass_count + kQHead, *done_p = cb.pass_count + kQDone;
@@ -1655,8 +1656,8 @@ void launch_hysteresis(hipStream_t st, const Geom &g, const CannyBuffers &cb)
         if (k == nbulk) hipLaunchKernelGGL(k_hyst_bulk<true>, dim3(bulk_blocks), dim3(256), 0, st, g, cb, t, total, k, ring_mask);
         else hipLaunchKernelGGL(k_hyst_bulk<false>, dim3(bulk_blocks), dim3(256), 0, st, g, cb, t, total, k, ring_mask);
     }
-    // consumers of the queue: a wave per 16 tiles, at most 4 x AEJ_X_HYST_DRAIN_WGS waves
-    long long drain = (total + 63) / 64;
+    // consumers of the queue: a wave per 16 tiles (per 4 for latency-sized problems), at most 4 x AEJ_X_HYST_DRAIN_WGS waves
+    long long drain = total <= 8192 ? (total + 15) / 16 : (total + 63) / 64;
     if (drain > AEJ_X_HYST_DRAIN_WGS) drain = AEJ_X_HYST_DRAIN_WGS;
     hipLaunchKernelGGL(k_hyst_drain, dim3((unsigned)drain), dim3(256), 0, st, g, cb, t, total, nbulk & 1, ring_mask);
 }

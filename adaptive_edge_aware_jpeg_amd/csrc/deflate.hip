@@ -5,15 +5,19 @@
 // compression ratio for five orders of magnitude of speed and is never the default: the default container stays byte-identical to the
 // reference's.
 //
-// Format.  A stream is cut into chunks of 32 KiB of input; a chunk is ONE fixed-Huffman block (BTYPE = 01, no code tables to build or
-// to transmit) followed by an empty stored block, which pads to a byte boundary (the Z_SYNC_FLUSH marker 00 00 FF FF), so chunks are
-// compressed independently and concatenated bytewise; a final empty block and the Adler-32 close the stream.  LZ77 matches are
+// Format.  A stream is cut into chunks of 32 KiB of input; a chunk is ONE Huffman block followed by an empty stored block, which pads to
+// a byte boundary (the Z_SYNC_FLUSH marker 00 00 FF FF), so chunks are compressed independently and concatenated bytewise; a final empty
+// block and the Adler-32 close the stream.  The block is coded with the smaller of two codes: RFC 1951's fixed code (BTYPE = 01), or a
+// dynamic code (BTYPE = 10) that the HOST builds once per layer of a batch from the symbol histogram k_deflate_hist counts
+// (adaptive_edge_aware_jpeg_amd/deflate_tables.py: length-limited Huffman, block header) -- the kernels are table-driven and never build
+// a tree.  Without a table every block is fixed-Huffman.  LZ77 matches are
 // restricted to distances 1 and 4 -- the previous byte and the same byte of the previous coefficient -- which is what an array of
 // mostly-zero, small-magnitude little-endian int32 values offers: zero runs (distance 1, up to 258 bytes per 12-13-bit token), the
 // three sign / zero bytes of a small coefficient behind another small coefficient (distance 4, length 3: 12 bits).  A thread parses 256
 // input bytes greedily; matches do not cross its sub-block (deflate's longest match is 258 bytes anyway).
 #include "aej_common.h"
 #include "aej_launch.h"
+#include <string.h>
 
 namespace aej {
 
@@ -21,8 +25,10 @@ constexpr int kDefSub = 256;                      // input bytes per thread
 constexpr int kDefThreads = 128;
 constexpr int kDefChunk = kDefSub * kDefThreads;  // 32 KiB of input per workgroup
 constexpr int kDefSubStride = kDefSub + 4;        // LDS stride of a sub-block: 65 dwords, so equal offsets of different threads fall into different banks
-constexpr int kDefOutWords = (kDefChunk * 9 / 8 + 64) / 4;      // a literal costs at most 9 bits
+constexpr int kDefOutWords = (kDefChunk * 9 / 8 + 64) / 4;      // fixed code: a literal costs at most 9 bits; a block whose dynamic code needs more falls back to it
 constexpr unsigned kAdlerMod = 65521u;
+constexpr int kDefTableWords = 385;               // AEJ_DEFLATE_TABLE_WORDS: 286 literal / length codes, 2 distance codes, header bit count, 96 header words
+constexpr int kDefHistBins = 288;                 // 286 literal / length symbols, then the matches at distance 1 and at distance 4
 
 struct DeflateStreams {
     const int *coeffs;            // [B][coeff_stride]
@@ -33,7 +39,10 @@ struct DeflateStreams {
     long long *sizes;             // [B * 3] bytes of each finished stream
     int *chunk_bytes;             // [B * 3][max_chunks] compressed bytes per chunk, then (after the scan) its exclusive offset
     unsigned *chunk_adler;        // [B * 3][max_chunks][2] sum of bytes, sum of (len - i) * byte, both mod 65521
-    unsigned short *sub_bits;     // [B * 3][max_chunks][kDefThreads] bits of each thread's tokens
+    unsigned short *sub_bits;     // [B * 3][max_chunks][kDefThreads] bits of each thread's tokens under the code the chunk uses
+    unsigned char *chunk_fixed;   // [B * 3][max_chunks] 1 = the chunk's block uses the fixed code
+    const unsigned *tables;       // [3][kDefTableWords] per-layer dynamic codes (deflate_tables.py), or null: fixed code everywhere
+    int *hist;                    // [3][kDefHistBins] (k_deflate_hist only)
     int *error;                   // [1] set when a stream does not fit its slot
     int max_chunks;
 };
@@ -68,13 +77,13 @@ struct BitSink {
 
 // Greedy parse of one sub-block of n bytes at stream position gpos: at every position the longer of the runs "equal to the byte one /
 // four positions back" (clipped to the sub-block and to 258) becomes a match when it is at least 3 long, else the byte is a literal.
-// EMIT = false: returns the number of bits; EMIT = true: also writes them.  `left4` holds the four bytes before the sub-block (byte k =
-// position k - 4).
-template <bool EMIT>
-__device__ __forceinline__ int deflate_parse(const unsigned char *sub, unsigned left4, int n, long long gpos, BitSink &sink)
+// `left4` holds the four bytes before the sub-block (byte k = position k - 4).  What happens to a token is the visitor's business:
+//   lit(byte)   /   match(length symbol, extra value, extra bits, distance-is-4)
+template <typename V>
+__device__ __forceinline__ void deflate_parse(const unsigned char *sub, unsigned left4, int n, long long gpos, V &&visit)
 {
     auto at = [&](int i) -> unsigned { return i >= 0 ? (unsigned)sub[i] : (left4 >> (8 * (i + 4))) & 0xffu; };      // i >= -4
-    int bits = 0, p = 0;
+    int p = 0;
     while (p < n) {
         const unsigned b = sub[p];
         int l1 = 0, l4 = 0;
@@ -94,24 +103,47 @@ __device__ __forceinline__ int deflate_parse(const unsigned char *sub, unsigned 
             if (L == 258) sym = 285;
             else if (l < 8) sym = 257 + l;
             else { e = 29 - __clz(l); sym = 257 + 4 * (e + 1) + ((l >> e) & 3); extra = (unsigned)l & ((1u << e) - 1u); }
-            unsigned code;
-            const int nb = fixed_code(sym, code);
-            bits += nb + e + 5;
-            if (EMIT) {
-                sink.put(code | (extra << nb), nb + e);
-                sink.put(l1 >= l4 ? 0u : (__brev(3u) >> 27), 5);      // distance 1 = code 0, distance 4 = code 3 (five bits, reversed), no extra bits
-            }
+            visit.match(sym, extra, e, l4 > l1);
             p += L;
         } else {
-            unsigned code;
-            const int nb = fixed_code((int)b, code);
-            bits += nb;
-            if (EMIT) sink.put(code, nb);
+            visit.lit((int)b);
             p++;
         }
     }
-    return bits;
 }
+
+// a code as the kernels use it: the code's bits reversed (the stream is LSB first) | number of bits << 16
+__device__ __forceinline__ unsigned fixed_entry(int sym) { unsigned c; const int n = fixed_code(sym, c); return c | ((unsigned)n << 16); }
+__device__ __forceinline__ unsigned fixed_dist_entry(bool four) { return (four ? (__brev(3u) >> 27) : 0u) | (5u << 16); }
+
+struct CountBits {               // bits of the tokens under the fixed code and under the table's code
+    const unsigned *tab;         // LDS copy of the layer's table, or null
+    int fixed = 0, dyn = 0;
+    __device__ __forceinline__ void lit(int b) { fixed += (int)(fixed_entry(b) >> 16); if (tab) dyn += (int)(tab[b] >> 16); }
+    __device__ __forceinline__ void match(int sym, unsigned, int e, bool four)
+    {
+        fixed += (int)(fixed_entry(sym) >> 16) + e + 5;
+        if (tab) dyn += (int)(tab[sym] >> 16) + e + (int)(tab[286 + (four ? 1 : 0)] >> 16);
+    }
+};
+struct CountSymbols {            // histogram of the tokens (LDS)
+    int *hist;
+    __device__ __forceinline__ void lit(int b) { atomicAdd(&hist[b], 1); }
+    __device__ __forceinline__ void match(int sym, unsigned, int, bool four) { atomicAdd(&hist[sym], 1); atomicAdd(&hist[286 + (four ? 1 : 0)], 1); }
+};
+struct EmitBits {
+    BitSink &sink;
+    const unsigned *tab;         // null: fixed code
+    __device__ __forceinline__ void lit(int b) { const unsigned e = tab ? tab[b] : fixed_entry(b); sink.put(e & 0xffffu, (int)(e >> 16)); }
+    __device__ __forceinline__ void match(int sym, unsigned extra, int ne, bool four)
+    {
+        const unsigned e = tab ? tab[sym] : fixed_entry(sym);
+        const int nb = (int)(e >> 16);
+        sink.put((e & 0xffffu) | (extra << nb), nb + ne);
+        const unsigned d = tab ? tab[286 + (four ? 1 : 0)] : fixed_dist_entry(four);
+        sink.put(d & 0xffffu, (int)(d >> 16));
+    }
+};
 
 // stage a chunk in LDS (coalesced 16-byte loads; sub-blocks at a stride of 65 dwords) with the four bytes before it
 __device__ __forceinline__ void deflate_stage(const unsigned char *src, long long n_bytes, long long c0, int len, unsigned char *sIn /* [4 + threads * stride] */)
@@ -143,11 +175,46 @@ __device__ __forceinline__ const unsigned char *stream_of(const DeflateStreams &
     return reinterpret_cast<const unsigned char *>(S.coeffs + (long long)b * S.coeff_stride + S.coeff_off[l]);
 }
 
-// Pass 1: bits per sub-block, compressed bytes and Adler-32 partial sums per chunk.
+// Pass 0 (only when dynamic codes are wanted): how often every symbol occurs, per layer.
+__global__ __launch_bounds__(kDefThreads) void k_deflate_hist(DeflateStreams S)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sIn[4 + kDefThreads * kDefSubStride + 12];
+    __shared__ int sHist[kDefHistBins];
+    const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    long long n_bytes;
+    const unsigned char *src = stream_of(S, s, n_bytes);
+    const long long c0 = (long long)c * kDefChunk;
+    if (c0 >= n_bytes) return;
+    const int len = (int)(n_bytes - c0 < kDefChunk ? n_bytes - c0 : kDefChunk);
+    deflate_stage(src, n_bytes, c0, len, sIn);
+    for (int i = tid; i < kDefHistBins; i += kDefThreads) sHist[i] = 0;
+    __syncthreads();
+    const int n = min(kDefSub, len - tid * kDefSub);
+    if (n > 0) {
+        const unsigned char *sub = sIn + 4 + tid * kDefSubStride;
+        CountSymbols v{ sHist };
+        deflate_parse(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, v);
+    }
+    __syncthreads();
+    int *gh = S.hist + (s % 3) * kDefHistBins;
+    for (int i = tid; i < kDefHistBins; i += kDefThreads) if (sHist[i]) atomicAdd(&gh[i], sHist[i]);
+}
+
+__device__ __forceinline__ const unsigned *deflate_load_table(const DeflateStreams &S, int s, unsigned *sTab)
+{
+    if (!S.tables) return nullptr;
+    const unsigned *t = S.tables + (s % 3) * kDefTableWords;
+    for (int i = threadIdx.x; i < kDefTableWords; i += kDefThreads) sTab[i] = t[i];
+    return sTab;
+}
+
+// Pass 1: bits per sub-block, which code the chunk's block uses, compressed bytes and Adler-32 partial sums per chunk.
 __global__ __launch_bounds__(kDefThreads) void k_deflate_sizes(DeflateStreams S)
 {
     __shared__ __attribute__((aligned(16))) unsigned char sIn[4 + kDefThreads * kDefSubStride + 12];
-    __shared__ unsigned sRed[3][kDefThreads / 64];
+    __shared__ unsigned sTab[kDefTableWords];
+    __shared__ unsigned sRed[4][kDefThreads / 64];
+    __shared__ int sUseFixed;
     const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
     long long n_bytes;
     const unsigned char *src = stream_of(S, s, n_bytes);
@@ -156,31 +223,40 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_sizes(DeflateStreams S)
     if (c0 >= n_bytes) { if (tid == 0) S.chunk_bytes[slot] = 0; return; }
     const int len = (int)(n_bytes - c0 < kDefChunk ? n_bytes - c0 : kDefChunk);
     deflate_stage(src, n_bytes, c0, len, sIn);
+    const unsigned *tab = deflate_load_table(S, s, sTab);
     __syncthreads();
     const int n = min(kDefSub, len - tid * kDefSub);
     const unsigned char *sub = sIn + 4 + tid * kDefSubStride;
-    BitSink none;
-    int bits = 0;
+    CountBits cnt;
+    cnt.tab = tab;
     unsigned a = 0, m = 0;
     if (n > 0) {
-        bits = deflate_parse<false>(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, none);
+        deflate_parse(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, cnt);
         for (int j = 0; j < n; j++) { a += sub[j]; m += (unsigned)j * sub[j]; }
     }
-    S.sub_bits[slot * kDefThreads + tid] = (unsigned short)bits;
-    // chunk totals: bits, sum of bytes, sum of (len - i) * byte = sum_t [(len - o_t) * a_t - m_t]
+    // the last thread also writes the end-of-block symbol
+    if (tid == kDefThreads - 1) { cnt.fixed += 7; if (tab) cnt.dyn += (int)(tab[256] >> 16); }
+    // chunk totals: bits under either code, sum of bytes, sum of (len - i) * byte = sum_t [(len - o_t) * a_t - m_t]
     unsigned long long w = n > 0 ? (unsigned long long)(len - tid * kDefSub) * a - m : 0ull;
-    unsigned vb = (unsigned)bits, va = a, vw = (unsigned)(w % kAdlerMod);
-    for (int o = 32; o > 0; o >>= 1) { vb += __shfl_down(vb, o); va += __shfl_down(va, o); vw += __shfl_down(vw, o); }
-    if ((tid & 63) == 0) { sRed[0][tid >> 6] = vb; sRed[1][tid >> 6] = va; sRed[2][tid >> 6] = vw; }
+    unsigned vf = (unsigned)cnt.fixed, vd = (unsigned)cnt.dyn, va = a, vw = (unsigned)(w % kAdlerMod);
+    for (int o = 32; o > 0; o >>= 1) { vf += __shfl_down(vf, o); vd += __shfl_down(vd, o); va += __shfl_down(va, o); vw += __shfl_down(vw, o); }
+    if ((tid & 63) == 0) { sRed[0][tid >> 6] = vf; sRed[1][tid >> 6] = vd; sRed[2][tid >> 6] = va; sRed[3][tid >> 6] = vw; }
     __syncthreads();
     if (tid == 0) {
-        unsigned tb = 0, ta = 0, tw = 0;
-        for (int k = 0; k < kDefThreads / 64; k++) { tb += sRed[0][k]; ta += sRed[1][k]; tw += sRed[2][k]; }
-        const unsigned total_bits = 3u + tb + 7u + 3u;             // block header, tokens, end of block, header of the empty stored block
-        S.chunk_bytes[slot] = (int)((total_bits + 7u) / 8u) + 4;    // ... padded to a byte, LEN = 0000, NLEN = FFFF
+        unsigned tf = 0, td = 0, ta = 0, tw = 0;
+        for (int k = 0; k < kDefThreads / 64; k++) { tf += sRed[0][k]; td += sRed[1][k]; ta += sRed[2][k]; tw += sRed[3][k]; }
+        // block header + tokens + end of block, then the header of the empty stored block; the dynamic code only when it is smaller AND the
+        // block fits the emit kernel's LDS buffer (a chunk the layer's code does not suit can cost up to 15 bits per byte)
+        const unsigned bits_fixed = 3u + tf + 3u, bits_dyn = tab ? tab[288] + td + 3u : 0xffffffffu;
+        const bool use_fixed = !tab || bits_fixed <= bits_dyn || (bits_dyn + 7u) / 8u + 4u > (unsigned)(kDefOutWords * 4);
+        sUseFixed = use_fixed ? 1 : 0;
+        S.chunk_fixed[slot] = use_fixed ? 1 : 0;
+        S.chunk_bytes[slot] = (int)(((use_fixed ? bits_fixed : bits_dyn) + 7u) / 8u) + 4;    // ... padded to a byte, LEN = 0000, NLEN = FFFF
         S.chunk_adler[slot * 2] = ta % kAdlerMod;
         S.chunk_adler[slot * 2 + 1] = tw % kAdlerMod;
     }
+    __syncthreads();
+    S.sub_bits[slot * kDefThreads + tid] = (unsigned short)(sUseFixed ? cnt.fixed : cnt.dyn);
 }
 
 // Pass 2 (one workgroup per stream): offsets of the chunks, the stream's size, its zlib header, final block and Adler-32.
@@ -236,6 +312,7 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_emit(DeflateStreams S)
 {
     __shared__ __attribute__((aligned(16))) unsigned char sIn[4 + kDefThreads * kDefSubStride + 12];
     __shared__ unsigned sOut[kDefOutWords];
+    __shared__ unsigned sTab[kDefTableWords];
     __shared__ unsigned sWaveBits[kDefThreads / 64];
     const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     long long n_bytes;
@@ -245,29 +322,36 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_emit(DeflateStreams S)
     const long long slot = (long long)s * S.max_chunks + c;
     const int len = (int)(n_bytes - c0 < kDefChunk ? n_bytes - c0 : kDefChunk);
     deflate_stage(src, n_bytes, c0, len, sIn);
+    const unsigned *tab = S.chunk_fixed[slot] ? nullptr : deflate_load_table(S, s, sTab);
     for (int i = tid; i < kDefOutWords; i += kDefThreads) sOut[i] = 0u;
-    // bit offset of this thread's tokens: 3 header bits + the bits of the threads before it
+    // bit offset of this thread's tokens: the block header + the bits of the threads before it
     const unsigned mine = S.sub_bits[slot * kDefThreads + tid];
     unsigned inc = mine;
     for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     if (lane == 63) sWaveBits[tid >> 6] = inc;
     __syncthreads();
-    unsigned off = 3u + inc - mine;
+    const unsigned hdr_bits = tab ? tab[288] : 3u;
+    unsigned off = hdr_bits + inc - mine;
     for (int k = 0; k < (tid >> 6); k++) off += sWaveBits[k];
     const int n = min(kDefSub, len - tid * kDefSub);
+    BitSink sink;
+    sink.start(sOut, tid == 0 ? 0u : off);
+    if (tid == 0) {
+        if (tab) for (unsigned w = 0; 32u * w < hdr_bits; w++) sink.put(tab[289 + w], (int)min(32u, hdr_bits - 32u * w));      // BFINAL = 0, BTYPE = 10, the code lengths
+        else sink.put(2u, 3);                                                                                                   // BFINAL = 0, BTYPE = 01
+    }
     if (n > 0) {
         const unsigned char *sub = sIn + 4 + tid * kDefSubStride;
-        BitSink sink;
-        sink.start(sOut, tid == 0 ? 0u : off);
-        if (tid == 0) sink.put(2u, 3);              // BFINAL = 0, BTYPE = 01 (fixed Huffman)
-        (void)deflate_parse<true>(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, sink);
-        sink.finish();
+        EmitBits v{ sink, tab };
+        deflate_parse(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, v);
     }
+    if (tid == kDefThreads - 1) { const unsigned e = tab ? tab[256] : fixed_entry(256); sink.put(e & 0xffffu, (int)(e >> 16)); }      // end of block
+    sink.finish();
     __syncthreads();
-    // end of block (seven zero bits) and the empty stored block's header (three zero bits) are already there; pad, then 00 00 FF FF
-    unsigned total = 0;
+    // the empty stored block's header (three zero bits) is already there; pad to a byte, then 00 00 FF FF
+    unsigned total = hdr_bits;
     for (int k = 0; k < kDefThreads / 64; k++) total += sWaveBits[k];
-    const unsigned body = (3u + total + 7u + 3u + 7u) / 8u;
+    const unsigned body = (total + 3u + 7u) / 8u;
     unsigned char *ob = reinterpret_cast<unsigned char *>(sOut);
     if (tid == 0) { ob[body + 2] = 0xFF; ob[body + 3] = 0xFF; }
     __syncthreads();
@@ -287,22 +371,43 @@ int deflate_max_chunks(long long max_coeffs) { return (int)((4 * max_coeffs + kD
 unsigned long long deflate_workspace_bytes(int streams, int max_chunks)
 {
     const unsigned long long n = (unsigned long long)streams * max_chunks;
-    return ((n * sizeof(int) + 255) & ~255ull) + ((n * 2 * sizeof(unsigned) + 255) & ~255ull) + ((n * kDefThreads * sizeof(unsigned short) + 255) & ~255ull) + 256;
+    return 256 + ((n * sizeof(int) + 255) & ~255ull) + ((n * 2 * sizeof(unsigned) + 255) & ~255ull) + ((n * kDefThreads * sizeof(unsigned short) + 255) & ~255ull) +
+           ((n + 255) & ~255ull);
+}
+
+static DeflateStreams deflate_args(const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off, int max_chunks)
+{
+    DeflateStreams S;
+    memset(&S, 0, sizeof S);
+    S.coeffs = coeffs; S.counts = counts; S.coeff_stride = coeff_stride;
+    for (int l = 0; l < 3; l++) S.coeff_off[l] = coeff_off[l];
+    S.max_chunks = max_chunks;
+    (void)batch;
+    return S;
+}
+
+void launch_deflate_hist(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
+                         int max_chunks, int *hist)
+{
+    DeflateStreams S = deflate_args(coeffs, counts, batch, coeff_stride, coeff_off, max_chunks);
+    S.hist = hist;
+    (void)hipMemsetAsync(hist, 0, 3 * kDefHistBins * sizeof(int), st);
+    if (max_chunks > 0) hipLaunchKernelGGL(k_deflate_hist, dim3(max_chunks, batch * 3), dim3(kDefThreads), 0, st, S);
 }
 
 void launch_deflate(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
-                    int max_chunks, unsigned char *out, unsigned long long stream_stride, long long *sizes, void *workspace)
+                    int max_chunks, const unsigned *tables, unsigned char *out, unsigned long long stream_stride, long long *sizes, void *workspace)
 {
-    DeflateStreams S;
-    S.coeffs = coeffs; S.counts = counts; S.coeff_stride = coeff_stride;
-    for (int l = 0; l < 3; l++) S.coeff_off[l] = coeff_off[l];
-    S.out = out; S.stream_stride = stream_stride; S.sizes = sizes; S.max_chunks = max_chunks;
+    DeflateStreams S = deflate_args(coeffs, counts, batch, coeff_stride, coeff_off, max_chunks);
+    S.tables = tables;
+    S.out = out; S.stream_stride = stream_stride; S.sizes = sizes;
     const unsigned long long n = (unsigned long long)batch * 3 * max_chunks;
     char *w = static_cast<char *>(workspace);
     S.error = reinterpret_cast<int *>(w); w += 256;
     S.chunk_bytes = reinterpret_cast<int *>(w); w += (n * sizeof(int) + 255) & ~255ull;
     S.chunk_adler = reinterpret_cast<unsigned *>(w); w += (n * 2 * sizeof(unsigned) + 255) & ~255ull;
-    S.sub_bits = reinterpret_cast<unsigned short *>(w);
+    S.sub_bits = reinterpret_cast<unsigned short *>(w); w += (n * kDefThreads * sizeof(unsigned short) + 255) & ~255ull;
+    S.chunk_fixed = reinterpret_cast<unsigned char *>(w);
     (void)hipMemsetAsync(S.error, 0, 256, st);
     if (max_chunks > 0) hipLaunchKernelGGL(k_deflate_sizes, dim3(max_chunks, batch * 3), dim3(kDefThreads), 0, st, S);
     hipLaunchKernelGGL(k_deflate_scan, dim3(batch * 3), dim3(256), 0, st, S);

@@ -253,13 +253,22 @@ class Jpeg:
     def _entropy_encode(self, layers) -> bytes:
         return self._header_bytes(len(layers)) + b"".join(self._layer_bytes(L) for L in layers)
 
-    def deflate_batch(self, enc: EncodedBatch) -> List[List[bytes]]:
+    def deflate_batch(self, enc: EncodedBatch, adaptive: bool = True) -> List[List[bytes]]:
         """OPT-IN GPU entropy stage (``aej_deflate_batch``, csrc/deflate.hip): the zlib stream of every layer of an encoded batch, written
-        on the GPU -- fixed-Huffman deflate with matches at distances 1 and 4, which ``zlib.decompress`` (the reference's decoder,
-        jpeg.py:659) reads like any other stream.  Only the compressed bytes cross to the host.  -> [image][layer] bytes."""
+        on the GPU -- Huffman-coded deflate blocks with matches at distances 1 and 4, which ``zlib.decompress`` (the reference's decoder,
+        jpeg.py:659) reads like any other stream.  ``adaptive``: one dynamic Huffman code per layer, built here on the host
+        (``deflate_tables.adaptive_table``) from the symbol histogram the GPU counts (a 3.5 KB round trip); otherwise RFC 1951's fixed code.
+        Only the compressed bytes cross to the host.  -> [image][layer] bytes."""
+        from . import deflate_tables as DT
         ctx = self._bind()
         t = ctx.torch
         p = enc.plan
+        tables = None
+        if adaptive:
+            hist = ctx.empty((3, 288), t.int32)
+            ctx.check(ctx.lib.aej_deflate_histogram(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W, hist.data_ptr()))
+            h = hist.cpu().numpy()
+            tables = ctx.to_device(np.stack([DT.adaptive_table(h[l, :286], h[l, 286:288]) for l in range(3)]).view(np.int32), t.int32)
         cap = max((p.coeff_off[l + 1] if l < 2 else p.coeff_stride) - p.coeff_off[l] for l in range(3))
         stride = int(ctx.lib.aej_deflate_stream_bound(ctypes.c_uint64(4 * cap)))
         stride = (stride + 255) // 256 * 256
@@ -268,7 +277,8 @@ class Jpeg:
         sizes = ctx.empty((n,), t.int64)
         nbytes = int(ctx.lib.aej_deflate_workspace_bytes(ctx.handle, p.batch, p.H, p.W))
         ws = ctx.workspace(nbytes)
-        ctx.check(ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W, streams.data_ptr(),
+        ctx.check(ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W,
+                                            tables.data_ptr() if tables is not None else None, streams.data_ptr(),
                                             ctypes.c_uint64(stride), sizes.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes)))
         sz = sizes.cpu().numpy()
         off = np.concatenate([[0], np.cumsum(sz)])
@@ -296,8 +306,8 @@ class Jpeg:
         self.update_layer_shapes((p.H, p.W))
         self.extension = extension
         header = self._header_bytes(3)
-        if entropy == "gpu":
-            streams = self.deflate_batch(enc)
+        if entropy in ("gpu", "gpu-fixed"):
+            streams = self.deflate_batch(enc, adaptive=entropy == "gpu")
             cnt = enc.counts_host
             out = []
             for b in range(p.batch):
@@ -309,7 +319,7 @@ class Jpeg:
                 out.append(header + b"".join(recs))
             return out
         if entropy != "host":
-            raise ValueError("entropy must be 'host' or 'gpu'")
+            raise ValueError("entropy must be 'host', 'gpu' or 'gpu-fixed'")
         jobs = [(b, l) for b in range(p.batch) for l in range(3)]
         with ThreadPoolExecutor(max_workers=workers or min(32, os.cpu_count() or 1)) as ex:
             recs = list(ex.map(lambda bl: self._layer_bytes(enc.layer(bl[0], bl[1]), zlib_level), jobs))

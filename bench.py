@@ -621,14 +621,15 @@ def main():
         ms = stage_ms.get(f"dct{sz}", 0.0)
         if ms <= 0 or n_leaves == 0:
             continue
-        e = {"ms": round(ms, 4), "GBps": round(8.0 * sz * sz * n_leaves / (ms * 1e-3) / 1e9, 1)}
+        gbps = 8.0 * sz * sz * n_leaves / (ms * 1e-3) / 1e9
+        e = {"ms": round(ms, 4), "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 3)}
         if sz >= 16:
             tf = 4.0 * sz ** 3 * n_leaves / (ms * 1e-3) / 1e12
             e.update({"TFLOPs": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 3)})
         if sz == 64:
             e["kernel"] = ("k_dct_mfma<64> (four waves per leaf): what a sub-batched / pipelined call runs, the headline path included; a call that has the "
                            "device to itself runs k_dct64_wave (one wave per leaf): 0.80-0.81 ms = 0.66 of the MFMA peak, "
-                           "profiles/r03_dct64_kernels_alone.txt, DESIGN.md 4c")
+                           "profiles/r03_dct64_kernels_alone.txt, EXPERIMENTS.md 4c")
         dct_sizes[str(sz)] = e
     out["dct_by_block_size"] = dct_sizes
     # Canny chain a-3 .. a-8 (5 B per plane pixel = float32 plane in, uint8 edge map out -> 7.5 B per image pixel)

@@ -222,16 +222,25 @@ AEJ_API int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, 
 /* ---- OPT-IN entropy stage on the GPU: every layer's coefficient array as a zlib stream ---------------------------
  * The container's per-layer streams are `zlib.compress(coeffs.tobytes(), level=9)` in the reference (jpeg.py:588-590) and are read back
  * with `zlib.decompress` (jpeg.py:659) -- which accepts ANY conforming zlib stream.  With the hot path on the GPU that host call is the
- * whole of Jpeg.compress end to end, so the library can write the streams itself: fixed-Huffman deflate blocks with matches at distances
- * 1 and 4 (zero runs, repeated sign / zero bytes of small int32 coefficients), 32 KiB of input per independent chunk.  The bytes differ
- * from zlib level 9's (and the streams are larger); the decoded coefficients are identical.  Never the default.
- * coeffs / counts: aej_encode_batch's outputs (counts is the DEVICE array).  Stream of (image b, layer l) is written at
- * streams + (3 b + l) * stream_stride, its length to sizes[3 b + l] (device int64).  aej_deflate_stream_bound(raw bytes) is always enough
- * for stream_stride; a stream that does not fit returns AEJ_ERR_CAPACITY.  The call synchronises the context's stream. */
+ * whole of Jpeg.compress end to end, so the library can write the streams itself: one Huffman block per 32 KiB of input (chunks are
+ * independent: each ends with an empty stored block, i.e. on a byte boundary), LZ77 matches at distances 1 and 4 only (zero runs, the
+ * repeated sign / zero bytes of small int32 coefficients).  A block uses RFC 1951's fixed code or -- when `tables` is given and smaller for
+ * that block -- a dynamic code per layer that the HOST builds from the symbol histogram of aej_deflate_histogram
+ * (adaptive_edge_aware_jpeg_amd/deflate_tables.py; layout of a table: that file's header).  The bytes differ from zlib level 9's (about
+ * 1.3 x larger with the dynamic codes); the decoded coefficients are identical.  Never the default.
+ * coeffs / counts: aej_encode_batch's outputs (counts is the DEVICE array).
+ * aej_deflate_histogram: hist = device [3][AEJ_DEFLATE_HIST_BINS] int32: per layer (summed over the batch) the occurrences of the 286
+ *   literal / length symbols, then of the matches at distance 1 and at distance 4; enqueued on the context's stream.
+ * aej_deflate_batch: tables = device [3][AEJ_DEFLATE_TABLE_WORDS] uint32 or NULL (fixed code everywhere).  The stream of (image b, layer l)
+ *   is written at streams + (3 b + l) * stream_stride, its length to sizes[3 b + l] (device int64).  aej_deflate_stream_bound(raw bytes) is
+ *   always enough for stream_stride; a stream that does not fit returns AEJ_ERR_CAPACITY.  The call synchronises the context's stream. */
+#define AEJ_DEFLATE_HIST_BINS 288
+#define AEJ_DEFLATE_TABLE_WORDS 385
 AEJ_API uint64_t aej_deflate_stream_bound(uint64_t raw_bytes);
 AEJ_API uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, int W);
-AEJ_API int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, uint8_t *streams,
-                              uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes);
+AEJ_API int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, int32_t *hist);
+AEJ_API int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables,
+                              uint8_t *streams, uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes);
 
 /* ---- decode path: Jpeg.decompress after the host-side entropy decode (jpeg.py:285-296) ------
  * coeffs / leaves / counts use the layout of aej_encode_batch's outputs (so an encoded batch can be decoded in

@@ -544,12 +544,22 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
     for space, qr, br, batch in cases:
         codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
         enc = codec.compress_batch(batch)
-        streams = codec.deflate_batch(enc)
-        for b in range(batch.shape[0]):
-            for l in range(3):
-                raw = enc.layer(b, l)["coeffs"].tobytes()
-                assert streams[b][l][:2] == b"\x78\x01"
-                assert zlib.decompress(streams[b][l]) == raw, f"{space} image {b} layer {l}: {len(raw)} bytes"
+        sizes = {}
+        for adaptive in (False, True):
+            streams = codec.deflate_batch(enc, adaptive=adaptive)
+            for b in range(batch.shape[0]):
+                for l in range(3):
+                    raw = enc.layer(b, l)["coeffs"].tobytes()
+                    assert streams[b][l][:2] == b"\x78\x01"
+                    assert zlib.decompress(streams[b][l]) == raw, f"{space} image {b} layer {l}: {len(raw)} bytes, adaptive={adaptive}"
+            sizes[adaptive] = sum(len(x) for im in streams for x in im)
+        # a block takes the dynamic code only where it is smaller: never larger than all-fixed, but for a table's worth of headers
+        assert sizes[True] <= sizes[False] + 64, sizes
+        # the kernels' parse, block layout and Adler-32 are restated in pure Python (deflate_tables.encode_reference): same bytes
+        from adaptive_edge_aware_jpeg_amd import deflate_tables as DT
+        raw0 = enc.layer(0, 2)["coeffs"].tobytes()
+        if len(raw0) <= 300000:
+            assert codec.deflate_batch(enc, adaptive=False)[0][2] == DT.encode_reference(raw0, DT.fixed_table())
         blobs_gpu = codec.compress_many(batch, extension=".png", entropy="gpu")
         blobs_ref = codec.compress_many(batch, extension=".png")
         for b in range(batch.shape[0]):

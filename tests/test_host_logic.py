@@ -203,3 +203,38 @@ def test_hardware_queue_policy_import_has_no_side_effect():
     assert run(opt_in) == "16 16"                                                   # explicit opt-in before torch: set and trusted
     assert run(opt_in, {"GPU_MAX_HW_QUEUES": "8"}) == "8 8"                         # never overrides the launcher
     assert run("import adaptive_edge_aware_jpeg_amd as A; A.set_hw_queues(24); print(A.hw_queues()[0])") == "24"
+
+
+def test_deflate_tables_and_reference_encoder_round_trip_through_zlib():
+    """Host side of the opt-in GPU entropy stage: the Huffman tables / dynamic-block headers built in deflate_tables.py, driven through
+    the pure-Python restatement of the kernels' parser and bit packer, must give streams `zlib.decompress` (the reference's decoder call,
+    jpeg.py:659) reads back exactly -- fixed code, adaptive code, a table counted on OTHER data, empty / tiny / incompressible inputs."""
+    import zlib
+    from adaptive_edge_aware_jpeg_amd import deflate_tables as DT
+    rng = np.random.default_rng(0)
+
+    def coeff_like(n, p_nonzero, scale):
+        v = np.zeros(n, np.int32)
+        m = rng.random(n) < p_nonzero
+        v[m] = np.round(rng.laplace(0, scale, int(m.sum()))).astype(np.int32)
+        return v.tobytes()
+    cases = {"sparse": coeff_like(20000, 0.05, 2), "dense": coeff_like(12000, 0.6, 6), "large values": coeff_like(9000, 0.3, 3000),
+             "zeros": bytes(70000), "one coefficient": b"\x01\x00\x00\x00", "empty": b"", "noise": rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()}
+    fixed = DT.fixed_table()
+    assert fixed.shape == (DT.TABLE_WORDS,) and int(fixed[288]) == 3
+    foreign = DT.adaptive_table(*DT.histogram_reference(cases["sparse"]))
+    for name, data in cases.items():
+        assert zlib.decompress(DT.encode_reference(data, fixed)) == data, name
+        own = DT.adaptive_table(*DT.histogram_reference(data))
+        assert int(own[288]) <= DT.HEADER_WORDS * 32 and all(0 < (int(e) >> 16) <= 15 for e in own[:288])
+        assert zlib.decompress(DT.encode_reference(data, own)) == data, name
+        assert zlib.decompress(DT.encode_reference(data, foreign)) == data, name + " (foreign table)"
+    # the adaptive code pays on coefficient-like data: well below the fixed code, within 1.5 x of zlib level 9
+    d = cases["dense"]
+    own = DT.adaptive_table(*DT.histogram_reference(d))
+    assert len(DT.encode_reference(d, own)) < 0.6 * len(DT.encode_reference(d, fixed))
+    assert len(DT.encode_reference(d, own)) < 1.5 * len(zlib.compress(d, 9))
+    # length-limited Huffman: Kraft equality for a skewed histogram that plain Huffman would give codes longer than 15 bits
+    skew = [2 ** i for i in range(30)]
+    ls = DT.huffman_lengths(skew, 15)
+    assert max(ls) <= 15 and sum(2.0 ** -l for l in ls) <= 1.0 + 1e-12

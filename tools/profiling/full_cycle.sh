@@ -5,8 +5,8 @@
 set -e
 case "$1" in
 a)
-  bash tools/profiling/kprof.sh r03_serial --pipeline 1 --sub-batches 1 > gpurun_out/cycle_kprof_serial.log 2>&1; echo "kprof serial done"
-  bash tools/profiling/kprof.sh r03_pipelined > gpurun_out/cycle_kprof_pipelined.log 2>&1; echo "kprof pipelined done"
+  bash tools/profiling/kprof.sh r04_serial --pipeline 1 --sub-batches 1 > gpurun_out/cycle_kprof_serial.log 2>&1; echo "kprof serial done"
+  bash tools/profiling/kprof.sh r04_pipelined > gpurun_out/cycle_kprof_pipelined.log 2>&1; echo "kprof pipelined done"
   for g in traffic valu mfma; do python3 tools/profiling/pmc.py $g > gpurun_out/cycle_pmc_$g.txt 2>&1; echo "pmc $g done"; done
   ;;
 b)
