@@ -1487,7 +1487,10 @@ int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const D
         // waits for CUs to drain and then shares them with nobody -- the pipelined 64 x 4K step is 6.70 ms with it and 6.45 ms with the
         // four-wave kernel, whose workgroups are a third of a CU.  So the caller says whether the launch will have company.
         const bool force_four = t.dct64_kernel == 4, force_wave = t.dct64_kernel == 1;      // aej_set_option "dct64_kernel"
-        if (wd || force_four || (a.crowded && !force_wave)) { AEJ_MFMA(64); }       // (the float32 DCT output, a debugging aid, stays with the four-wave kernel)
+        // (latency-sized calls -- at most a few hundred leaves can exist: the one-wave kernel's workgroup first fills 122 KiB of LDS tables,
+        // 0.038 against 0.027 ms for one 1080p image)
+        const bool tiny = max_items < 2048;
+        if (wd || force_four || ((a.crowded || tiny) && !force_wave)) { AEJ_MFMA(64); }       // (the float32 DCT output, a debugging aid, stays with the four-wave kernel)
         else launch_dct64_wave<false>(st, g, q, a, max_items);
         break;
     }

@@ -141,8 +141,9 @@ class Jpeg:
         finally:
             ctx._in_flight = None
 
-    def compress(self, img: Image) -> bytes:
-        """Compresses the input image (jpeg.py:240-272)."""
+    def compress(self, img: Image, *, zlib_level: int = 9, entropy: str = "host") -> bytes:
+        """Compresses the input image (jpeg.py:240-272).  The keyword-only arguments are the opt-ins of ``compress_many`` (a lower host
+        deflate level, or the zlib streams written on the GPU); with the defaults the bytes are the reference's."""
         if not isinstance(img, Image):
             raise TypeError("Input must be an Image object.")
         if img.data.ndim != 3:
@@ -150,6 +151,8 @@ class Jpeg:
         self.update_layer_shapes(img.original_shape[:2])
         self.extension = img.extension
         data = np.ascontiguousarray(img.data, dtype=np.float32).reshape(img.original_shape)
+        if entropy != "host" or zlib_level != 9:
+            return self.compress_many(data[None], extension=img.extension, workers=3, zlib_level=zlib_level, entropy=entropy)[0]
         enc = self.compress_batch(data[None])
         layers = [enc.layer(0, l) for l in range(3)]
         return self._entropy_encode(layers)
