@@ -13,16 +13,16 @@
 // a tree.  Without a table every block is fixed-Huffman.  LZ77 matches are
 // restricted to distances 1 and 4 -- the previous byte and the same byte of the previous coefficient -- which is what an array of
 // mostly-zero, small-magnitude little-endian int32 values offers: zero runs (distance 1, up to 258 bytes per 12-13-bit token), the
-// three sign / zero bytes of a small coefficient behind another small coefficient (distance 4, length 3: 12 bits).  A thread parses 256
-// input bytes greedily; matches do not cross its sub-block (deflate's longest match is 258 bytes anyway).
+// three sign / zero bytes of a small coefficient behind another small coefficient (distance 4, length 3: 12 bits).  A thread parses 128
+// input bytes greedily; matches do not cross its sub-block (a zero run costs one 12-13-bit token per 128 bytes).
 #include "aej_common.h"
 #include "aej_launch.h"
 #include <string.h>
 
 namespace aej {
 
-constexpr int kDefSub = 256;                      // input bytes per thread
-constexpr int kDefThreads = 128;
+constexpr int kDefSub = 128;                      // input bytes per thread (256 bytes per thread = half the waves per CU for the same LDS)
+constexpr int kDefThreads = 256;
 constexpr int kDefChunk = kDefSub * kDefThreads;  // 32 KiB of input per workgroup
 constexpr int kDefSubStride = kDefSub + 4;        // LDS stride of a sub-block: 65 dwords, so equal offsets of different threads fall into different banks
 constexpr int kDefOutWords = (kDefChunk * 9 / 8 + 64) / 4;      // fixed code: a literal costs at most 9 bits; a block whose dynamic code needs more falls back to it
@@ -155,13 +155,13 @@ __device__ __forceinline__ void deflate_stage(const unsigned char *src, long lon
     for (int i = tid * 16; i < kDefChunk; i += kDefThreads * 16) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (i < len) v = *reinterpret_cast<const uint4 *>(src + c0 + i);
-        unsigned *dst = reinterpret_cast<unsigned *>(sIn + 4 + (i >> 8) * kDefSubStride + (i & 255));
+        unsigned *dst = reinterpret_cast<unsigned *>(sIn + 4 + (i / kDefSub) * kDefSubStride + (i % kDefSub));
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
 }
 
 // the four bytes before a thread's sub-block: the chunk's halo (sIn[0..3]) for thread 0, else the tail of the sub-block before it, which
-// ends four bytes short of this one (stride 260)
+// ends four bytes short of this one (stride kDefSub + 4)
 __device__ __forceinline__ unsigned deflate_left4(const unsigned char *sIn, const unsigned char *sub, int tid)
 {
     const unsigned char *q = tid == 0 ? sIn : sub - 8;

@@ -195,7 +195,7 @@ def adaptive_table(litlen_hist, dist_hist):
 
 
 # ---- pure-Python restatement of the kernels (CPU tests only; small inputs) ------------------------------------------------------------
-SUB, CHUNK = 256, 256 * 128
+SUB, CHUNK = 128, 128 * 256
 
 
 def _length_symbol(L):
