@@ -5,7 +5,7 @@ variants=${1:-head}; reps=${2:-5}; shift; shift
 run() { env $1 python3 bench.py --no-cpu-baseline --no-verify --steps 40 --warmup 6 "${@:2}" 2>/dev/null | python3 -c "
 import json,sys
 d=json.load(sys.stdin)
-print('[$1]:', d['ms_per_step'], 'ms/step; blocking', d['pipeline']['serial_ms_per_step'], '; stages', {k: v['ms'] for k, v in d['stages'].items() if k in ('clahe_blur', 'sobel_nms', 'hysteresis', 'dct4', 'dct32', 'dct64')})"; }
+print('[$1]:', d['ms_per_step'], 'ms/step; blocking', d['pipeline']['serial_ms_per_step'], '; stages', {k: v['ms'] for k, v in d['stages'].items() if k in ('clahe_blur', 'sobel_nms', 'hysteresis', 'quadtree', 'dct4', 'dct32', 'dct64')})"; }
 for rep in $(seq $reps); do
 run "A=1" "$@"
 for v in $variants; do run "AEJ_LIBRARY=build/variants/$v/libaejpeg_hip.so" "$@"; done
