@@ -542,7 +542,7 @@ def main():
             if hit:
                 traffic = sum(hit)
                 traffic_src = src_of(tj, traffic_file)
-        r = {"bound": "hbm", "kernel": {"quadtree": "k_qt_upper+count+scan+emit", "hysteresis": "k_hyst_pass+k_hyst_drain"}.get(stage, KERNEL_OF_STAGE[stage][0]),
+        r = {"bound": "hbm", "kernel": {"quadtree": "k_qt_upper+count+scan+emit", "hysteresis": "k_hyst_pass0+k_hyst_bulk+k_hyst_drain"}.get(stage, KERNEL_OF_STAGE[stage][0]),
              "stage": stage, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
              "algorithmic_bytes_per_launch": algo[stage], "avg_launch_ms": round(kernels[stage], 4)}
@@ -594,10 +594,11 @@ def main():
         "verified": verified,
         "profile_gaps": profile_gaps or None,
         "ranks": ranks,
-        "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "launches_per_part": 2,
+        "hysteresis": {"timed_calls": h1["calls"] - h0["calls"], "launches_per_part": "2 (up to 8192 tiles), 3 (up to 32768), 4 (larger parts: the bench's sub-batches)",
                        "tiles_through_the_work_queue_last_call": h1["queued"], "tiles": int(B * sum(-(-plan.layer_h[l] // 64) * -(-plan.layer_w[l] // 64) for l in range(3))),
-                       "what": "a pass over every 64 x 64 tile, then a device-side work queue of dirtied tiles drained to the fix-point by one persistent "
-                               "launch: no pass count guessed by the host, nothing read back, nothing to repair"},
+                       "what": "a pass over every 64 x 64 tile that flags dirtied neighbours, for large parts two bulk launches over the flagged tiles, then a "
+                               "device-side work queue drained to the fix-point by one small persistent launch: no pass count guessed by the host, nothing "
+                               "read back, nothing to repair"},
         "pipeline": {"contexts": n_pipe, "what": "timed step i is enqueued (aej_encode_batch_begin) on context i % n, each context on its own stream with its own "
                                                   "output buffers and workspace, after the step that used that context before has been ended (aej_encode_batch_end: "
                                                   "waited for and verified); all K steps are complete inside the timed region",
