@@ -336,7 +336,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
 
     from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput, gather_rank_report
-    if not (args.no_verify and (args.no_cpu_baseline or rank != 0)) and not args.timed_only:
+    if not (args.no_verify and args.no_cpu_baseline) and not args.timed_only:      # (the same decision on every rank: it holds a barrier)
         build_oracle_once(dist, int(os.environ.get("LOCAL_RANK", "0")))        # the checker exists before anything is timed (it is not used until after)
 
     H, W = args.height, args.width
