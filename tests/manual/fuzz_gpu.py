@@ -1,8 +1,9 @@
-"""Randomised parity sweep (GPU box, manual): random sizes / colour spaces / block ranges / image kinds, whole encode and decode
-against the oracle.  python tests/manual/fuzz_gpu.py [n_cases] [seed]"""
+"""Randomised parity sweep (GPU box, manual): random sizes / colour spaces / block ranges / image kinds and small batches, whole encode
+and decode against the oracle, and the opt-in GPU entropy stage against zlib.decompress.  python tests/manual/fuzz_gpu.py [n_cases] [seed]"""
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -32,14 +33,19 @@ for case in range(n_cases):
     tag = f"case {case}: {space} {H}x{W} blocks ({lo},{hi}) q {tuple(q)} {kind}"
     try:
         codec = A.Jpeg(A.JpegCompressionSettings(space, tuple(q), (lo, hi)))
-        enc = codec.compress_batch(img[None])
+        nb = int(rng.integers(1, 4))          # the image rides in a batch of 1..3 (the others: flipped copies), at a random position
+        pos = int(rng.integers(nb))
+        batch = np.stack([img if b == pos else np.ascontiguousarray(img[::-1, ::-1]) for b in range(nb)])
+        enc = codec.compress_batch(batch)
         ref = O.encode_image(img, space, tuple(q), (lo, hi))
         ok = True
+        streams = codec.deflate_batch(enc, adaptive=bool(case & 1))
         for l in range(3):
-            got = enc.layer(0, l)
+            got = enc.layer(pos, l)
+            ok &= zlib.decompress(streams[pos][l]) == got["coeffs"].tobytes()
             ok &= got["root_size"] == ref[l]["root_size"] and np.array_equal(got["states"], ref[l]["states"])
             ok &= np.array_equal(got["leaves"], ref[l]["leaves"]) and np.array_equal(got["coeffs"], ref[l]["coeffs"])
-        dec = codec.decompress_batch(enc).cpu().numpy()[0]
+        dec = codec.decompress_batch(enc).cpu().numpy()[pos]
         want = O.decode_image(O.write_ajpg(ref, H, W, space, tuple(q), (lo, hi), ".png"))
         ok &= np.array_equal(dec, want, equal_nan=True)
         if not ok:

@@ -215,3 +215,34 @@ def test_oracle_runs_clean_under_address_and_ub_sanitizers(oracle):
     r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("clean"), (r.stdout[-500:], r.stderr[-3000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_oracle_stencils_against_independent_scipy_restatements(oracle):
+    """OpenCV itself is absent (parity unpinned), but the oracle's stencil stages can at least be checked against
+    restatements that share no code with it: SciPy's convolution / resampling with the border rules OpenCV documents.
+    * GaussianBlur 3x3, sigma 0 on uint8 = ([1 2 1]^T [1 2 1] * p + 8) >> 4 with BORDER_REFLECT_101 (scipy mode 'mirror');
+    * Sobel 3x3 with BORDER_REPLICATE (scipy mode 'nearest'): every STRONG pixel of the NMS map has mag = dx^2 + dy^2 > high, every
+      pixel with mag <= low is suppressed (the NMS in between is the oracle's own);
+    * cv.resize INTER_AREA with integer ratio 2 x 2 = the mean of each 2 x 2 block."""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    img = (rng.random((97, 131)) * 255).astype(np.uint8)
+    img[20:60, 30:90] = 200                                  # a flat patch and its edges
+    k = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.int64)
+    want = ((ndimage.convolve(img.astype(np.int64), k, mode="mirror") + 8) >> 4).astype(np.uint8)
+    assert np.array_equal(oracle.gauss3(img), want)
+    lo, hi = 40.0, 90.0
+    edge, nms = oracle.canny(img, lo, hi, return_nms=True)
+    p = img.astype(np.int64)
+    dx = ndimage.correlate(p, np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], np.int64), mode="nearest")
+    dy = ndimage.correlate(p, np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], np.int64), mode="nearest")
+    mag = dx * dx + dy * dy
+    low, high = oracle.canny_thresholds(lo, hi)
+    assert (mag[nms == 2] > high).all() and (nms[mag <= low] == 1).all()
+    assert set(np.unique(edge).tolist()) <= {0, 255} and (edge[nms == 2] == 255).all() and (edge[nms == 1] == 0).all()      # cv.Canny's 0 / 255 map
+    conv = rng.random((3, 40, 52)).astype(np.float32)
+    hw3 = np.ascontiguousarray(conv.transpose(1, 2, 0))
+    got = oracle.downsample(hw3, 1, 2, 2)
+    blocks = conv[1].reshape(20, 2, 26, 2)
+    want = ((blocks[:, 0, :, 0] + blocks[:, 0, :, 1]) + (blocks[:, 1, :, 0] + blocks[:, 1, :, 1])) * np.float32(0.25)
+    assert np.array_equal(got, want.astype(np.float32))
