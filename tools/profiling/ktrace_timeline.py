@@ -15,7 +15,7 @@ import sys
 
 def short(n):
     n = n.split("(")[0].replace("void ", "").replace("aej::", "").strip()
-    for k, v in (("k_color_planes", "colour"), ("k_clahe_blur", "blur"), ("k_sobel", "sobel"), ("k_hyst_pass<false", "hyst0"), ("k_hyst_pass<true", "hystN"),
+    for k, v in (("k_color_planes", "colour"), ("k_clahe_blur", "blur"), ("k_sobel", "sobel"), ("k_hyst_pass0", "hyst0"), ("k_hyst_bulk", "hystB"), ("k_hyst_drain", "hystQ"),
                  ("k_qt_", "qt"), ("k_dct_mfma<64", "dct64"), ("k_dct_mfma<32", "dct32"), ("k_dct16", "dct16"), ("k_dct8", "dct8"), ("k_dct4", "dct4")):
         if n.startswith(k):
             return v
