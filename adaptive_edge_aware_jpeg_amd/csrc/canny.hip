@@ -1349,7 +1349,11 @@ __device__ __forceinline__ unsigned hyst_tile(const Geom &g, const CannyBuffers 
     // which of the 8 neighbours see a changed pixel next to them: new bits in the first / last valid row (and their end
     // columns for the diagonal neighbours), in the first / last column
     const int last_row = min(63, h - 1 - ty * 64);
-    const unsigned long long dtop = __shfl(diff, 0), dbot = __shfl(diff, last_row);
+    // (wave-uniform lane indices: v_readlane, not a ds_bpermute round trip)
+    const unsigned dlo = (unsigned)diff, dhi = (unsigned)(diff >> 32);
+    const unsigned long long dtop = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, 0);
+    const int last_row_u = __builtin_amdgcn_readfirstlane(last_row);
+    const unsigned long long dbot = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, last_row_u) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, last_row_u);
     const bool dl = __any((diff & 1ull) != 0), dr = __any((diff >> 63) != 0);
     unsigned dirs = 0;
     if (dtop) dirs |= 2u | ((dtop & 1ull) ? 1u : 0u) | ((dtop >> 63) ? 4u : 0u);

@@ -70,15 +70,7 @@ struct LayerTabD {
     float mid[3], scale[3];
 };
 
-__device__ __forceinline__ int wave_incl_scan_d(int v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan_d(int v, int /*lane*/) { return wave_scan_incl(v); }      // (threads 0..63 of the workgroup: a whole wave)
 
 __device__ __forceinline__ void idct_prologue(const Geom &g, const QtGeom &q, const IdctArgs &a, int *s_pref, LayerTabD &lt)
 {
@@ -97,7 +89,7 @@ __device__ __forceinline__ void idct_prologue(const Geom &g, const QtGeom &q, co
             int v = p < a.nplanes ? a.work_count[(long long)p * kMaxSizes + a.k] : 0;
             int inc = wave_incl_scan_d(v, lane);
             if (p < a.nplanes) s_pref[p + 1] = carry + inc;
-            carry += __shfl(inc, 63);
+            carry += __builtin_amdgcn_readlane(inc, 63);
         }
     }
     __syncthreads();

@@ -266,22 +266,8 @@ __device__ __forceinline__ void unpack_lane(unsigned code, unsigned g0, int ltot
     }
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) { return wave_scan_incl(v); }      // aej_common.h: DPP, all lanes active
+__device__ __forceinline__ int wave_sum(int v) { return wave_total(v); }
 
 // pass 2: per-chunk totals (symbols, leaves, coefficients, leaves per block size); one wave per chunk
 __global__ __launch_bounds__(256) void k_qt_count(Geom g, QtGeom q, const unsigned long long *__restrict__ edge_bits,
