@@ -391,21 +391,32 @@ __global__ __launch_bounds__(kScanThreads) void k_qt_scan(Geom g, QtGeom q, int 
     const int nq = 3 + q.nsizes;
     if (tid < NQ) carry[tid] = 0;
     __syncthreads();
+    static_assert(kChunkInts == 12 && NQ == 11, "a chunk record is three int4: (nsym, nleaf, ncoef, pad), leaves per size 0..3, 4..7");
+    int4 *rec = reinterpret_cast<int4 *>(base);          // (chunk records start on 16-byte boundaries: 48 bytes each, workspace carved at 256)
     for (int start = 0; start < n; start += kScanThreads) {
         const int i = start + tid;
-        int v[NQ], inc[NQ];
+        // the record as three 16-byte loads (a wave reads 3 KiB contiguously) instead of eleven strided dword loads
+        int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        if (i < n) { r0 = rec[3 * i]; r1 = rec[3 * i + 1]; r2 = rec[3 * i + 2]; }
+        int v[NQ] = { r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w }, inc[NQ];
 #pragma unroll
         for (int c = 0; c < NQ; c++) {
-            v[c] = (i < n && c < nq) ? base[i * kChunkInts + (c < 3 ? c : c + 1)] : 0;
+            if (c >= nq) v[c] = 0;
             inc[c] = wave_incl_scan(v[c], lane);
             if (lane == 63) s_w[c][wv] = inc[c];
         }
         __syncthreads();
+        int o[NQ];
 #pragma unroll
         for (int c = 0; c < NQ; c++) {
             int p = carry[c];
             for (int k = 0; k < wv; k++) p += s_w[c][k];
-            if (i < n && c < nq) base[i * kChunkInts + (c < 3 ? c : c + 1)] = p + inc[c] - v[c];
+            o[c] = p + inc[c] - v[c];
+        }
+        if (i < n) {
+            rec[3 * i] = make_int4(o[0], o[1], o[2], r0.w);
+            rec[3 * i + 1] = make_int4(o[3], o[4], o[5], o[6]);
+            rec[3 * i + 2] = make_int4(o[7], o[8], o[9], o[10]);
         }
         __syncthreads();
         if (tid < NQ) {
