@@ -640,7 +640,12 @@ static int run_color_planes(aej_ctx *ctx, const void *rgb, bool in_u8, const Geo
     float mid[3], scale[3];
     for (int i = 0; i < 3; i++) { mid[i] = (float)kMid[ctx->space][i]; scale[i] = (float)kScale[ctx->space][i]; }
     if (planes_fast_ok(g)) {
-        if (launch_color_planes(ctx->stream, ctx->space, rgb, in_u8, g, mid, scale, raw, norm, u8, hist, ctx->tune)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
+        // the persistent colour streamer beside other parts' kernels (sub-batches, calls in flight): 224 instead of 256 workgroups -- a few CUs
+        // without a colour workgroup let the foreground kernels' largest workgroups in sooner (interleaved 3 x: 5.87-5.91 against 5.92-5.97 ms per
+        // 64 x 4K step; 192: 5.89-5.91; 160: 5.95-6.06; alone the kernel wants all 256: blocking calls 6.54-6.75 against 6.56-6.68)
+        Tuning t = ctx->tune;
+        if (t.color_workgroups == 0 && ctx->dct_crowded && ctx->space < 3) t.color_workgroups = 224;
+        if (launch_color_planes(ctx->stream, ctx->space, rgb, in_u8, g, mid, scale, raw, norm, u8, hist, t)) return fail(ctx, AEJ_ERR_ARG, "bad colour space");
         return 0;
     }
     AreaTabs t;
