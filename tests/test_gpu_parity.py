@@ -567,6 +567,29 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
             want = A.Jpeg(A.JpegCompressionSettings()).decompress(blobs_ref[b]).data
             assert np.array_equal(got, want)
             assert np.array_equal(oracle.decode_image(blobs_gpu[b]), oracle.decode_image(blobs_ref[b]), equal_nan=True)
+    # Jpeg.compress's keyword-only opt-ins: same container layout, decoded by the default reader
+    img = A.Image.from_array(golden_image("natural/house"), None, ".png")
+    codec = A.Jpeg(A.JpegCompressionSettings("YCoCg", (40, 80), (4, 64)))
+    ref_bytes = codec.compress(img)
+    for kw in ({"entropy": "gpu"}, {"entropy": "gpu-fixed"}, {"zlib_level": 1}):
+        alt = codec.compress(img, **kw)
+        assert alt != ref_bytes and np.array_equal(A.Jpeg(A.JpegCompressionSettings()).decompress(alt).data,
+                                                   A.Jpeg(A.JpegCompressionSettings()).decompress(ref_bytes).data), kw
+    with pytest.raises(ValueError):
+        codec.compress(img, entropy="cpu")
+    # a stream slot that is too small is refused, not overrun
+    import ctypes
+    from adaptive_edge_aware_jpeg_amd._lib import AejError, get_context
+    ctx = get_context()
+    enc = codec.compress_batch(img.data[None])
+    p = enc.plan
+    t = ctx.torch
+    streams, sizes = ctx.empty((3, 256), t.uint8), ctx.empty((3,), t.int64)
+    nbytes = int(ctx.lib.aej_deflate_workspace_bytes(ctx.handle, 1, p.H, p.W))
+    ws = ctx.workspace(nbytes)
+    rc = ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), 1, p.H, p.W, None, streams.data_ptr(),
+                                   ctypes.c_uint64(256), sizes.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes))
+    assert rc == -4 and int(sizes.cpu()[0]) > 256          # AEJ_ERR_CAPACITY, and the size it would have needed is reported
     # an empty layer cannot occur in the codec, but the stream format must still close: one image of the smallest shape the settings allow
     tiny = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (2, 2)))
     enc = tiny.compress_batch(np.full((1, 4, 4, 3), 0.25, np.float32))
