@@ -16,7 +16,7 @@ def shard_bounds(n_images: int, rank: int, world: int) -> Tuple[int, int]:
 
 def aggregate_throughput(dist, pixels_local: int, seconds_local: float, device=None) -> Tuple[int, float]:
     """-> (total pixels over all ranks, max seconds over ranks).  `dist` is torch.distributed or None."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return int(pixels_local), float(seconds_local)
     import torch
     px = torch.tensor([float(pixels_local)], dtype=torch.float64, device=device)
@@ -33,7 +33,7 @@ def gather_rank_report(dist, local_rank: int, ms_per_step: float, images: int, v
     -- a rank that never reached its check counts as a failure -- unless the run was asked not to verify (`require_verified=False`:
     then only an explicit False fails).  Every rank gets the same dict."""
     ok = -1.0 if verified_ok is None else (1.0 if verified_ok else 0.0)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         rows = [[float(local_rank), float(ms_per_step), float(images), ok]]
         world = 1
     else:

@@ -195,8 +195,7 @@ def build_oracle_once(dist, local_rank):
     from oracle import oracle as O
     if local_rank == 0:
         O.build()
-    if dist is not None:
-        dist.barrier()
+    group_barrier(dist)
     O.build()          # (no-op when rank 0 of this node has just built it)
     return O
 
@@ -206,17 +205,39 @@ def rank_env():
 
 
 def init_distributed(torch, backend, rank, local_rank, world):
-    """One process per GPU; rendezvous on 127.0.0.1 (the container hostname may not resolve).  Returns torch.distributed or None."""
-    if world <= 1:
-        return None
+    """One process per GPU; rendezvous on 127.0.0.1 (the container hostname may not resolve).  Returns torch.distributed or None.
+    The RCCL communicator is NOT created here (no `device_id`): it comes up at the first collective, which main() places after every
+    stream of this process exists -- see `hw_queue_default`."""
+    if world <= 1 and not os.environ.get("AEJ_BENCH_FORCE_DIST"):      # (rehearsal switch: a ONE-rank process group, so that a one-GPU box can
+        return None                                                     # run the barriers and the counter collectives through RCCL itself)
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    if backend == "nccl":
+    if backend == "nccl" and os.environ.get("AEJ_BENCH_NCCL_EAGER"):    # (A / B only: profiles/r04_rccl_hw_queues.txt)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist
+
+
+def group_barrier(dist):
+    if dist is None:
+        return
+    if dist.get_backend() == "nccl":
+        import torch
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
+def hw_queue_default(world):
+    """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue run one after the other.  This
+    process uses one stream per context plus the library's sub-batch streams: 16 with the null stream, so 16 queues give every stream its
+    own -- until somebody else creates streams first.  A live RCCL communicator does (measured on one GPU, one rank, profiles/
+    r04_rccl_hw_queues.txt: 6.85-6.96 ms per step against 5.96-5.98 with the same blocking-call time, back to 5.95-5.99 with 24 queues or
+    with the communicator created after our streams), so a process that will hold a process group asks for 24 AND creates its
+    communicator last."""
+    return "24" if world > 1 or os.environ.get("AEJ_BENCH_FORCE_DIST") else "16"
 
 
 def local_batch_and_seed(args, rank, world):
@@ -232,16 +253,14 @@ def local_batch_and_seed(args, rank, world):
 
 def timed_loop(torch, dist, step, steps, sync):
     """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> local seconds."""
-    if dist is not None:
-        dist.barrier()
+    group_barrier(dist)
     sync()
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
     sync()
     timed_loop.own_seconds = time.perf_counter() - t0      # this rank's own K steps, before it waits for the others (per-rank report)
-    if dist is not None:
-        dist.barrier()
+    group_barrier(dist)
     return time.perf_counter() - t0
 
 
@@ -297,25 +316,45 @@ def rehearse(args):
         verdict = None                                            # ... or never reach its check
     ranks = gather_rank_report(dist, local_rank, dt_local / args.steps * 1e3, B, verdict, None)
     if rank == 0:
-        print(json.dumps({"metric": "REHEARSAL of bench.py's multi-rank control flow (no GPU work, not a measurement)", "value": None,
+        emit(json.dumps({"metric": "REHEARSAL of bench.py's multi-rank control flow (no GPU work, not a measurement)", "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "pixels_total": px,
-                          "seconds_max": round(dt, 4), "rank0_images": B, "rank0_seeds": [seed_a, seed_b], "ranks": ranks}), flush=True)
+                          "seconds_max": round(dt, 4), "rank0_images": B, "rank0_seeds": [seed_a, seed_b], "ranks": ranks}))
     if dist is not None:
         dist.destroy_process_group()
     if not ranks["all_verified"]:
         raise SystemExit(3)                                       # every rank exits non-zero, as in the real run
 
 
+def keep_stdout_for_the_json_line():
+    """Rank 0 prints ONE JSON line on stdout, and nothing else may: libraries write there too (RCCL prints a five-line version banner on
+    stdout when its first communicator comes up).  File descriptor 1 is pointed at stderr for the rest of the process, and `print` is
+    given a copy of the real stdout only through `emit()`."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
+def emit(line):
+    _REAL_STDOUT.write(line + "\n")
+    _REAL_STDOUT.flush()
+
+
+_REAL_STDOUT = sys.stdout
+
+
 def main():
+    global _REAL_STDOUT
     args = parse_args()
     spawn_ranks_if_asked(args, sys.argv[1:])
+    _REAL_STDOUT = keep_stdout_for_the_json_line()
     if args.rehearse_control_flow:
         return rehearse(args)
 
     # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue run one after the other;
     # this process uses one stream per context plus the library's sub-batch streams, so give every stream a queue of its own
     # (must be set before the HIP runtime initialises)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", hw_queue_default(rank_env()[2]))
     import torch
     # imported BEFORE anything initialises HIP: the package then knows that the queue count in the environment is the one the runtime
     # will start with and tells the library (aej_set_hw_queues); imported later it would have to assume HIP's default of 4
@@ -336,9 +375,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
 
     from adaptive_edge_aware_jpeg_amd.sharding import aggregate_throughput, gather_rank_report
-    if not (args.no_verify and args.no_cpu_baseline) and not args.timed_only:      # (the same decision on every rank: it holds a barrier)
-        build_oracle_once(dist, int(os.environ.get("LOCAL_RANK", "0")))        # the checker exists before anything is timed (it is not used until after)
-
     H, W = args.height, args.width
     B, seed_a, seed_b, scaling = local_batch_and_seed(args, rank, world)
     if B < 1:
@@ -416,6 +452,10 @@ def main():
     for i in range(n_warm):
         step(i)
     sync()
+    # the first collective of the process -- after every context, stream and sub-batch stream exists (hw_queue_default) -- holds the
+    # barrier behind which ONE process per node builds the checker: it exists before anything is timed and is not used until after
+    if not (args.no_verify and args.no_cpu_baseline) and not args.timed_only:      # (the same decision on every rank)
+        build_oracle_once(dist, int(os.environ.get("LOCAL_RANK", "0")))
     h0 = hyst_stats()
     dt_local = timed_loop(torch, dist, step, args.steps, sync)
     own_ms_per_step = timed_loop.own_seconds / args.steps * 1e3
@@ -426,9 +466,9 @@ def main():
     last_pipe, last_batch = pipes[(args.steps - 1) % n_pipe], input_of(args.steps - 1)
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({"metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch", "value": round(value, 1), "unit": "MP/s",
+            emit(json.dumps({"metric": "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch", "value": round(value, 1), "unit": "MP/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-                              "encode_calls": args.steps + n_warm, "timed_only": True}), flush=True)
+                              "encode_calls": args.steps + n_warm, "timed_only": True}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -454,6 +494,9 @@ def main():
     # ---- first-contact evidence for N > 1: which ranks the collective saw, their own step times and oracle checks ----
     ranks = gather_rank_report(dist, local_rank, own_ms_per_step, B, None if verified is None else verified["ok"],
                                dev if backend == "nccl" else None, require_verified=not args.no_verify)
+    ranks["collectives"] = (None if dist is None else
+                            {"backend": dist.get_backend(), "what": "barriers around the timed region, all_reduce(SUM / MAX) of two float64 counters, all_gather of "
+                                                                    "four float64 per rank" + ("; tensors on the GPU" if backend == "nccl" else "")})
 
     # ---- strictly serial figure: blocking calls on one context, nothing in flight between them ----
     serial_step(0); serial_step(1)
@@ -686,7 +729,7 @@ def main():
                                                                     "sample": f"{n_fan} bench images, one per worker process (fresh interpreters, as the reference's "
                                                                               f"sweep fans out, metrics_computation.py:253), {t_fan:.1f} s wall including interpreter start-up"}}}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     # a rank whose outputs differ from the oracle's makes the whole run fail (every rank has the same `ranks` dict)
