@@ -1015,6 +1015,9 @@ constexpr int kDppRowShl1 = 0x101, kDppRowShr1 = 0x111, kDppRowShr2 = 0x112;
 
 struct NmsRowH { unsigned s[3], d[3]; };        // per source row: [1 2 1] sums and right-minus-left differences of the pixel pairs (-1, 2), (0, 3), (1, 4)
 
+#ifndef AEJ_X_SOBEL_DEPTH
+#define AEJ_X_SOBEL_DEPTH 4            // source rows in flight ahead of the row being worked on (round 4; 20 = all of them up front, as in round 3)
+#endif
 // one 64 x 64 tile; EDGE = the tile touches the plane's border (clamped source coordinates, magnitudes outside the image are 0)
 template <bool L2, bool EDGE>
 __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__ src, int w, int h, int tx, int ty, int low, int high,
@@ -1028,39 +1031,43 @@ __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__
     // the dword beyond the tile's edge is needed by lanes 0 and 15 of a row only (the DPP shifts' `old` operand); the other lanes
     // re-read their own dword instead of being masked off (same cache lines, no exec juggling)
     const int halo_col = j == 0 ? x0 - 4 : j == 15 ? x0 + 64 : px;
-    if constexpr (EDGE) {
-        // source dword of column c (a multiple of 4, possibly outside [0, w)) of clamped row y: BORDER_REPLICATE
-        auto load_col = [&](int y, int c) -> unsigned {
-            const int yc = y < 0 ? 0 : y >= h ? h - 1 : y;
-            const int cc = c < 0 ? 0 : c > w - 4 ? w - 4 : c;
-            unsigned d = *reinterpret_cast<const unsigned int *>(src + (long long)yc * w + cc);
-            if (c < 0) d = (d & 0xffu) * 0x01010101u;
-            else if (c > w - 4) d = (d >> 24) * 0x01010101u;
-            return d;
-        };
-#pragma unroll
-        for (int u = 0; u < kRows; u++) {
+    // source dword of column c (a multiple of 4, possibly outside [0, w)) of clamped row y: BORDER_REPLICATE (EDGE tiles)
+    auto load_col = [&](int y, int c) -> unsigned {
+        const int yc = y < 0 ? 0 : y >= h ? h - 1 : y;
+        const int cc = c < 0 ? 0 : c > w - 4 ? w - 4 : c;
+        unsigned d = *reinterpret_cast<const unsigned int *>(src + (long long)yc * w + cc);
+        if (c < 0) d = (d & 0xffu) * 0x01010101u;
+        else if (c > w - 4) d = (d >> 24) * 0x01010101u;
+        return d;
+    };
+    // interior tile: one wave-uniform row base per source row (scalar arithmetic) plus a per-lane 32-bit offset
+    // (row0 starts four pixels left of the tile, so that every per-lane offset is non-negative)
+    const unsigned own_off = (unsigned)(16 * q * w + 4 * j + 4), halo_off = (unsigned)(16 * q * w + (halo_col - x0) + 4);
+    const unsigned char *row0 = src + (long long)(ty * 64 - 2) * w + (x0 - 4);
+    auto fetch = [&](int u) {
+        if constexpr (EDGE) {
             own[u] = load_col(yb0 - 2 + u, px);
             halo[u] = load_col(yb0 - 2 + u, halo_col);
-        }
-    } else {
-        // interior tile: one wave-uniform row base per source row (scalar arithmetic) plus a per-lane 32-bit offset
-        // (row0 starts four pixels left of the tile, so that every per-lane offset is non-negative)
-        const unsigned own_off = (unsigned)(16 * q * w + 4 * j + 4), halo_off = (unsigned)(16 * q * w + (halo_col - x0) + 4);
-        const unsigned char *row0 = src + (long long)(ty * 64 - 2) * w + (x0 - 4);
-#pragma unroll
-        for (int u = 0; u < kRows; u++) {
+        } else {
             const unsigned char *row = row0 + (long long)u * w;
             own[u] = *reinterpret_cast<const unsigned int *>(row + own_off);
             halo[u] = *reinterpret_cast<const unsigned int *>(row + halo_off);
         }
-    }
+    };
+    // kDepth source rows are in flight ahead of the row being worked on: all twenty up front cost forty registers for the whole tile
+    constexpr int kDepth = AEJ_X_SOBEL_DEPTH < kRows ? AEJ_X_SOBEL_DEPTH : kRows;
+#pragma unroll
+    for (int u = 0; u < kDepth; u++) fetch(u);
 
     NmsRowH H[3];                                      // the last three source rows (index = u % 3)
     int M[3][6];                                       // magnitudes of pixels -1 .. 4 of the last three gradient rows (index = row % 3)
     unsigned G[3][4];                                  // dx | dy << 16 of the four own pixels, same rows
 #pragma unroll
     for (int u = 0; u < kRows; u++) {
+        if constexpr (kDepth < kRows) {
+            __builtin_amdgcn_sched_barrier(0);         // (the loads of row u + kDepth are issued here, not hoisted to the top)
+            if (u + kDepth < kRows) fetch(u + kDepth);
+        }
         // ---- horizontal pass of source row u: p[-2], p[-1] = left bytes 2, 3; p[0..3] = own; p[4], p[5] = right bytes 0, 1
         {
             const unsigned m = own[u];
@@ -1157,7 +1164,13 @@ __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__
 }
 
 #ifndef AEJ_X_SOBEL_MINW
-#define AEJ_X_SOBEL_MINW 5             // register budget for five waves per SIMD: 96 registers, no spills (99 = four waves when left to the compiler): 0.865 -> 0.78 ms
+// Waves per SIMD the register budget is cut for.  Round 3 loaded a tile's twenty source rows up front (forty registers for the whole tile):
+// 96 registers, five waves.  Round 4 keeps AEJ_X_SOBEL_DEPTH rows in flight instead, which frees the registers for more waves, and more
+// waves hide the latency the shorter look-ahead exposes (profiles/r04_ab_sobel_occupancy.txt, 64 x 4K, stage / step in ms):
+//   5 waves, all rows up front 0.77 / 5.84-5.93     6 waves, 8 rows 0.724 / 5.72-5.80     7 waves, 4 rows 0.70 / 5.73-5.83
+//   8 waves, 4 rows (64 registers, two spilled dwords) 0.69 / 5.75-5.80  <- this       8 waves, 5 rows: slower (36 bytes of spills)
+// (natural images: 0.905 -> 0.86 ms.)
+#define AEJ_X_SOBEL_MINW 8
 #endif
 template <bool L2>
 __global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles)
