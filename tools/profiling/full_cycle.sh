@@ -18,6 +18,6 @@ b)
   bash tools/profiling/configs.sh > gpurun_out/cycle_configs.txt 2>&1; echo "configs rc=$?"
   AEJ_BENCH_BACKEND=gloo AEJ_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 6 --batch 32 --no-cpu-baseline > gpurun_out/cycle_bench_2rank_gloo.json 2> gpurun_out/cycle_bench_2rank_gloo.err; echo "two ranks rc=$?"
   # one rank, but with a process group: the barriers and counter collectives run through RCCL (backend "nccl") on this box's one GPU
-  AEJ_BENCH_FORCE_DIST=1 MASTER_PORT=29517 python3 bench.py --steps 10 --no-cpu-baseline > gpurun_out/cycle_bench_1rank_rccl.json 2> gpurun_out/cycle_bench_1rank_rccl.err; echo "one rank over RCCL rc=$?"
+  AEJ_BENCH_FORCE_DIST=1 MASTER_PORT=29517 python3 bench.py --steps 20 --no-cpu-baseline > gpurun_out/cycle_bench_1rank_rccl.json 2> gpurun_out/cycle_bench_1rank_rccl.err; echo "one rank over RCCL rc=$?"
   ;;
 esac
