@@ -165,7 +165,7 @@ constexpr int kBGW = kBAW + 4;            // Gaussian row stride in halfwords; s
                                           // of a bilateral thread (columns 4 c4 + 2 .. 4 c4 + 9) is two ALIGNED 8-byte reads (conflict-free)
 constexpr int kBGW2 = kBGW / 2;           // ... in dwords
 static_assert(kBGW % 4 == 0, "Gaussian rows keep 8-byte alignment");
-constexpr int kBStripMax = 8;             // tiles of one tile-row handled by one workgroup (tables / histogram stay in LDS); fewer when
+constexpr int kBStripMax = 15;            // tiles of one tile-row handled by one workgroup (tables / histogram stay in LDS); fewer when
                                           // the batch is small, so that a single image still spreads over the whole chip
 constexpr int kASlots = kBT / kBAW4;      // 7 row slots: thread t owns column dword t % 34 and rows t / 34 + 7 k
 constexpr int kAIter = (kBAH + kASlots - 1) / kASlots;   // 6
@@ -1610,13 +1610,27 @@ static long long strips_per_image(const Geom &g, int TW, int TH, int strip)
 static int pick_strip(const Geom &g, int TW, int TH, int strip_max, long long want_workgroups)
 {
     int strip = strip_max;
-    while (strip > 1 && strips_per_image(g, TW, TH, strip) * g.B < want_workgroups) strip >>= 1;
+    while (strip > 1 && strips_per_image(g, TW, TH, strip) * g.B < want_workgroups) strip = (strip + 1) >> 1;
     return strip;
 }
 
 void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
 {
-    const int strip = pick_strip(g, kBTW, kBTH, kBStripMax, 1024);       // 256 CUs x 2 resident workgroups x 2
+    // Strip length: the one of 5 .. 15 tiles that cuts the tile rows of ALL layers into the most even pieces (fewest unused tile slots in
+    // the rows' last strips; ties go to the longer strip), then halved while the launch would not fill the chip.  Round 3 used 8 throughout;
+    // a 4K plane row is 30 (chroma 15) tiles -- 8 + 8 + 8 + 6 and 8 + 7 -- and strips of 15 (or 5) run the stage 4-7 % faster alone (2.02-2.07
+    // against 2.14-2.22 ms; 6: 2.08, 10: 2.22, 4: 2.28), blocking 64 x 4K calls 0.1-0.2 ms faster; 1080p (15 / 8 tiles) keeps its 8
+    // (15: 0.626 against 0.605 ms).  profiles/r04_ab_blur_strip.txt
+    int best = 8, best_waste = 1 << 30;
+    for (int s = 5; s <= kBStripMax; s++) {
+        int waste = 0;
+        for (int l = 0; l < g.nl; l++) {
+            const int ntx = (g.w[l] + kBTW - 1) / kBTW;
+            waste += (ntx + s - 1) / s * s - ntx;
+        }
+        if (waste <= best_waste) { best_waste = waste; best = s; }
+    }
+    const int strip = pick_strip(g, kBTW, kBTH, best, 1024);             // 256 CUs x 2 resident workgroups x 2
     if (cb.dump_clahe || cb.dump_gauss)
         hipLaunchKernelGGL(k_clahe_blur<true>, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), AEJ_X_BLUR_DYNLDS, st, g, cb, strip);
     else

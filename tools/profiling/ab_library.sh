@@ -1,7 +1,7 @@
 #!/bin/bash
 # A / B of the in-tree library against variant builds (build/variants/<name>/libaejpeg_hip.so), interleaved:
 #   bash tools/profiling/ab_library.sh "<variant> ..." [repetitions] [extra bench args, e.g. --data natural]
-variants=${1:-head}; reps=${2:-5}; shift; shift
+variants=$1; reps=${2:-5}; shift; shift      # "" = the in-tree library only
 run() { env $1 python3 bench.py --no-cpu-baseline --no-verify --steps 40 --warmup 6 "${@:2}" 2>/dev/null | python3 -c "
 import json,sys
 d=json.load(sys.stdin)
