@@ -63,9 +63,10 @@ struct aej_ctx {
     int *sub_flag[kMaxSub] = {};       // pinned read-back words per sub-batch (layout of h_flag)
     long long n_split_calls = 0;
     int sub_chain = -1;                // colour stages wait for a stage of the previous part (g_last_color_done): 1 its colour stage, 2 its blur, 3 its
-                                       // Sobel / NMS; 0 no staggering; -1 (default) = 1 between the sub-batches of one call, 2 between whole calls --
-                                       // measured best of each (64 x 4K: sub-batches 8.1 / 8.35 / 8.35 / 8.4 ms for 1 / 2 / 3 / 0, two contexts
-                                       // 8.0 / 7.8 / 7.9 / 8.4).  aej_set_option "sub_chain" overrides.
+                                       // Sobel / NMS; 0 no staggering; -1 (default) = 1, between the sub-batches of one call and between whole calls on
+                                       // rotating contexts alike (round 4, profiles/r04_sched_sweep_final.txt: unsplit 64 x 4K calls on three contexts
+                                       // 6.01 / 7.58 / 7.49 / 6.22 ms for 1 / 2 / 3 / 0; 6 x 4K 0.66 / 0.75 / 0.85 / 0.68; round 3's kernels had preferred 2
+                                       // between whole calls).  aej_set_option "sub_chain" overrides.
     int chain_hook = 0;                // run_canny_chain publishes chain_event after the blur (2) / Sobel (3) stage of the part being enqueued
     hipEvent_t chain_event = nullptr;
     Tuning tune;                       // aej_set_option: kernel / launch-shape choices (nothing in the library reads the environment)
@@ -924,7 +925,7 @@ static int enqueue_part(aej_ctx *ctx, EncodePart &p, const QtGeom &q, const void
     // one stage behind the part enqueued before this one (g_last_color_done): its colour stage (HBM-bound) has finished, its blur
     // (issue-bound) is starting
     const bool chain = ctx->sub_chain && done && !ctx->profiling;
-    const int chain_mode = ctx->sub_chain > 0 ? ctx->sub_chain : (p.whole_call ? 2 : 1);
+    const int chain_mode = ctx->sub_chain > 0 ? ctx->sub_chain : 1;
     if (chain) {
         std::lock_guard<std::mutex> lock(g_chain_mutex);
         if (hipEvent_t after = g_last_color_done[ctx->device]) AEJ_HIP_CHECK(hipStreamWaitEvent(ctx->stream, after, 0));

@@ -124,7 +124,7 @@ AEJ_API int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int32_t
  *   "dct_small_workgroups"  0..65536 (0)       cap on the grids of the 4 / 8 / 16 DCT kernels; 0 = automatic
  *   "sobel_lds"             0 | 1 (0)          1: the LDS-tiled Sobel / NMS kernel for every shape (default: register kernel when w % 4 == 0)
  *   "sub_chain"             -1..3 (-1)         which stage of the previously enqueued part a part's colour stage waits for: 0 none, 1 colour,
- *                                              2 blur, 3 Sobel; -1 = 1 between sub-batches of one call, 2 between whole calls */
+ *                                              2 blur, 3 Sobel; -1 = 1 */
 AEJ_API int aej_set_option(aej_ctx *ctx, const char *name, int64_t value);
 AEJ_API int aej_get_option(aej_ctx *ctx, const char *name, int64_t *value_host);
 /* The two halves of aej_encode_batch / aej_encode_batch_u8 (same arguments; rgb_is_u8 selects the ingest): _begin enqueues the whole
