@@ -74,11 +74,22 @@ constexpr int kMetricSlots = 40;
 constexpr int kMetricSlotGrey = 2;
 constexpr int kMetricSlotScales = 4;
 
+// One unit of DCT work (a leaf) in a per-size, per-plane list segment: 8 bytes.  The plane is NOT stored: a reader finds an item's
+// segment from the per-plane prefix counts anyway, and that IS the plane (round 4: 16-byte entries carried it a second time; on natural
+// images, nearly all 4 x 4 leaves, the lists were half of what the quadtree's emit pass wrote and a ninth of what the 4 x 4 DCT read).
 struct LeafWork {
-    int plane;      // b * 3 + layer
-    int x, y;       // origin in the layer
+    unsigned xy;    // origin in the layer: x | y << 16 (layers are at most 65535 pixels wide / high: make_geom)
     int coef;       // coefficient offset inside the layer's coefficient array
 };
+__host__ __device__ __forceinline__ LeafWork pack_work(int x, int y, int coef)
+{
+    LeafWork w;
+    w.xy = (unsigned)x | ((unsigned)y << 16);
+    w.coef = coef;
+    return w;
+}
+// -> (plane, x, y, coef), the form the kernels work with
+__device__ __forceinline__ int4 unpack_work(int plane, const LeafWork &w) { return make_int4(plane, (int)(w.xy & 0xffffu), (int)(w.xy >> 16), w.coef); }
 
 struct DctTables {
     // per size index k (size = bmin << k)

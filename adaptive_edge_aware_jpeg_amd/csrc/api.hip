@@ -202,6 +202,7 @@ static void fill_clahe_geom(Geom &g)
 static int make_geom(aej_ctx *ctx, int space, int B, int H, int W, Geom &g)
 {
     memset(&g, 0, sizeof g);
+    if (H > 65535 || W > 65535) return fail(ctx, AEJ_ERR_UNSUPPORTED, "image %dx%d: sides above 65535 pixels are not built (leaf origins travel as 16-bit pairs, LeafWork)", H, W);
     g.B = B; g.nl = 3; g.H = H; g.W = W;
     long long off = 0;
     for (int l = 0; l < 3; l++) {
@@ -1259,6 +1260,7 @@ extern "C" int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int 
     if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
     if (!ctx->has_settings) return fail(ctx, AEJ_ERR_STATE, "aej_set_settings has not been called");
     if (H < 1 || W < 1 || layer < 0 || layer > 2 || n_leaves < 0) return fail(ctx, AEJ_ERR_ARG, "bad argument");
+    if (H > 65535 || W > 65535) return fail(ctx, AEJ_ERR_UNSUPPORTED, "plane %dx%d: sides above 65535 pixels are not built", H, W);
     if (n_leaves == 0) return 0;
     if (!norm || !leaves || !coeffs) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));

@@ -120,7 +120,7 @@ __device__ __forceinline__ int4 fetch_item(const DctArgs &a, long long work_stri
     }
     const int b = lo / 3, l = lo - 3 * b;
     const long long idx = (long long)b * work_stride + lt.woff[l] + (item - s_pref[lo]);
-    return reinterpret_cast<const int4 *>(a.work)[idx];
+    return unpack_work(lo, a.work[idx]);
 }
 
 // The MFMA kernels (one leaf per workgroup and iteration) keep the descriptors of their next leaves in LDS: chunks of kDescChunk
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
             while ((long long)s_pref[p + 1] <= item) p++;      // (item < count = s_pref[nplanes]: p + 1 <= nplanes)
             b = p / 3;
             layer = p - 3 * b;
-            cur = reinterpret_cast<const int4 *>(a.work)[(long long)b * wstride + lt.woff[layer] + (item - s_pref[p])];
+            cur = unpack_work(p, a.work[(long long)b * wstride + lt.woff[layer] + (item - s_pref[p])]);
             const int w = lt.w[layer], h = lt.h[layer];
             const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
             const int hc = min(4, h - cur.z), wc = min(4, w - cur.y);
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a,
             if ((long long)rfl(s_pref[mid]) <= it) lo = mid; else hi = mid;
         }
         const int b = lo / 3, l = lo - 3 * b;
-        return reinterpret_cast<const int4 *>(a.work)[(long long)b * wstride + lt.woff[l] + (it - rfl(s_pref[lo]))];
+        return unpack_work(lo, a.work[(long long)b * wstride + lt.woff[l] + (it - rfl(s_pref[lo]))]);
     };
     auto load_x = [&](const int4 &d, float (&x)[4]) {      // d scalar
         const int b = d.x / 3, layer = d.x - b * 3;
@@ -764,7 +764,7 @@ extern "C" __attribute__((visibility("default"))) int aej_debug_read_stamps(long
 #endif
 
 template <int S, bool WANT_DCT>
-__device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const int4 *__restrict__ work /* = a.work, read-only: scalar loads */)
+__device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const LeafWork *__restrict__ work /* = a.work, read-only: scalar loads */)
 {
     using C = MfmaCfg<S>;
     constexpr int NT = C::NT, TPW = C::TPW, NWAVES = C::NWAVES, NTHREADS = C::NTHREADS;
@@ -972,7 +972,7 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
 // the kernel proper is a shell around the leaf loop above: with the arguments reaching the loop by reference the compiler's schedule of the
 // 64 x 64 instantiation needs 128 vector registers instead of 146 (no spills either way), i.e. a 128- instead of a 152-register allocation
 template <int S, bool WANT_DCT>
-__global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items, const int4 *__restrict__ work)
+__global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items, const LeafWork *__restrict__ work)
 {
     dct_mfma_leaves<S, WANT_DCT>(g, q, a, max_items, work);
 }
@@ -1028,7 +1028,7 @@ __device__ __forceinline__ Wave64B wave64_b(const Wave64Lds &L, int s0, int lane
 
 template <bool WANT_DCT>
 __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom q, DctArgs a, long long max_items,
-                                                                 const int4 *__restrict__ work /* = a.work, read-only: scalar loads */)
+                                                                 const LeafWork *__restrict__ work /* = a.work, read-only: scalar loads */)
 {
     constexpr int S = 64;
     __shared__ Wave64Lds L;
@@ -1112,9 +1112,9 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
         const long long woff = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(lw >> 32)) << 32) |
                                            (unsigned)__builtin_amdgcn_readfirstlane((int)lw));
         const long long idx = (long long)b * wstride + woff + (long long)(it - __builtin_amdgcn_readfirstlane(s_pref[pl]));
-        const int4 d = work[idx];          // a scalar load (counted by lgkmcnt): it does not wait for the vector loads and stores in flight
-        return LeafU{ __builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z),
-                      __builtin_amdgcn_readfirstlane(d.w) };
+        const LeafWork d = work[idx];      // a scalar load (counted by lgkmcnt): it does not wait for the vector loads and stores in flight
+        const unsigned xy = (unsigned)__builtin_amdgcn_readfirstlane((int)d.xy);
+        return LeafU{ pl, (int)(xy & 0xffffu), (int)(xy >> 16), __builtin_amdgcn_readfirstlane(d.coef) };
     };
     float xr[2][32];
     // Lane li of an A operand carries column pli, a permutation inside each group of eight (8 g + 4 h + j -> 8 g + 2 j + h): the MFMA
@@ -1384,7 +1384,7 @@ static void launch_dct64_wave(hipStream_t st, const Geom &g, const QtGeom &q, co
     const long long want = (max_items + kW64Waves - 1) / kW64Waves;
     const int blocks = (int)(want < 1 ? 1 : want > cus ? cus : want);
     hipLaunchKernelGGL((k_dct64_wave<WANT_DCT>), dim3(blocks), dim3(kW64Waves * 64), pref, st, g, q, a, max_items,
-                       reinterpret_cast<const int4 *>(a.work));
+                       a.work);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1401,7 +1401,7 @@ __global__ __launch_bounds__(256) void k_work_from_leaves(const int *__restrict_
     int k = (31 - __clz(lf.z)) - bmin_log2;
     if (k < 0 || k >= kMaxSizes || !wp.w[k]) return;
     int pos = atomicAdd(&work_count[plane * kMaxSizes + k], 1);
-    reinterpret_cast<int4 *>(wp.w[k])[pos] = make_int4(plane, lf.x, lf.y, lf.w);
+    wp.w[k][pos] = pack_work(lf.x, lf.y, lf.w);
 }
 
 void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int bmin, int plane, LeafWork *const *work, int *work_count)
@@ -1437,7 +1437,7 @@ static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const 
     }
     const int blocks = (int)(max_items < slots ? (max_items < 1 ? 1 : max_items) : slots);
     hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(MfmaCfg<S>::NTHREADS), lds, st, g, q, a, max_items,
-                       reinterpret_cast<const int4 *>(a.work));
+                       a.work);
 }
 
 int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const Tuning &t)

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_work_from_tables(Geom g, QtGeom q, cons
         }
         if (k >= 0) {
             const long long cap = (l < 2 ? q.work_off[l + 1][k] : q.work_stride[k]) - q.work_off[l][k];      // this plane's segment of the list
-            if (pos < cap) reinterpret_cast<int4 *>(wp.w[k])[(long long)b * q.work_stride[k] + q.work_off[l][k] + pos] = make_int4(plane, lf.x, lf.y, lf.w);
+            if (pos < cap) wp.w[k][(long long)b * q.work_stride[k] + q.work_off[l][k] + pos] = pack_work(lf.x, lf.y, lf.w);
             else *bad = 1;
         }
     }
@@ -103,7 +103,7 @@ __device__ __forceinline__ int4 fetch_item_d(const IdctArgs &a, long long work_s
         if ((long long)s_pref[mid] <= item) lo = mid; else hi = mid;
     }
     const int b = lo / 3, l = lo - 3 * b;
-    return reinterpret_cast<const int4 *>(a.work)[(long long)b * work_stride + lt.woff[l] + (item - s_pref[lo])];
+    return unpack_work(lo, a.work[(long long)b * work_stride + lt.woff[l] + (item - s_pref[lo])]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_qt_emit(Geom g, QtGeom q, QtBuffers qb)
                     long long pos = (long long)coff[4 + k] + (k == 0 ? rank0 : rank_big);
                     long long seg = (long long)b * q.work_stride[k] + q.work_off[l][k];
                     if (seg + pos < qb.work_cap[k])
-                        reinterpret_cast<int4 *>(qb.work[k])[seg + pos] = make_int4(b * 3 + l, cx * q.cell, cy * q.cell, coef_pos);
+                        qb.work[k][seg + pos] = pack_work(cx * q.cell, cy * q.cell, coef_pos);
                     else
                         *qb.overflow = 1;
                     if (k == 0) rank0++;
