@@ -147,7 +147,8 @@ AEJ_API const char *aej_stage_name(int stage);
  * Zigzag orders (jpeg.py:726-766) and DCT bases are derived inside the library. */
 AEJ_API int aej_set_settings(aej_ctx *ctx, int space, int bmin, int bmax, const int32_t *qmats_host);
 
-/* ---- whole path: Jpeg.compress up to and including the zigzag gather (jpeg.py:262-270, 579-588) -- */
+/* ---- whole path: Jpeg.compress up to and including the zigzag gather (jpeg.py:262-270, 579-588) --
+ * Any image size up to 65535 pixels a side (AEJ_ERR_UNSUPPORTED above; the reference has no limit of its own), at most 1024 images a call. */
 AEJ_API int aej_encode_plan(aej_ctx *ctx, int batch, int H, int W, aej_plan *plan_host);
 
 /* rgb: [batch][H][W][3] float32 in [0,1] (Image.data, image.py:26-36).
