@@ -238,3 +238,23 @@ def test_deflate_tables_and_reference_encoder_round_trip_through_zlib():
     skew = [2 ** i for i in range(30)]
     ls = DT.huffman_lengths(skew, 15)
     assert max(ls) <= 15 and sum(2.0 ** -l for l in ls) <= 1.0 + 1e-12
+
+
+def test_bench_asks_for_more_hardware_queues_when_it_will_hold_a_process_group(monkeypatch):
+    """A live RCCL communicator creates streams of its own; with the 16 queues a lone process uses it pushed the library's streams onto
+    shared queues (13 % of the step, profiles/r04_rccl_hw_queues.txt): a process that will hold a process group asks for 24 (and creates
+    the communicator after its own streams -- bench.init_distributed passes no device_id)."""
+    import importlib
+    import inspect
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    monkeypatch.delenv("AEJ_BENCH_FORCE_DIST", raising=False)
+    assert bench.hw_queue_default(1) == "16" and bench.hw_queue_default(2) == "24" and bench.hw_queue_default(8) == "24"
+    monkeypatch.setenv("AEJ_BENCH_FORCE_DIST", "1")
+    assert bench.hw_queue_default(1) == "24"
+    src = inspect.getsource(bench.init_distributed)
+    eager = src.index('AEJ_BENCH_NCCL_EAGER')
+    assert "device_id" in src[eager:src.index("else:", eager)] and "device_id" not in src[src.index("else:", eager):]      # only the A / B switch binds the device early

@@ -81,8 +81,11 @@ def test_bench_multi_rank_control_flow_rehearsal(extra, scaling, images):
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
-    json_lines = [[ln for ln in o[0].splitlines() if ln.startswith("{")] for o in outs]      # gloo itself chats on stdout
+    json_lines = [[ln for ln in o[0].splitlines() if ln.startswith("{")] for o in outs]
     assert len(json_lines[0]) == 1 and json_lines[1] == []           # only rank 0 prints the result line
+    # ... and NOTHING else reaches stdout: bench.py points file descriptor 1 at stderr (gloo chats there, RCCL prints a banner there) and
+    # writes its line to a saved copy of the real stdout
+    assert outs[0][0].strip() == json_lines[0][0] and outs[1][0].strip() == "", [o[0][-500:] for o in outs]
     line = json.loads(json_lines[0][0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == scaling
     assert line["pixels_total"] == sum(images) * 100 * 200 * 3       # SUM over ranks
@@ -108,7 +111,7 @@ def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu():
                         "--batch", "3", "--height", "64", "--width", "96"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines) == 1 and r.stdout.strip() == lines[0], r.stdout[-2000:]      # the one JSON line and nothing else, also through the launcher
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks"]["n_ranks_seen"] == 2 and line["ranks"]["local_ranks_seen"] == [0, 1]
     assert line["pixels_total"] == 2 * 3 * 64 * 96 * 2
