@@ -595,3 +595,17 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
     enc = tiny.compress_batch(np.full((1, 4, 4, 3), 0.25, np.float32))
     for l in range(3):
         assert zlib.decompress(tiny.deflate_batch(enc)[0][l]) == enc.layer(0, l)["coeffs"].tobytes()
+
+
+@pytest.mark.gpu
+def test_sides_above_65535_pixels_are_refused_not_wrapped():
+    """Leaf origins travel to the DCT kernels as 16-bit pairs (LeafWork, aej_common.h): a plan for a larger image is refused with
+    AEJ_ERR_UNSUPPORTED (NotImplementedError here) instead of being computed with wrapped coordinates; 65535 itself is planned."""
+    import adaptive_edge_aware_jpeg_amd as A
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    ctx = codec._bind()
+    for H, W in ((65536, 16), (16, 70000)):
+        with pytest.raises(NotImplementedError):
+            ctx.plan(1, H, W)
+    p = ctx.plan(1, 16, 65535 // 4 * 4)
+    assert p.W == 65535 // 4 * 4 and p.workspace_bytes > 0
