@@ -21,8 +21,12 @@
 
 namespace aej {
 
-constexpr int kDefSub = 128;                      // input bytes per thread (256 bytes per thread = half the waves per CU for the same LDS)
-constexpr int kDefThreads = 256;
+// Input bytes per thread.  A match cannot leave its sub-block, so longer sub-blocks compress better (runs of zero coefficients): 256 bytes
+// instead of 128 is -13 % on sparse layers and -3 % on natural images (512 adds little) -- but a 32 KiB block then has 128 threads, half the
+// waves per CU for the same LDS, and the three passes take 4.7 instead of 1.9 ms per 400 MB (profiles/r04_deflate_kernels.txt).  The
+// stage exists for speed: 128.  (deflate_tables.SUB is the Python restatement's copy of this constant; 128 and 256 are both built.)
+constexpr int kDefSub = 128;
+constexpr int kDefThreads = 32768 / kDefSub;
 constexpr int kDefChunk = kDefSub * kDefThreads;  // 32 KiB of input per workgroup
 constexpr int kDefSubStride = kDefSub + 4;        // LDS stride of a sub-block: 65 dwords, so equal offsets of different threads fall into different banks
 constexpr int kDefOutWords = (kDefChunk * 9 / 8 + 64) / 4;      // fixed code: a literal costs at most 9 bits; a block whose dynamic code needs more falls back to it
@@ -76,37 +80,91 @@ struct BitSink {
 };
 
 // Greedy parse of one sub-block of n bytes at stream position gpos: at every position the longer of the runs "equal to the byte one /
-// four positions back" (clipped to the sub-block and to 258) becomes a match when it is at least 3 long, else the byte is a literal.
+// four positions back" (clipped to the sub-block) becomes a match when it is at least 3 long, else the byte is a literal.
 // `left4` holds the four bytes before the sub-block (byte k = position k - 4).  What happens to a token is the visitor's business:
 //   lit(byte)   /   match(length symbol, extra value, extra bits, distance-is-4)
+//
+// The runs come from two 128-bit masks -- bit p of E1 / E4 = "byte p equals the byte one / four positions before it" -- built once per
+// sub-block from its 32 dwords with whole-word arithmetic; the run that starts at p is then the number of consecutive ones from bit p
+// (a shift and a count-trailing-zeros).  The first version walked the runs byte by byte: the lanes of a wave sit in runs of very
+// different lengths, every step of the token loop cost the longest run among 64 lanes, and the three passes took 13.4 ms per 400 MB
+// (profiles/r04_deflate_kernels.txt).
+struct SubMasks { unsigned long long e1[kDefSub / 64], e4[kDefSub / 64]; };
+static_assert(kDefSub == 128 || kDefSub == 256, "two or four mask words");
+
+__device__ __forceinline__ unsigned zero_byte_nibble(unsigned x)      // bit k = "byte k of x is zero"
+{
+    unsigned t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    t = ~(t | x | 0x7f7f7f7fu);                      // 0x80 in every zero byte, exact (no borrow between bytes)
+    return ((t >> 7) * 0x01020408u) >> 24;           // the four flags (bits 0, 8, 16, 24) gathered into bits 0..3
+}
+
+__device__ __forceinline__ SubMasks deflate_masks(const unsigned *subw /* kDefSub / 4 dwords, LDS */, unsigned left4, long long gpos)
+{
+    SubMasks m;
+#pragma unroll
+    for (int k = 0; k < kDefSub / 64; k++) { m.e1[k] = 0ull; m.e4[k] = 0ull; }
+    unsigned prev = left4;
+#pragma unroll
+    for (int i = 0; i < kDefSub / 4; i++) {          // (fully unrolled: the word index i / 16 is a constant, the masks stay in registers)
+        const unsigned w = subw[i];
+        const unsigned long long n4 = zero_byte_nibble(w ^ prev);                              // byte k against the byte four back
+        const unsigned long long n1 = zero_byte_nibble(w ^ ((w << 8) | (prev >> 24)));         // byte k against the byte before it
+        m.e4[i / 16] |= n4 << (4 * (i % 16));
+        m.e1[i / 16] |= n1 << (4 * (i % 16));
+        prev = w;
+    }
+    if (gpos == 0) { m.e1[0] &= ~1ull; m.e4[0] &= ~15ull; }      // nothing lies before the first bytes of a stream
+    return m;
+}
+
+// consecutive ones of the kDefSub-bit mask from bit p (the word is picked by compares: no indexed register access)
+__device__ __forceinline__ int ones_from(const unsigned long long (&m)[kDefSub / 64], int p)
+{
+    if constexpr (kDefSub == 128) {                 // two words: branch-free (0.35 / 0.44 / 0.92 ms for the three passes against 0.48 / 0.63 / 1.24 with the loop)
+        unsigned long long a, b;
+        if (p < 64) { a = p ? (m[0] >> p) | (m[1] << (64 - p)) : m[0]; b = m[1] >> p; }
+        else { a = m[1] >> (p - 64); b = 0ull; }
+        const unsigned long long na = ~a, nb = ~b;
+        return na ? __builtin_ctzll(na) : 64 + (nb ? __builtin_ctzll(nb) : 64);
+    }
+    int run = 0;
+    while (p < kDefSub) {
+        const int k = p >> 6, s = p & 63;
+        unsigned long long word = m[0];
+#pragma unroll
+        for (int j = 1; j < kDefSub / 64; j++) word = k == j ? m[j] : word;
+        const unsigned long long inv = ~(word >> s);             // (the zeros shifted in at the top end the count at the word's edge)
+        const int avail = 64 - s;
+        const int ones = inv ? __builtin_ctzll(inv) : 64;
+        if (ones < avail) return run + ones;
+        run += avail;
+        p += avail;
+    }
+    return run;
+}
+
 template <typename V>
 __device__ __forceinline__ void deflate_parse(const unsigned char *sub, unsigned left4, int n, long long gpos, V &&visit)
 {
-    auto at = [&](int i) -> unsigned { return i >= 0 ? (unsigned)sub[i] : (left4 >> (8 * (i + 4))) & 0xffu; };      // i >= -4
+    const SubMasks m = deflate_masks(reinterpret_cast<const unsigned *>(sub), left4, gpos);
     int p = 0;
     while (p < n) {
-        const unsigned b = sub[p];
-        int l1 = 0, l4 = 0;
-        if (gpos + p >= 1 && b == at(p - 1)) {
-            l1 = 1;
-            while (p + l1 < n && l1 < 258 && sub[p + l1] == b) l1++;
-        }
-        if (gpos + p >= 4 && l1 < 258 && b == at(p - 4)) {
-            l4 = 1;
-            while (p + l4 < n && l4 < 258 && sub[p + l4] == at(p + l4 - 4)) l4++;
-        }
+        const int room = n - p;
+        int l1 = ones_from(m.e1, p), l4 = ones_from(m.e4, p);
+        l1 = l1 < room ? l1 : room;
+        l4 = l4 < room ? l4 : room;
         const int L = l1 >= l4 ? l1 : l4;
         if (L >= 3) {
             const int l = L - 3;
             int sym, e = 0;
             unsigned extra = 0;
-            if (L == 258) sym = 285;
-            else if (l < 8) sym = 257 + l;
+            if (l < 8) sym = 257 + l;
             else { e = 29 - __clz(l); sym = 257 + 4 * (e + 1) + ((l >> e) & 3); extra = (unsigned)l & ((1u << e) - 1u); }
             visit.match(sym, extra, e, l4 > l1);
             p += L;
         } else {
-            visit.lit((int)b);
+            visit.lit((int)sub[p]);
             p++;
         }
     }
@@ -119,11 +177,20 @@ __device__ __forceinline__ unsigned fixed_dist_entry(bool four) { return (four ?
 struct CountBits {               // bits of the tokens under the fixed code and under the table's code
     const unsigned *tab;         // LDS copy of the layer's table, or null
     int fixed = 0, dyn = 0;
-    __device__ __forceinline__ void lit(int b) { fixed += (int)(fixed_entry(b) >> 16); if (tab) dyn += (int)(tab[b] >> 16); }
+    bool missing = false;        // a token has no code in the table (a table counted on other data): the chunk takes the fixed code
+    __device__ __forceinline__ void lit(int b)
+    {
+        fixed += (int)(fixed_entry(b) >> 16);
+        if (tab) { const int nb = (int)(tab[b] >> 16); dyn += nb; missing = missing || nb == 0; }
+    }
     __device__ __forceinline__ void match(int sym, unsigned, int e, bool four)
     {
         fixed += (int)(fixed_entry(sym) >> 16) + e + 5;
-        if (tab) dyn += (int)(tab[sym] >> 16) + e + (int)(tab[286 + (four ? 1 : 0)] >> 16);
+        if (tab) {
+            const int nb = (int)(tab[sym] >> 16), nd = (int)(tab[286 + (four ? 1 : 0)] >> 16);
+            dyn += nb + e + nd;
+            missing = missing || nb == 0 || nd == 0;
+        }
     }
 };
 struct CountSymbols {            // histogram of the tokens (LDS)
@@ -232,10 +299,21 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_sizes(DeflateStreams S)
     unsigned a = 0, m = 0;
     if (n > 0) {
         deflate_parse(sub, deflate_left4(sIn, sub, tid), n, c0 + (long long)tid * kDefSub, cnt);
-        for (int j = 0; j < n; j++) { a += sub[j]; m += (unsigned)j * sub[j]; }
+        // sum of the bytes and sum of j * byte[j], a dword at a time (bytes past n are not part of the stream: masked off)
+        const unsigned *subw = reinterpret_cast<const unsigned *>(sub);
+#pragma unroll
+        for (int i = 0; i < kDefSub / 4; i++) {
+            unsigned w = subw[i];
+            const int left = n - 4 * i;
+            if (left < 4) w = left > 0 ? w & ((1u << (8 * left)) - 1u) : 0u;
+            const unsigned sum = __builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
+            a += sum;
+            m += (unsigned)(4 * i) * sum + __builtin_amdgcn_udot4(w, 0x03020100u, 0u, false);
+        }
     }
     // the last thread also writes the end-of-block symbol
-    if (tid == kDefThreads - 1) { cnt.fixed += 7; if (tab) cnt.dyn += (int)(tab[256] >> 16); }
+    if (tid == kDefThreads - 1) { cnt.fixed += 7; if (tab) { cnt.dyn += (int)(tab[256] >> 16); cnt.missing = cnt.missing || (tab[256] >> 16) == 0; } }
+    const int any_missing = __syncthreads_or(cnt.missing ? 1 : 0);
     // chunk totals: bits under either code, sum of bytes, sum of (len - i) * byte = sum_t [(len - o_t) * a_t - m_t]
     unsigned long long w = n > 0 ? (unsigned long long)(len - tid * kDefSub) * a - m : 0ull;
     unsigned vf = (unsigned)cnt.fixed, vd = (unsigned)cnt.dyn, va = a, vw = (unsigned)(w % kAdlerMod);
@@ -248,7 +326,7 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_sizes(DeflateStreams S)
         // block header + tokens + end of block, then the header of the empty stored block; the dynamic code only when it is smaller AND the
         // block fits the emit kernel's LDS buffer (a chunk the layer's code does not suit can cost up to 15 bits per byte)
         const unsigned bits_fixed = 3u + tf + 3u, bits_dyn = tab ? tab[288] + td + 3u : 0xffffffffu;
-        const bool use_fixed = !tab || bits_fixed <= bits_dyn || (bits_dyn + 7u) / 8u + 4u > (unsigned)(kDefOutWords * 4);
+        const bool use_fixed = !tab || any_missing || bits_fixed <= bits_dyn || (bits_dyn + 7u) / 8u + 4u > (unsigned)(kDefOutWords * 4);
         sUseFixed = use_fixed ? 1 : 0;
         S.chunk_fixed[slot] = use_fixed ? 1 : 0;
         S.chunk_bytes[slot] = (int)(((use_fixed ? bits_fixed : bits_dyn) + 7u) / 8u) + 4;    // ... padded to a byte, LEN = 0000, NLEN = FFFF

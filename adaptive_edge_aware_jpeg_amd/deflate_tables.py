@@ -24,12 +24,19 @@ TABLE_WORDS = 289 + HEADER_WORDS
 CL_ORDER = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]      # RFC 1951 3.2.7
 
 
+_REV15 = None
+
+
 def _rev(code, n):
-    r = 0
-    for _ in range(n):
-        r = (r << 1) | (code & 1)
-        code >>= 1
-    return r
+    """the n-bit code with its bits in reverse order (the stream is LSB first, Huffman codes go in MSB first)"""
+    global _REV15
+    if _REV15 is None:                       # all 15-bit reversals, built once (vectorised)
+        v = np.arange(1 << 15, dtype=np.uint32)
+        r = np.zeros_like(v)
+        for b in range(15):
+            r |= ((v >> b) & 1) << (14 - b)
+        _REV15 = r.tolist()
+    return _REV15[code] >> (15 - n) if n else 0
 
 
 def huffman_lengths(counts, limit):
@@ -43,24 +50,27 @@ def huffman_lengths(counts, limit):
     if len(used) == 1:
         lengths[used[0]] = 1
         return lengths
-    heap = [(counts[i], i, None, None) for i in used]
-    heapq.heapify(heap)
-    nxt = len(counts)
-    nodes = {}
-    while len(heap) > 1:
-        a = heapq.heappop(heap)
-        b = heapq.heappop(heap)
-        nodes[nxt] = (a[1], b[1])
-        heapq.heappush(heap, (a[0] + b[0], nxt, None, None))
+    # two-queue construction: leaves sorted by (count, symbol), internal nodes appear in non-decreasing weight order
+    leaves = sorted(used, key=lambda i: (counts[i], i))
+    n = len(leaves)
+    weight = [counts[i] for i in leaves] + [0] * (n - 1)      # nodes 0 .. n-1 = leaves (in sorted order), n .. 2n-2 = internal
+    parent = [0] * (2 * n - 1)
+    li, ii, nxt = 0, n, n
+    while nxt < 2 * n - 1:
+        picked = []
+        for _ in range(2):
+            if li < n and (ii >= nxt or weight[li] <= weight[ii]):
+                picked.append(li); li += 1
+            else:
+                picked.append(ii); ii += 1
+        weight[nxt] = weight[picked[0]] + weight[picked[1]]
+        parent[picked[0]] = parent[picked[1]] = nxt
         nxt += 1
-    stack = [(heap[0][1], 0)]
-    while stack:
-        n, d = stack.pop()
-        if n in nodes:
-            stack.append((nodes[n][0], d + 1))
-            stack.append((nodes[n][1], d + 1))
-        else:
-            lengths[n] = max(d, 1)
+    depth = [0] * (2 * n - 1)
+    for node in range(2 * n - 3, -1, -1):                        # parents have larger indices: depths top-down
+        depth[node] = depth[parent[node]] + 1
+    for k, i in enumerate(leaves):
+        lengths[i] = max(depth[k], 1)
     for i in used:
         lengths[i] = min(lengths[i], limit)
     kraft = sum(1 << (limit - lengths[i]) for i in used)
@@ -141,12 +151,23 @@ def fixed_table():
     return _pack(lit, [(0, 5), (3, 5)], h)
 
 
-def adaptive_table(litlen_hist, dist_hist):
+def adaptive_table(litlen_hist, dist_hist, cover_all=True):
     """litlen_hist: counts of the 286 literal / length symbols over the blocks that will use the table (the end-of-block symbol is added
-    here); dist_hist: counts of distance symbols 0 (distance 1) and 3 (distance 4)."""
-    # every symbol gets a code (count + 1): a table is then valid for ANY input, whatever it was counted on -- the cost is a 15-bit code
-    # for symbols that never occur and ~100 bytes of header per 32 KiB block
-    ll = [int(c) + 1 for c in litlen_hist[:N_LITLEN]]
+    here); dist_hist: counts of distance symbols 0 (distance 1) and 3 (distance 4).
+
+    ``cover_all`` (default): every symbol gets a code (count + 1), so the table is valid for ANY input, whatever it was counted on -- at
+    the cost of a 15-bit code for symbols that never occur and ~100 bytes of header per 32 KiB block.  ``cover_all=False``: only the
+    symbols that occur (and the end-of-block symbol) get codes -- for a table that is used on exactly the data it was counted on, as
+    ``Jpeg.deflate_batch`` does (same parser, same data: the kernels fall back to the fixed code for any block that would need a missing
+    code, so a mismatch costs size, never correctness); the header shrinks to 40-60 bytes, which is 13 % of the output on very
+    compressible data."""
+    if cover_all:
+        ll = [int(c) + 1 for c in litlen_hist[:N_LITLEN]]
+    else:
+        ll = [int(c) for c in litlen_hist[:N_LITLEN]]
+        ll[256] = max(ll[256], 1)                              # end of block
+        if sum(1 for c in ll if c) < 2:                        # (a complete code needs two symbols)
+            ll[0 if ll[0] == 0 else 1] = 1
     ll_len = huffman_lengths(ll, 15)
     # both distance symbols always get a code (a block may use either), one bit each: lengths 1, 0, 0, 1 are a complete code
     d_len = [1, 0, 0, 1]
@@ -195,7 +216,7 @@ def adaptive_table(litlen_hist, dist_hist):
 
 
 # ---- pure-Python restatement of the kernels (CPU tests only; small inputs) ------------------------------------------------------------
-SUB, CHUNK = 128, 128 * 256
+SUB, CHUNK = 128, 32768                 # bytes a thread parses on its own (csrc/deflate.hip kDefSub: keep the two equal); bytes per deflate block
 
 
 def _length_symbol(L):

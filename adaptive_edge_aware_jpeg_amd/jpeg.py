@@ -241,37 +241,48 @@ class Jpeg:
         return len(mb).to_bytes(4, byteorder="big") + mb
 
     @staticmethod
-    def _layer_bytes(L, zlib_level: int = 9, stream: Optional[bytes] = None) -> bytes:
-        """One layer record of the container (jpeg.py:561-595): state bits, root size, zlib-9 of the int32 coefficients
-        (``zlib_level`` other than the reference's 9 is an opt-in: any level gives a stream the reference's ``zlib.decompress`` reads)."""
+    def _layer_pieces(L, zlib_level: int = 9, stream=None) -> tuple:
+        """The pieces of one layer record of the container (jpeg.py:561-595): state bits, root size, zlib-9 of the int32 coefficients
+        (``zlib_level`` other than the reference's 9 is an opt-in: any level gives a stream the reference's ``zlib.decompress`` reads).
+        ``stream``: the finished zlib stream (bytes or a buffer view), when it was written elsewhere."""
         st = L["states"]
         bits_len = 2 * len(st)
         pad = (-len(st)) % 4
         quad = np.concatenate([st, np.zeros(pad, np.uint8)]).reshape(-1, 4)
         packed = ((quad[:, 0] << 6) | (quad[:, 1] << 4) | (quad[:, 2] << 2) | quad[:, 3]).astype(np.uint8)
         comp = stream if stream is not None else zlib.compress(np.ascontiguousarray(L["coeffs"], dtype=np.int32).tobytes(), level=zlib_level)
-        return b"".join((bits_len.to_bytes(4, byteorder="big"), int(L["root_size"]).to_bytes(4, byteorder="big"), packed.tobytes(),
-                         len(comp).to_bytes(4, byteorder="big"), comp))
+        return (bits_len.to_bytes(4, byteorder="big"), int(L["root_size"]).to_bytes(4, byteorder="big"), packed.tobytes(),
+                len(comp).to_bytes(4, byteorder="big"), comp)
+
+    @staticmethod
+    def _layer_bytes(L, zlib_level: int = 9, stream=None) -> bytes:
+        return b"".join(Jpeg._layer_pieces(L, zlib_level, stream))
 
     def _entropy_encode(self, layers) -> bytes:
         return self._header_bytes(len(layers)) + b"".join(self._layer_bytes(L) for L in layers)
 
-    def deflate_batch(self, enc: EncodedBatch, adaptive: bool = True) -> List[List[bytes]]:
+    def deflate_batch(self, enc: EncodedBatch, adaptive: bool = True, as_views: bool = False, tables: Optional[np.ndarray] = None) -> List[List[bytes]]:
         """OPT-IN GPU entropy stage (``aej_deflate_batch``, csrc/deflate.hip): the zlib stream of every layer of an encoded batch, written
         on the GPU -- Huffman-coded deflate blocks with matches at distances 1 and 4, which ``zlib.decompress`` (the reference's decoder,
         jpeg.py:659) reads like any other stream.  ``adaptive``: one dynamic Huffman code per layer, built here on the host
         (``deflate_tables.adaptive_table``) from the symbol histogram the GPU counts (a 3.5 KB round trip); otherwise RFC 1951's fixed code.
-        Only the compressed bytes cross to the host.  -> [image][layer] bytes."""
+        Only the compressed bytes cross to the host.  -> [image][layer] bytes (``as_views``: memoryviews into the one host buffer the
+        device-to-host copy filled, for callers that assemble larger records and want no intermediate copy; ``tables``: use these codes
+        instead of counting -- a block that needs a symbol they have no code for is written with the fixed code)."""
         from . import deflate_tables as DT
         ctx = self._bind()
         t = ctx.torch
         p = enc.plan
-        tables = None
-        if adaptive:
+        if tables is not None:                 # caller-built codes ([3][deflate_tables.TABLE_WORDS] uint32), e.g. kept from an earlier batch
+            tables = ctx.to_device(np.ascontiguousarray(tables, dtype=np.uint32).view(np.int32), t.int32)
+        elif adaptive:
             hist = ctx.empty((3, 288), t.int32)
             ctx.check(ctx.lib.aej_deflate_histogram(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W, hist.data_ptr()))
             h = hist.cpu().numpy()
-            tables = ctx.to_device(np.stack([DT.adaptive_table(h[l, :286], h[l, 286:288]) for l in range(3)]).view(np.int32), t.int32)
+            # few distinct symbols (sparse layers): codes for exactly those, a 40-byte block header instead of 55 and 2-4 % smaller streams;
+            # otherwise the cover-everything code (natural images use nearly every symbol: the two are the same size there)
+            tables = ctx.to_device(np.stack([DT.adaptive_table(h[l, :286], h[l, 286:288], cover_all=int((h[l, :286] > 0).sum()) >= 128)
+                                             for l in range(3)]).view(np.int32), t.int32)
         cap = max((p.coeff_off[l + 1] if l < 2 else p.coeff_stride) - p.coeff_off[l] for l in range(3))
         stride = int(ctx.lib.aej_deflate_stream_bound(ctypes.c_uint64(4 * cap)))
         stride = (stride + 255) // 256 * 256
@@ -289,7 +300,9 @@ class Jpeg:
         for i in range(n):
             packed[int(off[i]):int(off[i + 1])] = streams[i, :int(sz[i])]
         host = packed.cpu().numpy()
-        return [[host[int(off[3 * b + l]):int(off[3 * b + l + 1])].tobytes() for l in range(3)] for b in range(p.batch)]
+        view = memoryview(host)
+        cut = (lambda a, b: view[a:b]) if as_views else (lambda a, b: host[a:b].tobytes())
+        return [[cut(int(off[3 * b + l]), int(off[3 * b + l + 1])) for l in range(3)] for b in range(p.batch)]
 
     def compress_many(self, batch, extension: Optional[str] = None, workers: Optional[int] = None, zlib_level: int = 9,
                       entropy: str = "host") -> List[bytes]:
@@ -310,16 +323,16 @@ class Jpeg:
         self.extension = extension
         header = self._header_bytes(3)
         if entropy in ("gpu", "gpu-fixed"):
-            streams = self.deflate_batch(enc, adaptive=entropy == "gpu")
+            streams = self.deflate_batch(enc, adaptive=entropy == "gpu", as_views=True)
             cnt = enc.counts_host
             out = []
             for b in range(p.batch):
-                recs = []
+                pieces = [header]
                 for l in range(3):
                     so = b * p.state_stride + p.state_off[l]
                     st = enc.states[so:so + int(cnt[b, l, 2])].cpu().numpy()
-                    recs.append(self._layer_bytes({"states": st, "root_size": int(cnt[b, l, 3])}, stream=streams[b][l]))
-                out.append(header + b"".join(recs))
+                    pieces += self._layer_pieces({"states": st, "root_size": int(cnt[b, l, 3])}, stream=streams[b][l])
+                out.append(b"".join(pieces))            # the one copy of the compressed bytes on the host
             return out
         if entropy != "host":
             raise ValueError("entropy must be 'host', 'gpu' or 'gpu-fixed'")

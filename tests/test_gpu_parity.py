@@ -555,8 +555,17 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
             sizes[adaptive] = sum(len(x) for im in streams for x in im)
         # a block takes the dynamic code only where it is smaller: never larger than all-fixed, but for a table's worth of headers
         assert sizes[True] <= sizes[False] + 64, sizes
-        # the kernels' parse, block layout and Adler-32 are restated in pure Python (deflate_tables.encode_reference): same bytes
         from adaptive_edge_aware_jpeg_amd import deflate_tables as DT
+        # codes counted on OTHER data, without codes for symbols that data did not contain (a run of zero coefficients: two literal / length
+        # symbols in all): every block that needs a missing code falls back to the fixed code -- still this batch's bytes, and never smaller
+        # than the all-fixed stream by more than the blocks that could use the foreign code
+        zl, zd = DT.histogram_reference(bytes(4096))
+        foreign = np.stack([DT.adaptive_table(zl, zd, cover_all=False)] * 3)
+        streams_f = codec.deflate_batch(enc, tables=foreign)
+        for b in range(batch.shape[0]):
+            for l in range(3):
+                assert zlib.decompress(streams_f[b][l]) == enc.layer(b, l)["coeffs"].tobytes(), f"{space} image {b} layer {l}: foreign exact table"
+        # the kernels' parse, block layout and Adler-32 are restated in pure Python (deflate_tables.encode_reference): same bytes
         raw0 = enc.layer(0, 2)["coeffs"].tobytes()
         if len(raw0) <= 300000:
             assert codec.deflate_batch(enc, adaptive=False)[0][2] == DT.encode_reference(raw0, DT.fixed_table())

@@ -229,6 +229,15 @@ def test_deflate_tables_and_reference_encoder_round_trip_through_zlib():
         assert int(own[288]) <= DT.HEADER_WORDS * 32 and all(0 < (int(e) >> 16) <= 15 for e in own[:288])
         assert zlib.decompress(DT.encode_reference(data, own)) == data, name
         assert zlib.decompress(DT.encode_reference(data, foreign)) == data, name + " (foreign table)"
+        # exact tables (cover_all=False: what Jpeg.deflate_batch builds -- codes only for the symbols the SAME data contains): valid, and never
+        # larger than the cover-everything table
+        if data:
+            exact = DT.adaptive_table(*DT.histogram_reference(data), cover_all=False)
+            enc_exact = DT.encode_reference(data, exact)
+            assert zlib.decompress(enc_exact) == data, name + " (exact table)"
+            assert len(enc_exact) <= len(DT.encode_reference(data, own)) + 16, name       # (when nearly every symbol occurs the two are the same code)
+            if name in ("sparse", "zeros", "one coefficient"):
+                assert int(exact[288]) < int(own[288]) - 100, name              # few symbols: a shorter block header
     # the adaptive code pays on coefficient-like data: well below the fixed code, within 1.5 x of zlib level 9
     d = cases["dense"]
     own = DT.adaptive_table(*DT.histogram_reference(d))

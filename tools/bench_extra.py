@@ -83,10 +83,14 @@ def end_to_end(torch, bench, A, codec, args, dev, H, W):
     streams = codec.deflate_batch(enc2)
     t_def = time.perf_counter() - t0
     assert _z.decompress(streams[0][0]) == enc2.layer(0, 0)["coeffs"].tobytes()
-    t0 = time.perf_counter()
-    gpu_blobs = codec.compress_many(x, extension=".png", entropy="gpu")
-    dtg = time.perf_counter() - t0
-    res["compress_many_gpu_entropy"] = {"s": round(dtg, 4), "MP/s": round(mp / dtg, 1), "bytes_out": int(sum(len(b) for b in gpu_blobs)),
+    runs = []
+    for _ in range(5):                                        # one call is ~10 ms of mostly host work: the fastest of five, all five reported
+        t0 = time.perf_counter()
+        gpu_blobs = codec.compress_many(x, extension=".png", entropy="gpu")
+        runs.append(time.perf_counter() - t0)
+    dtg = min(runs)
+    res["compress_many_gpu_entropy"] = {"s": round(dtg, 4), "MP/s": round(mp / dtg, 1), "s_of_five_calls": [round(r, 4) for r in runs],
+                                        "bytes_out": int(sum(len(b) for b in gpu_blobs)),
                                         "bits_per_pixel": round(8.0 * sum(len(b) for b in gpu_blobs) / (n * H * W), 3),
                                         "deflate_batch_s": round(t_def, 4), "note": "aej_deflate_batch + device-side compaction + one D2H of the compressed bytes"}
     img = A.Image.from_array(x[0].cpu().numpy(), (H, W, 3), ".png")
