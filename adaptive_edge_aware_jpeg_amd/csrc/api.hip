@@ -1429,6 +1429,15 @@ static int deflate_geometry(aej_ctx *ctx, int batch, int H, int W, QtGeom &q, in
 
 extern "C" uint64_t aej_deflate_stream_bound(uint64_t raw_bytes) { return deflate_stream_bound(raw_bytes); }
 
+// host only (no context, no device): the per-layer dynamic codes from the histograms aej_deflate_histogram counted
+extern "C" int aej_deflate_build_tables(const int32_t *hist_host, const int32_t *cover_all, uint32_t *tables_host)
+{
+    if (!hist_host || !tables_host) return AEJ_ERR_ARG;
+    for (int l = 0; l < 3; l++)
+        if (deflate_build_table_host(hist_host + l * AEJ_DEFLATE_HIST_BINS, cover_all ? cover_all[l] : 1, tables_host + l * AEJ_DEFLATE_TABLE_WORDS)) return AEJ_ERR_CAPACITY;
+    return 0;
+}
+
 extern "C" uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, int W)
 {
     QtGeom q;

@@ -19,6 +19,9 @@
 #include "aej_launch.h"
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 namespace aej {
 
 // Input bytes per thread.  A match cannot leave its sub-block, so longer sub-blocks compress better (runs of zero coefficients): 256 bytes
@@ -436,6 +439,159 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_emit(DeflateStreams S)
     const unsigned nout = body + 4u;
     unsigned char *dst = S.out + (unsigned long long)s * S.stream_stride + S.chunk_bytes[slot];
     for (unsigned i = tid; i < nout; i += kDefThreads) dst[i] = ob[i];
+}
+
+// ---- host side: the dynamic code of one layer from its symbol histogram -------------------------------------------------------------------
+// The same construction as adaptive_edge_aware_jpeg_amd/deflate_tables.py (adaptive_table / huffman_lengths / canonical_codes), which
+// stays the readable restatement and the test reference: the tables are compared word for word (tests/test_host_logic.py).  In Python
+// the three tables of a call cost 2.7 ms -- a quarter of compress_many(entropy="gpu") -- here tens of microseconds.
+namespace {
+// code lengths of a Huffman code for `counts` (symbols with count 0 get length 0), none longer than `limit`
+std::vector<int> huffman_lengths_host(const std::vector<long long> &counts, int limit)
+{
+    const int ns = (int)counts.size();
+    std::vector<int> lengths((size_t)ns, 0), used;
+    for (int i = 0; i < ns; i++) if (counts[(size_t)i] > 0) used.push_back(i);
+    if (used.empty()) return lengths;
+    if (used.size() == 1) { lengths[(size_t)used[0]] = 1; return lengths; }
+    // two-queue construction: leaves sorted by (count, symbol), internal nodes appear in non-decreasing weight order
+    std::vector<int> leaves = used;
+    std::stable_sort(leaves.begin(), leaves.end(), [&](int a, int b) { return counts[(size_t)a] < counts[(size_t)b]; });      // (stable: ties by symbol)
+    const int n = (int)leaves.size();
+    std::vector<long long> weight((size_t)(2 * n - 1), 0);
+    std::vector<int> parent((size_t)(2 * n - 1), 0), depth((size_t)(2 * n - 1), 0);
+    for (int k = 0; k < n; k++) weight[(size_t)k] = counts[(size_t)leaves[(size_t)k]];
+    int li = 0, ii = n, nxt = n;
+    while (nxt < 2 * n - 1) {
+        int picked[2];
+        for (int t = 0; t < 2; t++) {
+            if (li < n && (ii >= nxt || weight[(size_t)li] <= weight[(size_t)ii])) picked[t] = li++;
+            else picked[t] = ii++;
+        }
+        weight[(size_t)nxt] = weight[(size_t)picked[0]] + weight[(size_t)picked[1]];
+        parent[(size_t)picked[0]] = parent[(size_t)picked[1]] = nxt;
+        nxt++;
+    }
+    for (int node = 2 * n - 3; node >= 0; node--) depth[(size_t)node] = depth[(size_t)parent[(size_t)node]] + 1;
+    for (int k = 0; k < n; k++) lengths[(size_t)leaves[(size_t)k]] = std::max(depth[(size_t)k], 1);
+    // length limit: clamp, then while the Kraft sum exceeds 1 lengthen the rarest symbol that can still be lengthened ...
+    for (int i : used) lengths[(size_t)i] = std::min(lengths[(size_t)i], limit);
+    long long kraft = 0;
+    for (int i : used) kraft += 1LL << (limit - lengths[(size_t)i]);
+    std::vector<int> by_rarity = used;
+    {
+        const std::vector<int> len0 = lengths;          // (the sort key uses the lengths as they are now)
+        std::stable_sort(by_rarity.begin(), by_rarity.end(), [&](int a, int b) {
+            if (counts[(size_t)a] != counts[(size_t)b]) return counts[(size_t)a] < counts[(size_t)b];
+            return len0[(size_t)a] > len0[(size_t)b];
+        });
+    }
+    while (kraft > (1LL << limit)) {
+        for (int i : by_rarity)
+            if (lengths[(size_t)i] < limit) { kraft -= 1LL << (limit - lengths[(size_t)i] - 1); lengths[(size_t)i]++; break; }
+    }
+    // ... and give back what the repair left over to the most frequent symbols
+    std::vector<int> by_count = used;
+    std::stable_sort(by_count.begin(), by_count.end(), [&](int a, int b) { return counts[(size_t)a] > counts[(size_t)b]; });
+    for (int i : by_count)
+        while (lengths[(size_t)i] > 1 && kraft + (1LL << (limit - lengths[(size_t)i])) <= (1LL << limit)) {
+            kraft += 1LL << (limit - lengths[(size_t)i]);
+            lengths[(size_t)i]--;
+        }
+    return lengths;
+}
+
+std::vector<unsigned> canonical_codes_host(const std::vector<int> &lengths)      // RFC 1951 3.2.2
+{
+    int max_len = 0;
+    for (int l : lengths) max_len = std::max(max_len, l);
+    std::vector<int> bl_count((size_t)max_len + 2, 0);
+    for (int l : lengths) if (l) bl_count[(size_t)l]++;
+    std::vector<unsigned> next_code((size_t)max_len + 2, 0), out(lengths.size(), 0);
+    unsigned code = 0;
+    for (int bits = 1; bits <= max_len; bits++) { code = (code + (unsigned)bl_count[(size_t)bits - 1]) << 1; next_code[(size_t)bits] = code; }
+    for (size_t i = 0; i < lengths.size(); i++) if (lengths[i]) out[i] = next_code[(size_t)lengths[i]]++;
+    return out;
+}
+
+unsigned rev_bits(unsigned code, int n) { unsigned r = 0; for (int i = 0; i < n; i++) { r = (r << 1) | (code & 1u); code >>= 1; } return r; }
+
+struct HostBits {
+    std::vector<unsigned> words;
+    int n = 0;
+    void put(unsigned v, int nb)
+    {
+        for (int i = 0; i < nb; i++, n++) {
+            if ((size_t)(n >> 5) >= words.size()) words.push_back(0u);
+            if ((v >> i) & 1u) words[(size_t)(n >> 5)] |= 1u << (n & 31);
+        }
+    }
+    void put_code(unsigned code, int nb) { put(rev_bits(code, nb), nb); }
+};
+}  // namespace
+
+// hist: [288] = 286 literal / length counts, then the matches at distance 1 and 4; table: [kDefTableWords].  cover_all: every symbol gets
+// a code (count + 1); otherwise only those that occur (and end-of-block).  Returns 0, or -1 if the block header would not fit the table.
+int deflate_build_table_host(const int *hist, int cover_all, unsigned *table)
+{
+    constexpr int kLitLen = 286;
+    static const int kClOrder[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+    std::vector<long long> ll((size_t)kLitLen);
+    for (int i = 0; i < kLitLen; i++) ll[(size_t)i] = (long long)hist[i] + (cover_all ? 1 : 0);
+    if (!cover_all) {
+        ll[256] = std::max(ll[256], 1LL);
+        int nused = 0;
+        for (long long c : ll) nused += c > 0;
+        if (nused < 2) ll[ll[0] == 0 ? 0 : 1] = 1;
+    }
+    const std::vector<int> ll_len = huffman_lengths_host(ll, 15);
+    const std::vector<int> d_len = { 1, 0, 0, 1 };
+    const std::vector<unsigned> ll_code = canonical_codes_host(ll_len), d_code = canonical_codes_host(d_len);
+    std::vector<int> seq = ll_len;
+    seq.insert(seq.end(), d_len.begin(), d_len.end());
+    struct ClSym { int s; unsigned extra; int ebits; };
+    std::vector<ClSym> syms;
+    for (size_t i = 0; i < seq.size();) {
+        const int v = seq[i];
+        int run = 1;
+        while (i + (size_t)run < seq.size() && seq[i + (size_t)run] == v) run++;
+        i += (size_t)run;
+        if (v == 0) {
+            while (run >= 11) { const int r = std::min(run, 138); syms.push_back({ 18, (unsigned)(r - 11), 7 }); run -= r; }
+            if (run >= 3) { syms.push_back({ 17, (unsigned)(run - 3), 3 }); run = 0; }
+            for (; run > 0; run--) syms.push_back({ 0, 0u, 0 });
+        } else {
+            syms.push_back({ v, 0u, 0 });
+            run--;
+            while (run >= 3) { const int r = std::min(run, 6); syms.push_back({ 16, (unsigned)(r - 3), 2 }); run -= r; }
+            for (; run > 0; run--) syms.push_back({ v, 0u, 0 });
+        }
+    }
+    std::vector<long long> cl_hist(19, 0);
+    for (const ClSym &c : syms) cl_hist[(size_t)c.s]++;
+    const std::vector<int> cl_len = huffman_lengths_host(cl_hist, 7);
+    const std::vector<unsigned> cl_code = canonical_codes_host(cl_len);
+    int hclen = 19;
+    while (hclen > 4 && cl_len[(size_t)kClOrder[hclen - 1]] == 0) hclen--;
+    HostBits h;
+    h.put(0u, 1);                          // BFINAL = 0
+    h.put(2u, 2);                          // BTYPE = 10
+    h.put((unsigned)(kLitLen - 257), 5);   // HLIT
+    h.put(3u, 5);                          // HDIST: four distance codes
+    h.put((unsigned)(hclen - 4), 4);       // HCLEN
+    for (int k = 0; k < hclen; k++) h.put((unsigned)cl_len[(size_t)kClOrder[k]], 3);
+    for (const ClSym &c : syms) {
+        h.put_code(cl_code[(size_t)c.s], cl_len[(size_t)c.s]);
+        if (c.ebits) h.put(c.extra, c.ebits);
+    }
+    if (h.n > (kDefTableWords - 289) * 32) return -1;
+    for (int i = 0; i < kDefTableWords; i++) table[i] = 0u;
+    for (int i = 0; i < kLitLen; i++) table[i] = rev_bits(ll_code[(size_t)i], ll_len[(size_t)i]) | ((unsigned)ll_len[(size_t)i] << 16);
+    table[286] = rev_bits(d_code[0], d_len[0]) | ((unsigned)d_len[0] << 16);
+    table[287] = rev_bits(d_code[3], d_len[3]) | ((unsigned)d_len[3] << 16);
+    table[288] = (unsigned)h.n;
+    for (size_t w = 0; w < h.words.size(); w++) table[289 + w] = h.words[w];
+    return 0;
 }
 
 unsigned long long deflate_stream_bound(unsigned long long raw_bytes)

@@ -16,7 +16,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import tables
-from ._lib import get_context
+from ._lib import AejError, get_context
 from .image import Image
 from .settings import JpegCompressionSettings
 
@@ -278,11 +278,15 @@ class Jpeg:
         elif adaptive:
             hist = ctx.empty((3, 288), t.int32)
             ctx.check(ctx.lib.aej_deflate_histogram(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W, hist.data_ptr()))
-            h = hist.cpu().numpy()
+            h = np.ascontiguousarray(hist.cpu().numpy(), dtype=np.int32)
             # few distinct symbols (sparse layers): codes for exactly those, a 40-byte block header instead of 55 and 2-4 % smaller streams;
-            # otherwise the cover-everything code (natural images use nearly every symbol: the two are the same size there)
-            tables = ctx.to_device(np.stack([DT.adaptive_table(h[l, :286], h[l, 286:288], cover_all=int((h[l, :286] > 0).sum()) >= 128)
-                                             for l in range(3)]).view(np.int32), t.int32)
+            # otherwise the cover-everything code (natural images use nearly every symbol: the two are the same size there).  The tables come
+            # from the library's host helper -- the same construction as deflate_tables.adaptive_table, word for word, at 1 / 50 of the time
+            cover = np.array([int((h[l, :286] > 0).sum()) >= 128 for l in range(3)], np.int32)
+            tab = np.empty((3, DT.TABLE_WORDS), np.uint32)
+            if ctx.lib.aej_deflate_build_tables(h.ctypes.data, cover.ctypes.data, tab.ctypes.data):
+                raise AejError("aej_deflate_build_tables failed")
+            tables = ctx.to_device(tab.view(np.int32), t.int32)
         cap = max((p.coeff_off[l + 1] if l < 2 else p.coeff_stride) - p.coeff_off[l] for l in range(3))
         stride = int(ctx.lib.aej_deflate_stream_bound(ctypes.c_uint64(4 * cap)))
         stride = (stride + 255) // 256 * 256

@@ -240,6 +240,12 @@ AEJ_API int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, 
 AEJ_API uint64_t aej_deflate_stream_bound(uint64_t raw_bytes);
 AEJ_API uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, int W);
 AEJ_API int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, int32_t *hist);
+/* HOST-only helper (no context, no device work): the three layers' dynamic codes from the histograms above, copied to the host --
+ * hist_host [3][AEJ_DEFLATE_HIST_BINS], tables_host [3][AEJ_DEFLATE_TABLE_WORDS] -- word for word what deflate_tables.adaptive_table
+ * builds (the Python file stays the readable restatement; tests compare the two).  cover_all [3] or NULL (= all 1): 1 = every symbol gets a
+ * code (a table valid for any data), 0 = only the symbols counted (shorter block headers; a block that needs a missing code is written
+ * with the fixed code by aej_deflate_batch). */
+AEJ_API int aej_deflate_build_tables(const int32_t *hist_host, const int32_t *cover_all, uint32_t *tables_host);
 AEJ_API int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables,
                               uint8_t *streams, uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes);
 

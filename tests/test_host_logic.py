@@ -267,3 +267,36 @@ def test_bench_asks_for_more_hardware_queues_when_it_will_hold_a_process_group(m
     src = inspect.getsource(bench.init_distributed)
     eager = src.index('AEJ_BENCH_NCCL_EAGER')
     assert "device_id" in src[eager:src.index("else:", eager)] and "device_id" not in src[src.index("else:", eager):]      # only the A / B switch binds the device early
+
+
+def test_library_builds_the_same_huffman_tables_as_the_python_restatement():
+    """aej_deflate_build_tables (host-only C++ in csrc/deflate.hip, what Jpeg.deflate_batch calls) against deflate_tables.adaptive_table
+    (the readable restatement the reference encoder and the CPU tests use): word for word, for skewed, flat, sparse and empty histograms,
+    in both cover modes -- including histograms whose plain Huffman code would be longer than 15 bits."""
+    import ctypes
+    from adaptive_edge_aware_jpeg_amd import deflate_tables as DT
+    from adaptive_edge_aware_jpeg_amd._lib import load_library
+    lib = load_library()
+    rng = np.random.default_rng(7)
+    hists = [np.zeros(288, np.int32), np.ones(288, np.int32)]
+    for trial in range(60):
+        h = (rng.random(288) ** int(rng.integers(1, 8)) * 10.0 ** int(rng.integers(1, 8))).astype(np.int64)
+        h[rng.random(288) < rng.random()] = 0                       # a random share of symbols never occurs
+        h[286:288] = rng.integers(0, 1000, 2)
+        hists.append(np.minimum(h, 2 ** 31 - 1).astype(np.int32))
+    fib = np.zeros(288, np.int32); fib[:40] = [min(int(1.6 ** k), 2 ** 30) for k in range(40)]     # plain Huffman: depths far beyond 15
+    hists.append(fib)
+    for k in range(0, len(hists) - 2, 3):
+        hist = np.ascontiguousarray(np.stack(hists[k:k + 3]), dtype=np.int32)
+        for cover in ([1, 1, 1], [0, 0, 0], [1, 0, 1]):
+            cov = np.array(cover, np.int32)
+            tab = np.full((3, DT.TABLE_WORDS), 0xdeadbeef, np.uint32)
+            assert lib.aej_deflate_build_tables(hist.ctypes.data, cov.ctypes.data, tab.ctypes.data) == 0
+            for l in range(3):
+                want = DT.adaptive_table(hist[l, :286], hist[l, 286:288], cover_all=bool(cover[l]))
+                assert np.array_equal(tab[l], want), (k, l, cover, np.flatnonzero(tab[l] != want)[:8])
+    # NULL cover = every symbol gets a code
+    tab = np.zeros((3, DT.TABLE_WORDS), np.uint32)
+    hist = np.ascontiguousarray(np.stack(hists[2:5]), dtype=np.int32)
+    assert lib.aej_deflate_build_tables(hist.ctypes.data, None, tab.ctypes.data) == 0
+    assert all(np.array_equal(tab[l], DT.adaptive_table(hist[l, :286], hist[l, 286:288])) for l in range(3))
