@@ -122,7 +122,6 @@ int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float 
 
 // deflate.hip -- opt-in GPU entropy stage: the layers' int32 coefficients as zlib streams (jpeg.py:588-590, 659)
 unsigned long long deflate_stream_bound(unsigned long long raw_bytes);
-int deflate_build_table_host(const int *hist /* [288] */, int cover_all, unsigned *table /* [385] */);      // host only
 int deflate_max_chunks(long long max_coeffs);
 unsigned long long deflate_workspace_bytes(int streams, int max_chunks);
 void launch_deflate_hist(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,

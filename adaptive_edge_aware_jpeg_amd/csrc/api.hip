@@ -1430,6 +1430,7 @@ static int deflate_geometry(aej_ctx *ctx, int batch, int H, int W, QtGeom &q, in
 extern "C" uint64_t aej_deflate_stream_bound(uint64_t raw_bytes) { return deflate_stream_bound(raw_bytes); }
 
 // host only (no context, no device): the per-layer dynamic codes from the histograms aej_deflate_histogram counted
+namespace aej { int deflate_build_table_host(const int *hist /* [288] */, int cover_all, unsigned *table /* [385] */); }      // deflate.hip
 extern "C" int aej_deflate_build_tables(const int32_t *hist_host, const int32_t *cover_all, uint32_t *tables_host)
 {
     if (!hist_host || !tables_host) return AEJ_ERR_ARG;
