@@ -156,6 +156,7 @@ SIGNATURES = {
     "aej_deflate_histogram": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "aej_deflate_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _U64, _P, _P, _U64]),
     "aej_deflate_build_tables": (_I, [_P, _P, _P]),
+    "aej_pack_u8_levels_host": (_I, [_P, _I64, _P, _I]),
     "aej_decode_workspace_bytes": (_U64, [_P, _I, _I, _I]),
     "aej_decode_batch": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _U64]),
     "aej_color_convert_inverse": (_I, [_P, _I, _P, _P, _I64]),

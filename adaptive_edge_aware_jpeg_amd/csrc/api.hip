@@ -7,7 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/aej.h"
@@ -1439,6 +1441,46 @@ extern "C" int aej_deflate_build_tables(const int32_t *hist_host, const int32_t 
     return 0;
 }
 
+// host only: 8-bit ingest of a host float32 batch (include/aej.h)
+extern "C" int aej_pack_u8_levels_host(const float *rgb_host, int64_t n, uint8_t *u8_host, int threads)
+{
+    if (!rgb_host || !u8_host || n < 0) return AEJ_ERR_ARG;
+    float lut[256];
+    for (int k = 0; k < 256; k++) lut[k] = (float)k / 255.0f;        // the quotients Image.load forms (image.py:80) and the ingest kernel's table
+    const int64_t kBlock = 1 << 16;
+    const int64_t nblocks = (n + kBlock - 1) / kBlock;
+    int nt = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+    if ((int64_t)nt > nblocks) nt = nblocks > 0 ? (int)nblocks : 1;
+    std::atomic<int64_t> next(0);
+    std::atomic<int> exact(1);
+    auto work = [&]() {
+        for (;;) {
+            const int64_t blk = next.fetch_add(1);
+            if (blk >= nblocks || !exact.load(std::memory_order_relaxed)) return;      // (another thread met a value that is no level: stop early)
+            const int64_t lo = blk * kBlock, hi = std::min(n, lo + kBlock);
+            unsigned bad = 0;
+            for (int64_t i = lo; i < hi; i++) {
+                const float x = rgb_host[i];
+                // x * 255 is within half a unit of k for x = float32(k) / 255; anything outside [0, 255] (or NaN) maps to an entry that cannot compare equal
+                float y = x * 255.0f + 0.5f;
+                y = y >= 0.0f ? y : 0.0f;                                              // (NaN -> 0: lut[0] == NaN is false)
+                const int k = y < 255.5f ? (int)y : 255;
+                uint32_t a, b;
+                memcpy(&a, &x, 4);
+                memcpy(&b, &lut[k], 4);
+                bad |= a ^ b;                                                          // bit-exact: -0.0f is not a level either
+                u8_host[i] = (uint8_t)k;
+            }
+            if (bad) { exact.store(0, std::memory_order_relaxed); return; }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    return exact.load();
+}
+
 extern "C" uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, int W)
 {
     QtGeom q;
@@ -1636,6 +1678,7 @@ const OptionDef kOptions[] = {
     { "dct64_kernel", &aej::Tuning::dct64_kernel, nullptr, 0, 4, true },
     { "dct_small_workgroups", &aej::Tuning::dct_small_workgroups, nullptr, 0, 1 << 16, true },
     { "sobel_lds", &aej::Tuning::sobel_lds, nullptr, 0, 1, true },
+    { "sobel_xcd", &aej::Tuning::sobel_xcd, nullptr, 0, 1, true },
     { "sub_chain", nullptr, &aej_ctx::sub_chain, -1, 3, false },
 };
 const OptionDef *find_option(const char *name)

@@ -1173,12 +1173,20 @@ __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__
 #define AEJ_X_SOBEL_MINW 8
 #endif
 template <bool L2>
-__global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles)
+__global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int xcd_contiguous)
 {
     const int lane = threadIdx.x & 63;
     // the tile index as a 32-bit SCALAR (wave index through readfirstlane): the division by the tiles per image, the walk over the layers and
-    // the tile's base addresses are then scalar work, not a 64-bit vector division per wave
-    const int T = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the tile's base addresses are then scalar work, not a 64-bit vector division per wave.
+    // Workgroups are dealt round-robin over the XCDs: with plain indices a workgroup's left / right halo dwords and its four overlap rows
+    // sit in lines that only OTHER XCDs' L2s hold, and are fetched from memory again (round 5, profiles/r05_counter_calibration.txt);
+    // xcd_contiguous gives each XCD a contiguous range of workgroups (speed only).
+    int wg = (int)blockIdx.x;
+    if (xcd_contiguous) {
+        const int n = (int)gridDim.x, q = n >> 3, r = n & 7, xcd = wg & 7, k = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int T = wg * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if ((long long)T >= total_tiles) return;
     const int tpi = (int)tiles_per_img;
     const int b = T / tpi;
@@ -1642,17 +1650,18 @@ void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
     hipLaunchKernelGGL(k_thresholds, dim3(g.nl, g.B), dim3(256), 0, st, g, cb.blur_hist, cb.thr, cb.low_q, cb.high_q, cb.l2);
 }
 
-void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, const Tuning &t)
+void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, const Tuning &tn)
 {
     // register kernel: every layer's rows must be whole aligned dwords (w % 4 == 0, w >= 4); other shapes take the LDS kernel
     // (aej_set_option "sobel_lds": the LDS-tiled kernel of rounds 1-2 for every shape)
-    bool reg_ok = !t.sobel_lds;
+    bool reg_ok = !tn.sobel_lds;
     for (int l = 0; l < g.nl; l++) reg_ok = reg_ok && (g.w[l] % 4) == 0 && g.w[l] >= 4;
     if (reg_ok) {
         const long long t = hyst_tiles_per_image(g), total = t * g.B;
         const dim3 rgrid((unsigned)((total + 3) / 4));
-        if (cb.l2) hipLaunchKernelGGL(k_sobel_nms_reg<true>, rgrid, dim3(256), 0, st, g, cb, t, total);
-        else hipLaunchKernelGGL(k_sobel_nms_reg<false>, rgrid, dim3(256), 0, st, g, cb, t, total);
+        const int xcd = tn.sobel_xcd;
+        if (cb.l2) hipLaunchKernelGGL(k_sobel_nms_reg<true>, rgrid, dim3(256), 0, st, g, cb, t, total, xcd);
+        else hipLaunchKernelGGL(k_sobel_nms_reg<false>, rgrid, dim3(256), 0, st, g, cb, t, total, xcd);
         return;
     }
     const int strip = pick_strip(g, kBlurTW, kBlurTH, kStripMax, 2048);

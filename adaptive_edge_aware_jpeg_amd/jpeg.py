@@ -21,6 +21,14 @@ from .image import Image
 from .settings import JpegCompressionSettings
 
 
+def usable_cpus() -> int:
+    """Cores this process may run on (its affinity mask; a container's share is usually far below ``os.cpu_count()``)."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
 class EncodedBatch:
     """Device-resident result of the encode hot path for a batch (layout: include/aej.h, aej_plan)."""
 
@@ -153,7 +161,7 @@ class Jpeg:
         data = np.ascontiguousarray(img.data, dtype=np.float32).reshape(img.original_shape)
         if entropy != "host" or zlib_level != 9:
             return self.compress_many(data[None], extension=img.extension, workers=3, zlib_level=zlib_level, entropy=entropy)[0]
-        enc = self.compress_batch(data[None])
+        enc = self.compress_batch(self._host_batch_for_upload(data[None]))
         layers = [enc.layer(0, l) for l in range(3)]
         return self._entropy_encode(layers)
 
@@ -259,7 +267,29 @@ class Jpeg:
         return b"".join(Jpeg._layer_pieces(L, zlib_level, stream))
 
     def _entropy_encode(self, layers) -> bytes:
-        return self._header_bytes(len(layers)) + b"".join(self._layer_bytes(L) for L in layers)
+        """Header + one record per layer (jpeg.py:531-597).  The layers' zlib streams are independent (jpeg.py:588-595 writes them one
+        after the other) and ``zlib.compress`` releases the GIL, so they are deflated on one thread each: the same bytes, in the time
+        of the largest layer (luma: two thirds of the coefficients) instead of the sum."""
+        if len(layers) <= 1:
+            recs = [self._layer_bytes(L) for L in layers]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(layers)) as ex:
+                recs = list(ex.map(self._layer_bytes, layers))
+        return self._header_bytes(len(layers)) + b"".join(recs)
+
+    def _host_batch_for_upload(self, batch):
+        """A host float32 batch whose values are all exactly ``float32(k) / 255`` -- what ``Image.load`` produces (image.py:80) -- crosses
+        PCIe as the uint8 levels ``k`` (3 B per pixel instead of 12) and takes the 8-bit ingest entry, which forms the same float32
+        quotients on the GPU: identical outputs.  One threaded pass of a host helper of the library decides (it stops at the first value
+        that is not such a quotient); device tensors, uint8 input and everything else are returned unchanged."""
+        if not isinstance(batch, np.ndarray) or batch.dtype != np.float32 or batch.size < (1 << 16):
+            return batch
+        ctx = self._bind()
+        src = np.ascontiguousarray(batch)
+        out = np.empty(src.shape, np.uint8)
+        ok = ctx.lib.aej_pack_u8_levels_host(src.ctypes.data, ctypes.c_int64(src.size), out.ctypes.data, usable_cpus())
+        return out if ok == 1 else batch
 
     def deflate_batch(self, enc: EncodedBatch, adaptive: bool = True, as_views: bool = False, tables: Optional[np.ndarray] = None) -> List[List[bytes]]:
         """OPT-IN GPU entropy stage (``aej_deflate_batch``, csrc/deflate.hip): the zlib stream of every layer of an encoded batch, written
@@ -300,10 +330,8 @@ class Jpeg:
                                             ctypes.c_uint64(stride), sizes.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes)))
         sz = sizes.cpu().numpy()
         off = np.concatenate([[0], np.cumsum(sz)])
-        packed = ctx.empty((int(off[-1]),), t.uint8)              # compacted on the device: one device-to-host copy of the compressed bytes
-        for i in range(n):
-            packed[int(off[i]):int(off[i + 1])] = streams[i, :int(sz[i])]
-        host = packed.cpu().numpy()
+        # compacted on the device by ONE gather launch, then one device-to-host copy of the compressed bytes
+        host = t.cat([streams[i, :int(sz[i])] for i in range(n)]).cpu().numpy()
         view = memoryview(host)
         cut = (lambda a, b: view[a:b]) if as_views else (lambda a, b: host[a:b].tobytes())
         return [[cut(int(off[3 * b + l]), int(off[3 * b + l + 1])) for l in range(3)] for b in range(p.batch)]
@@ -321,7 +349,9 @@ class Jpeg:
         compressed bytes cross to the host.  The default stays host zlib level 9, the reference's (jpeg.py:590), so the bytes stay the
         reference's."""
         from concurrent.futures import ThreadPoolExecutor
-        enc = self.compress_batch(batch)
+        if entropy not in ("host", "gpu", "gpu-fixed"):
+            raise ValueError("entropy must be 'host', 'gpu' or 'gpu-fixed'")
+        enc = self.compress_batch(self._host_batch_for_upload(batch))
         p = enc.plan
         self.update_layer_shapes((p.H, p.W))
         self.extension = extension
@@ -329,19 +359,17 @@ class Jpeg:
         if entropy in ("gpu", "gpu-fixed"):
             streams = self.deflate_batch(enc, adaptive=entropy == "gpu", as_views=True)
             cnt = enc.counts_host
+            states = enc.states.cpu().numpy()           # every image's state symbols in ONE device-to-host copy
             out = []
             for b in range(p.batch):
                 pieces = [header]
                 for l in range(3):
                     so = b * p.state_stride + p.state_off[l]
-                    st = enc.states[so:so + int(cnt[b, l, 2])].cpu().numpy()
-                    pieces += self._layer_pieces({"states": st, "root_size": int(cnt[b, l, 3])}, stream=streams[b][l])
+                    pieces += self._layer_pieces({"states": states[so:so + int(cnt[b, l, 2])], "root_size": int(cnt[b, l, 3])}, stream=streams[b][l])
                 out.append(b"".join(pieces))            # the one copy of the compressed bytes on the host
             return out
-        if entropy != "host":
-            raise ValueError("entropy must be 'host', 'gpu' or 'gpu-fixed'")
         jobs = [(b, l) for b in range(p.batch) for l in range(3)]
-        with ThreadPoolExecutor(max_workers=workers or min(32, os.cpu_count() or 1)) as ex:
+        with ThreadPoolExecutor(max_workers=workers or usable_cpus()) as ex:
             recs = list(ex.map(lambda bl: self._layer_bytes(enc.layer(bl[0], bl[1]), zlib_level), jobs))
         return [header + b"".join(recs[3 * b:3 * b + 3]) for b in range(p.batch)]
 

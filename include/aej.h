@@ -123,6 +123,7 @@ AEJ_API int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int32_t
  *   "dct64_kernel"          0 | 1 | 4 (0)      64 x 64 DCT: 0 = by company (one wave per leaf alone, four beside other work), 1 / 4 force
  *   "dct_small_workgroups"  0..65536 (0)       cap on the grids of the 4 / 8 / 16 DCT kernels; 0 = automatic
  *   "sobel_lds"             0 | 1 (0)          1: the LDS-tiled Sobel / NMS kernel for every shape (default: register kernel when w % 4 == 0)
+ *   "sobel_xcd"             0 | 1 (1)          1: each XCD gets a contiguous range of the register Sobel kernel's tiles (0: round-robin)
  *   "sub_chain"             -1..3 (-1)         which stage of the previously enqueued part a part's colour stage waits for: 0 none, 1 colour,
  *                                              2 blur, 3 Sobel; -1 = 1 */
 AEJ_API int aej_set_option(aej_ctx *ctx, const char *name, int64_t value);
@@ -248,6 +249,13 @@ AEJ_API int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int
 AEJ_API int aej_deflate_build_tables(const int32_t *hist_host, const int32_t *cover_all, uint32_t *tables_host);
 AEJ_API int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables,
                               uint8_t *streams, uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes);
+
+/* HOST-only helper (no context, no device work) for the 8-bit ingest of HOST images (src/image/image.py:80 makes every
+ * loaded image `uint8.astype(float32) / 255.0`): if every one of the n float32 values at rgb_host is bit for bit float32(k) / 255.0f for
+ * some k in 0..255, the levels k are written to u8_host and 1 is returned -- the caller then uploads 3 B per pixel instead of 12 and
+ * calls aej_encode_batch_u8, whose outputs are identical; otherwise 0 (u8_host is then undefined; the pass stops at the first block that
+ * holds another value).  `threads` host threads share the pass (clamped to 1..64). */
+AEJ_API int aej_pack_u8_levels_host(const float *rgb_host, int64_t n, uint8_t *u8_host, int threads);
 
 /* ---- decode path: Jpeg.decompress after the host-side entropy decode (jpeg.py:285-296) ------
  * coeffs / leaves / counts use the layout of aej_encode_batch's outputs (so an encoded batch can be decoded in

@@ -300,3 +300,27 @@ def test_library_builds_the_same_huffman_tables_as_the_python_restatement():
     hist = np.ascontiguousarray(np.stack(hists[2:5]), dtype=np.int32)
     assert lib.aej_deflate_build_tables(hist.ctypes.data, None, tab.ctypes.data) == 0
     assert all(np.array_equal(tab[l], DT.adaptive_table(hist[l, :286], hist[l, 286:288])) for l in range(3))
+
+
+def test_pack_u8_levels_host_helper():
+    """aej_pack_u8_levels_host (include/aej.h): a host float32 batch is taken for 8-bit ingest only when EVERY value is bit for bit
+    float32(k) / 255 -- what Image.load produces (src/image/image.py:80) -- and the levels it writes are those k."""
+    lib = _lib.load_library()
+    rng = np.random.default_rng(5)
+    u = rng.integers(0, 256, size=(70, 333, 3), dtype=np.uint8)
+    u.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)                      # every level occurs
+    f = u.astype(np.float32) / np.float32(255.0)
+    out = np.empty(f.shape, np.uint8)
+    for threads in (1, 3, 64):
+        out[:] = 0
+        assert lib.aej_pack_u8_levels_host(f.ctypes.data, f.size, out.ctypes.data, threads) == 1
+        assert np.array_equal(out, u)
+    for bad in (np.nextafter(f[3, 7, 1], np.float32(2)), np.float32(np.nan), np.float32(-0.0), np.float32(1.5), np.float32(-1.0), np.float32(np.inf),
+                np.float32(0.5)):                                             # 0.5 = 127.5 / 255 is no level
+        g = f.copy()
+        g[3, 7, 1] = bad
+        assert lib.aej_pack_u8_levels_host(g.ctypes.data, g.size, out.ctypes.data, 2) == 0, bad
+    r = rng.random((64, 64, 3), dtype=np.float32)
+    assert lib.aej_pack_u8_levels_host(r.ctypes.data, r.size, out.ctypes.data, 2) == 0
+    assert lib.aej_pack_u8_levels_host(f.ctypes.data, 0, out.ctypes.data, 2) == 1      # an empty batch is trivially all levels
+    assert lib.aej_pack_u8_levels_host(None, 4, out.ctypes.data, 2) < 0
