@@ -305,6 +305,7 @@ def test_library_builds_the_same_huffman_tables_as_the_python_restatement():
 def test_pack_u8_levels_host_helper():
     """aej_pack_u8_levels_host (include/aej.h): a host float32 batch is taken for 8-bit ingest only when EVERY value is bit for bit
     float32(k) / 255 -- what Image.load produces (src/image/image.py:80) -- and the levels it writes are those k."""
+    from adaptive_edge_aware_jpeg_amd import _lib
     lib = _lib.load_library()
     rng = np.random.default_rng(5)
     u = rng.integers(0, 256, size=(70, 333, 3), dtype=np.uint8)
