@@ -340,3 +340,16 @@ def get_context(device=0):
     if ctx is None:
         ctx = _contexts[key] = Context(idx)
     return ctx
+
+
+def release_context(ctx):
+    """Destroy a context handed out by get_context() and forget it: the library's state for it is freed (aej_destroy) and its
+    workspace goes back to torch's allocator.  For callers that walk through many streams or batch shapes (bench.py's other_configs)."""
+    for key, known in list(_contexts.items()):
+        if known is ctx:
+            del _contexts[key]
+    ctx._ws = None
+    ctx._in_flight = None
+    if getattr(ctx, "handle", None):
+        ctx.lib.aej_destroy(ctx.handle)
+        ctx.handle = None

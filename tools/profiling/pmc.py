@@ -10,7 +10,10 @@ the number of aej_encode_batch calls.
 
 Copy the JSON to be judged into profiles/ (bench.py reads profiles/r02_hbm_traffic.json and profiles/r02_pmc_valu.json and labels
 them with the commit they were taken at).  HBM bytes follow MI355X_MICROARCH.md's gfx950 correction: reads = 2 x FETCH_SIZE (the
-counter tallies 128-byte requests at 64 B), writes = WRITE_SIZE, both reported in KB by rocprofv3.
+counter tallies 128-byte requests at 64 B), writes = WRITE_SIZE, both reported in KB by rocprofv3.  The guide calibrates that factor for
+16-byte-per-lane streaming only; profiles/r05_counter_calibration.txt (tools/profiling/counter_calibration.py) extends it to every access
+shape of this library: 16 / 8 / 4 / 2 / 1 B per lane and the Sobel kernel's 64-byte row segments all read FETCH_SIZE = bytes / 2, stores of
+16 / 4 / 2 / 1 B per lane WRITE_SIZE = bytes (+ <= 1.3 %).
 """
 import collections
 import csv

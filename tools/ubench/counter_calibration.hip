@@ -40,7 +40,7 @@ __device__ __forceinline__ void rd_body(const T *__restrict__ p, long long n)
 {
     unsigned acc = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc ^= fold<T>(p[i]);
-    if (acc == 0x12345679u) g_sink = acc;
+    if (acc == (unsigned)n) g_sink = acc;      // (a run-time value: a constant the narrow types cannot reach lets the compiler drop the loads)
 }
 template <typename T>
 __device__ __forceinline__ void wr_body(T *__restrict__ p, long long n, T v)
@@ -94,7 +94,7 @@ __device__ __forceinline__ void rd4_tile_body(const unsigned char *__restrict__ 
             acc ^= *reinterpret_cast<const unsigned *>(plane + (long long)y * w + c) * 3u;
         }
     }
-    if (acc == 0x12345679u) g_sink = acc;
+    if (acc == (unsigned)planes) g_sink = acc;
 }
 
 __global__ __launch_bounds__(256) void k_rd4_tile(const unsigned char *s, int w, int h, int p) { rd4_tile_body<0, false>(s, w, h, p); }
