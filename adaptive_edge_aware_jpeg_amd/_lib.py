@@ -153,8 +153,8 @@ SIGNATURES = {
     "aej_dct_quant_zigzag": (_I, [_P, _P, _I, _I, _I, _P, _I64, _P, _P]),
     "aej_deflate_stream_bound": (_U64, [_U64]),
     "aej_deflate_workspace_bytes": (_U64, [_P, _I, _I, _I]),
-    "aej_deflate_histogram": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "aej_deflate_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _U64, _P, _P, _U64]),
+    "aej_deflate_histogram": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _U64]),
+    "aej_deflate_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _U64, _P, _P, _U64]),
     "aej_deflate_build_tables": (_I, [_P, _P, _P]),
     "aej_pack_u8_levels_host": (_I, [_P, _I64, _P, _I]),
     "aej_decode_workspace_bytes": (_U64, [_P, _I, _I, _I]),
@@ -248,6 +248,14 @@ class Context:
             self._ws = None
             self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
         return self._ws
+
+    def pinned(self, nbytes):
+        """Page-locked host staging buffer of at least `nbytes`, reused across calls (device-to-host copies into pageable memory run at
+        a third of the PCIe rate).  Its contents are only valid until the next call that uses it."""
+        if getattr(self, "_pinned", None) is None or self._pinned.numel() < nbytes:
+            self._pinned = None
+            self._pinned = self.torch.empty(int(max(nbytes, 1 << 20)), dtype=self.torch.uint8, pin_memory=True)
+        return self._pinned
 
     def hysteresis_stats(self):
         """-> dict(calls, queued): whole-path calls on this context, tiles that went through the device-side hysteresis work queue
@@ -349,6 +357,7 @@ def release_context(ctx):
         if known is ctx:
             del _contexts[key]
     ctx._ws = None
+    ctx._pinned = None
     ctx._in_flight = None
     if getattr(ctx, "handle", None):
         ctx.lib.aej_destroy(ctx.handle)

@@ -127,6 +127,18 @@ __device__ __forceinline__ int wave_scan_incl(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
     return v;
 }
+// Wave-wide maximum by the same DPP steps (lanes that would read from outside their row take 0: for values >= 0).  All 64 lanes must be active.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    auto mx = [](unsigned a, int b) { return a > (unsigned)b ? a : (unsigned)b; };
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));      // row_shr:1
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));      // row_shr:2
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));      // row_shr:4
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));      // row_shr:8
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));      // row_bcast:15 -> rows 1 and 3
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));      // row_bcast:31 -> rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
 
 }  // namespace aej

@@ -122,13 +122,14 @@ int launch_upsample_color(hipStream_t st, int space, const Geom &g, const float 
 
 // deflate.hip -- opt-in GPU entropy stage: the layers' int32 coefficients as zlib streams (jpeg.py:588-590, 659)
 unsigned long long deflate_stream_bound(unsigned long long raw_bytes);
-int deflate_max_chunks(long long max_coeffs);
-unsigned long long deflate_workspace_bytes(int streams, int max_chunks);
-void launch_deflate_hist(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
-                         int max_chunks, int *hist /* [3][288] */);
+unsigned long long deflate_workspace_bytes(int batch, const long long *coeff_cap /* [3] */);
+// LZ77 match search + parse of every stream: tokens into the workspace, symbol histogram (device [3][320], may be null)
+void launch_deflate_parse(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
+                          const long long *coeff_cap, int *hist, void *workspace);
+// the streams from the parse in the workspace (reuse_parse) or from a fresh one
 void launch_deflate(hipStream_t st, const int *coeffs, const long long *counts, int batch, long long coeff_stride, const long long *coeff_off,
-                    int max_chunks, const unsigned *tables /* [3][385] or null */, unsigned char *out, unsigned long long stream_stride, long long *sizes,
-                    void *workspace);
+                    const long long *coeff_cap, const unsigned *tables /* [3][448] or null */, int reuse_parse, unsigned char *out,
+                    unsigned long long stream_stride, long long *sizes, void *workspace);
 
 // metrics.hip
 void launch_metric_prep(hipStream_t st, const float *a, const float *b, int B, long long npx, double *acc, unsigned char *ga, unsigned char *gb);

@@ -1416,23 +1416,19 @@ extern "C" int aej_decode_batch(aej_ctx *ctx, const int32_t *coeffs, const int32
 }
 
 // ---- opt-in GPU entropy stage (deflate.hip) -----------------------------------------------------------------------
-static int deflate_geometry(aej_ctx *ctx, int batch, int H, int W, QtGeom &q, int &max_chunks)
+static int deflate_geometry(aej_ctx *ctx, int batch, int H, int W, QtGeom &q)
 {
     int rc = check_encode_args(ctx, batch, H, W);
     if (rc) return rc;
     Geom g;
     if ((rc = make_geom(ctx, ctx->space, batch, H, W, g))) return rc;
-    if ((rc = make_qtgeom(ctx, g, ctx->bmin, ctx->bmax, q))) return rc;
-    long long cap = 0;
-    for (int l = 0; l < 3; l++) cap = std::max(cap, q.coeff_cap[l]);
-    max_chunks = deflate_max_chunks(cap);
-    return 0;
+    return make_qtgeom(ctx, g, ctx->bmin, ctx->bmax, q);
 }
 
 extern "C" uint64_t aej_deflate_stream_bound(uint64_t raw_bytes) { return deflate_stream_bound(raw_bytes); }
 
 // host only (no context, no device): the per-layer dynamic codes from the histograms aej_deflate_histogram counted
-namespace aej { int deflate_build_table_host(const int *hist /* [288] */, int cover_all, unsigned *table /* [385] */); }      // deflate.hip
+namespace aej { int deflate_build_table_host(const int *hist /* [320] */, int cover_all, unsigned *table /* [448] */); }      // deflate.hip
 extern "C" int aej_deflate_build_tables(const int32_t *hist_host, const int32_t *cover_all, uint32_t *tables_host)
 {
     if (!hist_host || !tables_host) return AEJ_ERR_ARG;
@@ -1484,44 +1480,56 @@ extern "C" int aej_pack_u8_levels_host(const float *rgb_host, int64_t n, uint8_t
 extern "C" uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, int W)
 {
     QtGeom q;
-    int max_chunks;
-    if (deflate_geometry(ctx, batch, H, W, q, max_chunks)) return 0;
-    return deflate_workspace_bytes(batch * 3, max_chunks);
+    if (deflate_geometry(ctx, batch, H, W, q)) return 0;
+    return deflate_workspace_bytes(batch, q.coeff_cap);
 }
 
-extern "C" int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, int32_t *hist)
+static int deflate_check(aej_ctx *ctx, const char *who, const void *a, const void *b, const void *ws, uint64_t ws_bytes, int batch, const QtGeom &q)
 {
-    QtGeom q;
-    int max_chunks;
-    int rc = deflate_geometry(ctx, batch, H, W, q, max_chunks);
-    if (rc) return rc;
-    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
-    if (!coeffs || !counts || !hist) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
-    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
-    launch_deflate_hist(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, max_chunks, hist);
-    AEJ_HIP_CHECK(hipGetLastError());
+    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", who);
+    if (!a || !b || !ws) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    if (ws_bytes < deflate_workspace_bytes(batch, q.coeff_cap)) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
     return 0;
 }
 
-extern "C" int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables,
+// the error word is the workspace's first: 1 = a stream does not fit, 2 = a count beyond its layer's capacity
+static int deflate_finish(aej_ctx *ctx, void *workspace, uint64_t stream_stride)
+{
+    AEJ_HIP_CHECK(hipGetLastError());
+    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, workspace, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (*ctx->h_flag == 2) return fail(ctx, AEJ_ERR_ARG, "counts: a layer's coefficient count is negative or exceeds the capacity the plan gives it (corrupt or stale counts buffer)");
+    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "a deflate stream does not fit stream_stride = %llu bytes (aej_deflate_stream_bound gives a safe size)", (unsigned long long)stream_stride);
+    return 0;
+}
+
+extern "C" int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, int32_t *hist, void *workspace,
+                                     uint64_t workspace_bytes)
+{
+    QtGeom q;
+    int rc = deflate_geometry(ctx, batch, H, W, q);
+    if (rc) return rc;
+    if (!hist) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    if ((rc = deflate_check(ctx, __func__, coeffs, counts, workspace, workspace_bytes, batch, q))) return rc;
+    AEJ_HIP_CHECK(hipSetDevice(ctx->device));
+    launch_deflate_parse(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, q.coeff_cap, hist, workspace);
+    return deflate_finish(ctx, workspace, 0);
+}
+
+extern "C" int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables, int reuse_parse,
                                  uint8_t *streams, uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes)
 {
     QtGeom q;
-    int max_chunks;
-    int rc = deflate_geometry(ctx, batch, H, W, q, max_chunks);
+    int rc = deflate_geometry(ctx, batch, H, W, q);
     if (rc) return rc;
-    if (call_in_flight(ctx)) return fail(ctx, AEJ_ERR_STATE, "%s between aej_encode_batch_begin and aej_encode_batch_end", __func__);
-    if (!coeffs || !counts || !streams || !sizes || !workspace) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
-    if (workspace_bytes < deflate_workspace_bytes(batch * 3, max_chunks)) return fail(ctx, AEJ_ERR_CAPACITY, "workspace too small");
-    if (stream_stride < 16) return fail(ctx, AEJ_ERR_CAPACITY, "stream_stride too small");
+    if (!streams || !sizes) return fail(ctx, AEJ_ERR_ARG, "NULL buffer");
+    if ((rc = deflate_check(ctx, __func__, coeffs, counts, workspace, workspace_bytes, batch, q))) return rc;
+    if (stream_stride < 16 || (stream_stride & 3)) return fail(ctx, AEJ_ERR_CAPACITY, "stream_stride must be a multiple of 4 and at least 16");
+    if ((reinterpret_cast<uintptr_t>(streams) & 3) != 0) return fail(ctx, AEJ_ERR_ARG, "streams must be 4-byte aligned");
     AEJ_HIP_CHECK(hipSetDevice(ctx->device));
-    launch_deflate(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, max_chunks, tables, streams,
-                   stream_stride, reinterpret_cast<long long *>(sizes), workspace);
-    AEJ_HIP_CHECK(hipGetLastError());
-    AEJ_HIP_CHECK(hipMemcpyAsync(ctx->h_flag, workspace, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));      // the error word is the workspace's first
-    AEJ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (*ctx->h_flag) return fail(ctx, AEJ_ERR_CAPACITY, "a deflate stream does not fit stream_stride = %llu bytes (aej_deflate_stream_bound gives a safe size)", (unsigned long long)stream_stride);
-    return 0;
+    launch_deflate(ctx->stream, coeffs, reinterpret_cast<const long long *>(counts), batch, q.coeff_stride, q.coeff_off, q.coeff_cap, tables, reuse_parse ? 1 : 0,
+                   streams, stream_stride, reinterpret_cast<long long *>(sizes), workspace);
+    return deflate_finish(ctx, workspace, stream_stride);
 }
 
 // ---- evaluation metrics (evaluation_metrics.py:50-89) ------------------------------------------------------------

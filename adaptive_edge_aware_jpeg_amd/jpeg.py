@@ -292,27 +292,31 @@ class Jpeg:
         return out if ok == 1 else batch
 
     def deflate_batch(self, enc: EncodedBatch, adaptive: bool = True, as_views: bool = False, tables: Optional[np.ndarray] = None) -> List[List[bytes]]:
-        """OPT-IN GPU entropy stage (``aej_deflate_batch``, csrc/deflate.hip): the zlib stream of every layer of an encoded batch, written
-        on the GPU -- Huffman-coded deflate blocks with matches at distances 1 and 4, which ``zlib.decompress`` (the reference's decoder,
-        jpeg.py:659) reads like any other stream.  ``adaptive``: one dynamic Huffman code per layer, built here on the host
-        (``deflate_tables.adaptive_table``) from the symbol histogram the GPU counts (a 3.5 KB round trip); otherwise RFC 1951's fixed code.
-        Only the compressed bytes cross to the host.  -> [image][layer] bytes (``as_views``: memoryviews into the one host buffer the
-        device-to-host copy filled, for callers that assemble larger records and want no intermediate copy; ``tables``: use these codes
-        instead of counting -- a block that needs a symbol they have no code for is written with the fixed code)."""
+        """OPT-IN GPU entropy stage (``aej_deflate_histogram`` / ``aej_deflate_batch``, csrc/deflate.hip): the zlib stream of every layer
+        of an encoded batch, written on the GPU -- one deflate block per stream, LZ77 matches from an exact hash-chain search over 32 KiB
+        chunks, tokens chosen by dynamic programming -- which ``zlib.decompress`` (the reference's decoder, jpeg.py:659) reads like any
+        other stream.  ``adaptive``: one dynamic Huffman code per layer, built by the library's host helper from the token histogram the
+        GPU counts (a 4 KB round trip); otherwise RFC 1951's fixed code.  Only the compressed bytes cross to the host.
+        -> [image][layer] bytes (``as_views``: memoryviews into the page-locked host buffer the device-to-host copy filled -- valid until
+        this context's next ``deflate_batch`` -- for callers that assemble larger records at once and want no intermediate copy; ``tables``: use these codes ([3][deflate_tables.TABLE_WORDS] uint32, e.g.
+        kept from an earlier batch) instead of counting -- a stream that needs a symbol they have no code for takes the fixed code)."""
         from . import deflate_tables as DT
         ctx = self._bind()
         t = ctx.torch
         p = enc.plan
-        if tables is not None:                 # caller-built codes ([3][deflate_tables.TABLE_WORDS] uint32), e.g. kept from an earlier batch
+        nbytes = int(ctx.lib.aej_deflate_workspace_bytes(ctx.handle, p.batch, p.H, p.W))
+        ws = ctx.workspace(nbytes)
+        parsed = 0
+        if tables is not None:
             tables = ctx.to_device(np.ascontiguousarray(tables, dtype=np.uint32).view(np.int32), t.int32)
         elif adaptive:
-            hist = ctx.empty((3, 288), t.int32)
-            ctx.check(ctx.lib.aej_deflate_histogram(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W, hist.data_ptr()))
+            hist = ctx.empty((3, DT.HIST_BINS), t.int32)
+            ctx.check(ctx.lib.aej_deflate_histogram(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W, hist.data_ptr(),
+                                                    ws.data_ptr(), ctypes.c_uint64(nbytes)))
+            parsed = 1                              # the tokens stay in the workspace: aej_deflate_batch does not parse again
             h = np.ascontiguousarray(hist.cpu().numpy(), dtype=np.int32)
-            # few distinct symbols (sparse layers): codes for exactly those, a 40-byte block header instead of 55 and 2-4 % smaller streams;
-            # otherwise the cover-everything code (natural images use nearly every symbol: the two are the same size there).  The tables come
-            # from the library's host helper -- the same construction as deflate_tables.adaptive_table, word for word, at 1 / 50 of the time
-            cover = np.array([int((h[l, :286] > 0).sum()) >= 128 for l in range(3)], np.int32)
+            # codes for exactly the symbols that occur: the table is used on the very data (and parse) it was counted on
+            cover = np.zeros(3, np.int32)
             tab = np.empty((3, DT.TABLE_WORDS), np.uint32)
             if ctx.lib.aej_deflate_build_tables(h.ctypes.data, cover.ctypes.data, tab.ctypes.data):
                 raise AejError("aej_deflate_build_tables failed")
@@ -323,15 +327,16 @@ class Jpeg:
         n = p.batch * 3
         streams = ctx.empty((n, stride), t.uint8)
         sizes = ctx.empty((n,), t.int64)
-        nbytes = int(ctx.lib.aej_deflate_workspace_bytes(ctx.handle, p.batch, p.H, p.W))
-        ws = ctx.workspace(nbytes)
         ctx.check(ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), p.batch, p.H, p.W,
-                                            tables.data_ptr() if tables is not None else None, streams.data_ptr(),
+                                            tables.data_ptr() if tables is not None else None, parsed, streams.data_ptr(),
                                             ctypes.c_uint64(stride), sizes.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes)))
         sz = sizes.cpu().numpy()
         off = np.concatenate([[0], np.cumsum(sz)])
-        # compacted on the device by ONE gather launch, then one device-to-host copy of the compressed bytes
-        host = t.cat([streams[i, :int(sz[i])] for i in range(n)]).cpu().numpy()
+        # compacted on the device by ONE gather launch, then one device-to-host copy of the compressed bytes into page-locked memory
+        packed = t.cat([streams[i, :int(sz[i])] for i in range(n)])
+        stage = ctx.pinned(packed.numel())[:packed.numel()]
+        stage.copy_(packed)
+        host = stage.numpy()                        # (as_views: valid until this context's next deflate_batch)
         view = memoryview(host)
         cut = (lambda a, b: view[a:b]) if as_views else (lambda a, b: host[a:b].tobytes())
         return [[cut(int(off[3 * b + l]), int(off[3 * b + l + 1])) for l in range(3)] for b in range(p.batch)]
@@ -359,13 +364,30 @@ class Jpeg:
         if entropy in ("gpu", "gpu-fixed"):
             streams = self.deflate_batch(enc, adaptive=entropy == "gpu", as_views=True)
             cnt = enc.counts_host
-            states = enc.states.cpu().numpy()           # every image's state symbols in ONE device-to-host copy
+            aligned = p.state_stride % 4 == 0 and all(p.state_off[l] % 4 == 0 for l in range(3))
+            if aligned:
+                # the 2-bit packing of the state symbols (jpeg.py:561-578) for the whole batch in a few device operations: the layers' slots
+                # start on multiples of four symbols, so packing the buffer four by four packs every layer; only a layer's last byte can
+                # hold symbols from beyond its end, and those bits are cleared below (the reference pads with zeros)
+                q = enc.states.view(-1, 4) & 3              # (what lies beyond a layer's last symbol is not ours: keep it out of the neighbouring bit fields)
+                packed_all = ((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).cpu().numpy()
+            else:
+                states = enc.states.cpu().numpy()       # every image's state symbols in ONE device-to-host copy
             out = []
             for b in range(p.batch):
                 pieces = [header]
                 for l in range(3):
-                    so = b * p.state_stride + p.state_off[l]
-                    pieces += self._layer_pieces({"states": states[so:so + int(cnt[b, l, 2])], "root_size": int(cnt[b, l, 3])}, stream=streams[b][l])
+                    so, n_st = b * p.state_stride + p.state_off[l], int(cnt[b, l, 2])
+                    if aligned:
+                        seg = packed_all[so // 4:so // 4 + (n_st + 3) // 4]
+                        if n_st % 4:
+                            seg = seg.copy()
+                            seg[-1] &= (0xFF << (2 * (4 - n_st % 4))) & 0xFF
+                        comp = streams[b][l]
+                        pieces += [(2 * n_st).to_bytes(4, byteorder="big"), int(cnt[b, l, 3]).to_bytes(4, byteorder="big"), seg.data,
+                                   len(comp).to_bytes(4, byteorder="big"), comp]
+                    else:
+                        pieces += self._layer_pieces({"states": states[so:so + n_st], "root_size": int(cnt[b, l, 3])}, stream=streams[b][l])
                 out.append(b"".join(pieces))            # the one copy of the compressed bytes on the host
             return out
         jobs = [(b, l) for b in range(p.batch) for l in range(3)]

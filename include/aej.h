@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define AEJ_ABI_VERSION 2   /* 2: the hysteresis completes on the device -- the speculation entry points of version 1 are gone; aej_set_option */
+#define AEJ_ABI_VERSION 3   /* 2: the hysteresis completes on the device -- the speculation entry points of version 1 are gone; aej_set_option.
+                             * 3: the entropy stage keeps its parse in the workspace (aej_deflate_histogram / _batch signatures, table layout); aej_pack_u8_levels_host */
 
 #if defined(__GNUC__)
 #define AEJ_API __attribute__((visibility("default")))
@@ -224,30 +225,33 @@ AEJ_API int aej_dct_quant_zigzag(aej_ctx *ctx, const float *norm, int H, int W, 
 /* ---- OPT-IN entropy stage on the GPU: every layer's coefficient array as a zlib stream ---------------------------
  * The container's per-layer streams are `zlib.compress(coeffs.tobytes(), level=9)` in the reference (jpeg.py:588-590) and are read back
  * with `zlib.decompress` (jpeg.py:659) -- which accepts ANY conforming zlib stream.  With the hot path on the GPU that host call is the
- * whole of Jpeg.compress end to end, so the library can write the streams itself: one Huffman block per 32 KiB of input (chunks are
- * independent: each ends with an empty stored block, i.e. on a byte boundary), LZ77 matches at distances 1 and 4 only (zero runs, the
- * repeated sign / zero bytes of small int32 coefficients).  A block uses RFC 1951's fixed code or -- when `tables` is given and smaller for
- * that block -- a dynamic code per layer that the HOST builds from the symbol histogram of aej_deflate_histogram
- * (adaptive_edge_aware_jpeg_amd/deflate_tables.py; layout of a table: that file's header).  The bytes differ from zlib level 9's (about
- * 1.3 x larger with the dynamic codes); the decoded coefficients are identical.  Never the default.
- * coeffs / counts: aej_encode_batch's outputs (counts is the DEVICE array).
- * aej_deflate_histogram: hist = device [3][AEJ_DEFLATE_HIST_BINS] int32: per layer (summed over the batch) the occurrences of the 286
- *   literal / length symbols, then of the matches at distance 1 and at distance 4; enqueued on the context's stream.
- * aej_deflate_batch: tables = device [3][AEJ_DEFLATE_TABLE_WORDS] uint32 or NULL (fixed code everywhere).  The stream of (image b, layer l)
- *   is written at streams + (3 b + l) * stream_stride, its length to sizes[3 b + l] (device int64).  aej_deflate_stream_bound(raw bytes) is
- *   always enough for stream_stride; a stream that does not fit returns AEJ_ERR_CAPACITY.  The call synchronises the context's stream. */
-#define AEJ_DEFLATE_HIST_BINS 288
-#define AEJ_DEFLATE_TABLE_WORDS 385
+ * whole of Jpeg.compress end to end, so the library can write the streams itself (csrc/deflate.hip): ONE deflate block per stream, LZ77
+ * matches found by an exact hash-chain search over 32 KiB chunks (window: the chunk), tokens chosen by dynamic programming over a static
+ * cost model, coded with RFC 1951's fixed code or -- when `tables` is given, complete for the stream and smaller -- a dynamic code per
+ * layer that the HOST builds from the token histogram (aej_deflate_build_tables).  The bytes differ from zlib level 9's (about 1.1 x larger
+ * on natural images with the dynamic codes: zlib level 6's size); the decoded coefficients are identical.  Never the default.
+ * coeffs / counts: aej_encode_batch's outputs (counts is the DEVICE array; a count outside its layer's capacity returns AEJ_ERR_ARG).
+ * aej_deflate_histogram: match search + parse of every stream.  The tokens stay in `workspace`; hist = device [3][AEJ_DEFLATE_HIST_BINS]
+ *   int32: per layer (summed over the batch) the occurrences of the 286 literal / length symbols, then of the 30 distance symbols.
+ * aej_deflate_batch: tables = device [3][AEJ_DEFLATE_TABLE_WORDS] uint32 or NULL (fixed code everywhere).  reuse_parse != 0: the tokens
+ *   aej_deflate_histogram left in this workspace for these very coeffs / counts are used (the usual sequence: histogram -> build tables ->
+ *   batch); 0: the streams are parsed again first.  The stream of (image b, layer l) is written at streams + (3 b + l) * stream_stride
+ *   (4-byte aligned, stride a multiple of 4), its length to sizes[3 b + l] (device int64).  aej_deflate_stream_bound(raw bytes) is always
+ *   enough for stream_stride; a stream that does not fit returns AEJ_ERR_CAPACITY.  Both calls synchronise the context's stream. */
+#define AEJ_DEFLATE_HIST_BINS 320
+#define AEJ_DEFLATE_TABLE_WORDS 448
 AEJ_API uint64_t aej_deflate_stream_bound(uint64_t raw_bytes);
 AEJ_API uint64_t aej_deflate_workspace_bytes(aej_ctx *ctx, int batch, int H, int W);
-AEJ_API int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, int32_t *hist);
+AEJ_API int aej_deflate_histogram(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, int32_t *hist, void *workspace,
+                                  uint64_t workspace_bytes);
 /* HOST-only helper (no context, no device work): the three layers' dynamic codes from the histograms above, copied to the host --
- * hist_host [3][AEJ_DEFLATE_HIST_BINS], tables_host [3][AEJ_DEFLATE_TABLE_WORDS] -- word for word what deflate_tables.adaptive_table
- * builds (the Python file stays the readable restatement; tests compare the two).  cover_all [3] or NULL (= all 1): 1 = every symbol gets a
- * code (a table valid for any data), 0 = only the symbols counted (shorter block headers; a block that needs a missing code is written
- * with the fixed code by aej_deflate_batch). */
+ * hist_host [3][AEJ_DEFLATE_HIST_BINS], tables_host [3][AEJ_DEFLATE_TABLE_WORDS].  Layout of a table: [0..285] literal / length symbols as
+ * `bit-reversed code | nbits << 16`, [286..315] the distance symbols likewise, [316] number of block-header bits, [317..] those bits, LSB
+ * first (BFINAL = 1, BTYPE = 10, HLIT / HDIST / HCLEN, the run-length coded code lengths).  tests/deflate_reference.py is the readable
+ * restatement (tests compare the two word for word).  cover_all [3] or NULL (= all 1): 1 = every symbol gets a code (a table valid for
+ * any data), 0 = only the symbols counted (shorter block headers; a stream that needs a missing code is written with the fixed code). */
 AEJ_API int aej_deflate_build_tables(const int32_t *hist_host, const int32_t *cover_all, uint32_t *tables_host);
-AEJ_API int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables,
+AEJ_API int aej_deflate_batch(aej_ctx *ctx, const int32_t *coeffs, const int64_t *counts, int batch, int H, int W, const uint32_t *tables, int reuse_parse,
                               uint8_t *streams, uint64_t stream_stride, int64_t *sizes, void *workspace, uint64_t workspace_bytes);
 
 /* HOST-only helper (no context, no device work) for the 8-bit ingest of HOST images (src/image/image.py:80 makes every

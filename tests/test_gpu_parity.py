@@ -529,11 +529,13 @@ def test_unsupported_inputs_fail_loudly(A):
 
 # ------------------------------------------------------------------ opt-in GPU entropy stage (csrc/deflate.hip)
 def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
-    """aej_deflate_batch: every layer's stream must be a conforming zlib stream -- `zlib.decompress`, the call the reference's decoder
-    makes (jpeg.py:659), returns exactly the layer's int32 coefficients -- for smooth, noisy, natural and ragged images, a batch, and
-    sizes that leave partial 32 KiB chunks and partial 256-byte sub-blocks; the container built from them decodes to the same image as
-    the default (host zlib-9) container, with our decoder AND with the oracle's restatement of the reference's."""
+    """aej_deflate_histogram / aej_deflate_batch: every layer's stream must be a conforming zlib stream -- `zlib.decompress`, the call
+    the reference's decoder makes (jpeg.py:659), returns exactly the layer's int32 coefficients -- for smooth, noisy, natural and ragged
+    images, a batch, and sizes that leave partial 32 KiB chunks and partial sub-blocks; the container built from them decodes to the
+    same image as the default (host zlib-9) container, with our decoder AND with the oracle's restatement of the reference's.  The
+    matcher must really find far matches (distance histogram) and land near zlib's size on natural images."""
     import zlib
+    import deflate_reference as DT
     from conftest import golden_image
     rng = np.random.default_rng(5)
     cases = [("YCbCr", (40, 80), (4, 64), np.stack([synth(oracle, 200, 328, 3), synth(oracle, 200, 328, 4)])),
@@ -547,28 +549,25 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
         sizes = {}
         for adaptive in (False, True):
             streams = codec.deflate_batch(enc, adaptive=adaptive)
+            again = codec.deflate_batch(enc, adaptive=adaptive)
             for b in range(batch.shape[0]):
                 for l in range(3):
                     raw = enc.layer(b, l)["coeffs"].tobytes()
-                    assert streams[b][l][:2] == b"\x78\x01"
+                    assert streams[b][l][:1] == b"\x78"
                     assert zlib.decompress(streams[b][l]) == raw, f"{space} image {b} layer {l}: {len(raw)} bytes, adaptive={adaptive}"
+                    assert streams[b][l] == again[b][l], "the same input must give the same bytes"
             sizes[adaptive] = sum(len(x) for im in streams for x in im)
-        # a block takes the dynamic code only where it is smaller: never larger than all-fixed, but for a table's worth of headers
-        assert sizes[True] <= sizes[False] + 64, sizes
-        from adaptive_edge_aware_jpeg_amd import deflate_tables as DT
-        # codes counted on OTHER data, without codes for symbols that data did not contain (a run of zero coefficients: two literal / length
-        # symbols in all): every block that needs a missing code falls back to the fixed code -- still this batch's bytes, and never smaller
-        # than the all-fixed stream by more than the blocks that could use the foreign code
-        zl, zd = DT.histogram_reference(bytes(4096))
-        foreign = np.stack([DT.adaptive_table(zl, zd, cover_all=False)] * 3)
+        # a stream takes the dynamic code only where it is smaller: never larger than all-fixed
+        assert sizes[True] <= sizes[False], sizes
+        # codes counted on OTHER data, without codes for symbols that data did not contain (a run of zero coefficients): a stream that
+        # needs a missing code falls back to the fixed code -- still this batch's bytes
+        zt = [("lit", 0)] + [("match", 258, 1)] * 15
+        zh = DT.histogram_of(zt)
+        foreign = np.stack([DT.adaptive_table(zh[:286], zh[286:316], cover_all=False)] * 3)
         streams_f = codec.deflate_batch(enc, tables=foreign)
         for b in range(batch.shape[0]):
             for l in range(3):
                 assert zlib.decompress(streams_f[b][l]) == enc.layer(b, l)["coeffs"].tobytes(), f"{space} image {b} layer {l}: foreign exact table"
-        # the kernels' parse, block layout and Adler-32 are restated in pure Python (deflate_tables.encode_reference): same bytes
-        raw0 = enc.layer(0, 2)["coeffs"].tobytes()
-        if len(raw0) <= 300000:
-            assert codec.deflate_batch(enc, adaptive=False)[0][2] == DT.encode_reference(raw0, DT.fixed_table())
         blobs_gpu = codec.compress_many(batch, extension=".png", entropy="gpu")
         blobs_ref = codec.compress_many(batch, extension=".png")
         for b in range(batch.shape[0]):
@@ -576,6 +575,27 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
             want = A.Jpeg(A.JpegCompressionSettings()).decompress(blobs_ref[b]).data
             assert np.array_equal(got, want)
             assert np.array_equal(oracle.decode_image(blobs_gpu[b]), oracle.decode_image(blobs_ref[b]), equal_nan=True)
+    # natural image: the matcher works at arbitrary distances (token histogram of the parse) and the streams are close to zlib level 9's
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    enc = codec.compress_batch(golden_image("natural/baboon")[None])
+    ctx = codec._bind()
+    t = ctx.torch
+    p = enc.plan
+    nbytes = int(ctx.lib.aej_deflate_workspace_bytes(ctx.handle, 1, p.H, p.W))
+    ws = ctx.workspace(nbytes)
+    hist = ctx.empty((3, DT.HIST_BINS), t.int32)
+    import ctypes
+    ctx.check(ctx.lib.aej_deflate_histogram(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), 1, p.H, p.W, hist.data_ptr(), ws.data_ptr(),
+                                            ctypes.c_uint64(nbytes)))
+    h = hist.cpu().numpy()
+    dist = h[0, 286:316]
+    assert dist[:4].sum() > 0 and dist[4:10].sum() > 0 and dist[10:18].sum() > 0 and dist[18:].sum() > 0, dist      # <= 4, <= 32, <= 512, beyond
+    assert dist[14:].sum() > 0.2 * dist.sum(), dist                      # a fifth of the matches come from more than 128 bytes back
+    assert h[0, 256] == 1 and h[0, :256].sum() > 0
+    gpu_bytes = sum(len(x) for x in codec.deflate_batch(enc)[0])
+    z9 = sum(len(zlib.compress(enc.layer(0, l)["coeffs"].tobytes(), 9)) for l in range(3))
+    z1 = sum(len(zlib.compress(enc.layer(0, l)["coeffs"].tobytes(), 1)) for l in range(3))
+    assert gpu_bytes < 1.2 * z9 and gpu_bytes < z1, (gpu_bytes, z9, z1)
     # Jpeg.compress's keyword-only opt-ins: same container layout, decoded by the default reader
     img = A.Image.from_array(golden_image("natural/house"), None, ".png")
     codec = A.Jpeg(A.JpegCompressionSettings("YCoCg", (40, 80), (4, 64)))
@@ -586,9 +606,8 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
                                                    A.Jpeg(A.JpegCompressionSettings()).decompress(ref_bytes).data), kw
     with pytest.raises(ValueError):
         codec.compress(img, entropy="cpu")
-    # a stream slot that is too small is refused, not overrun
-    import ctypes
-    from adaptive_edge_aware_jpeg_amd._lib import AejError, get_context
+    # a stream slot that is too small is refused, not overrun; a count beyond its layer's capacity is refused, not followed
+    from adaptive_edge_aware_jpeg_amd._lib import get_context
     ctx = get_context()
     enc = codec.compress_batch(img.data[None])
     p = enc.plan
@@ -596,9 +615,17 @@ def test_gpu_deflate_streams_are_zlib_streams_of_the_coefficients(A, oracle):
     streams, sizes = ctx.empty((3, 256), t.uint8), ctx.empty((3,), t.int64)
     nbytes = int(ctx.lib.aej_deflate_workspace_bytes(ctx.handle, 1, p.H, p.W))
     ws = ctx.workspace(nbytes)
-    rc = ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), 1, p.H, p.W, None, streams.data_ptr(),
+    rc = ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), enc.counts.data_ptr(), 1, p.H, p.W, None, 0, streams.data_ptr(),
                                    ctypes.c_uint64(256), sizes.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes))
     assert rc == -4 and int(sizes.cpu()[0]) > 256          # AEJ_ERR_CAPACITY, and the size it would have needed is reported
+    bad_counts = enc.counts.clone()
+    bad_counts[0, 1, 0] = 1 << 40
+    cap = max((p.coeff_off[l + 1] if l < 2 else p.coeff_stride) - p.coeff_off[l] for l in range(3))
+    stride = (int(ctx.lib.aej_deflate_stream_bound(ctypes.c_uint64(4 * cap))) + 255) // 256 * 256
+    streams = ctx.empty((3, stride), t.uint8)
+    rc = ctx.lib.aej_deflate_batch(ctx.handle, enc.coeffs.data_ptr(), bad_counts.data_ptr(), 1, p.H, p.W, None, 0, streams.data_ptr(),
+                                   ctypes.c_uint64(stride), sizes.data_ptr(), ws.data_ptr(), ctypes.c_uint64(nbytes))
+    assert rc == -1                                          # AEJ_ERR_ARG
     # an empty layer cannot occur in the codec, but the stream format must still close: one image of the smallest shape the settings allow
     tiny = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (2, 2)))
     enc = tiny.compress_batch(np.full((1, 4, 4, 3), 0.25, np.float32))

@@ -123,7 +123,7 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.aej_abi_version() == 2
+    assert lib.aej_abi_version() == 3
     # host-only geometry helpers (no device needed)
     lc, sc, cc = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     assert lib.aej_quadtree_capacity(2160, 3840, 4, 64, ctypes.byref(lc), ctypes.byref(sc), ctypes.byref(cc)) == 0
@@ -205,12 +205,13 @@ def test_hardware_queue_policy_import_has_no_side_effect():
     assert run("import adaptive_edge_aware_jpeg_amd as A; A.set_hw_queues(24); print(A.hw_queues()[0])") == "24"
 
 
-def test_deflate_tables_and_reference_encoder_round_trip_through_zlib():
-    """Host side of the opt-in GPU entropy stage: the Huffman tables / dynamic-block headers built in deflate_tables.py, driven through
-    the pure-Python restatement of the kernels' parser and bit packer, must give streams `zlib.decompress` (the reference's decoder call,
-    jpeg.py:659) reads back exactly -- fixed code, adaptive code, a table counted on OTHER data, empty / tiny / incompressible inputs."""
+def test_deflate_tables_round_trip_through_zlib():
+    """Host side of the opt-in GPU entropy stage: the Huffman tables / dynamic-block headers (restated in tests/deflate_reference.py, the
+    construction aej_deflate_build_tables follows), driven through a small token-level encoder, must give streams `zlib.decompress` (the
+    reference's decoder call, jpeg.py:659) reads back exactly -- fixed code, adaptive code, a table counted on OTHER data, empty / tiny /
+    incompressible inputs, matches at every distance class."""
     import zlib
-    from adaptive_edge_aware_jpeg_amd import deflate_tables as DT
+    import deflate_reference as DT
     rng = np.random.default_rng(0)
 
     def coeff_like(n, p_nonzero, scale):
@@ -218,31 +219,40 @@ def test_deflate_tables_and_reference_encoder_round_trip_through_zlib():
         m = rng.random(n) < p_nonzero
         v[m] = np.round(rng.laplace(0, scale, int(m.sum()))).astype(np.int32)
         return v.tobytes()
-    cases = {"sparse": coeff_like(20000, 0.05, 2), "dense": coeff_like(12000, 0.6, 6), "large values": coeff_like(9000, 0.3, 3000),
-             "zeros": bytes(70000), "one coefficient": b"\x01\x00\x00\x00", "empty": b"", "noise": rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()}
+    cases = {"sparse": coeff_like(1500, 0.05, 2), "dense": coeff_like(1200, 0.6, 6), "large values": coeff_like(900, 0.3, 3000),
+             "zeros": bytes(3000), "one coefficient": b"\x01\x00\x00\x00", "empty": b"", "noise": rng.integers(0, 256, 1500, dtype=np.uint8).tobytes()}
     fixed = DT.fixed_table()
-    assert fixed.shape == (DT.TABLE_WORDS,) and int(fixed[288]) == 3
-    foreign = DT.adaptive_table(*DT.histogram_reference(cases["sparse"]))
+    assert fixed.shape == (DT.TABLE_WORDS,) and int(fixed[DT.HDR_BITS_AT]) == 3
+    foreign = None
     for name, data in cases.items():
-        assert zlib.decompress(DT.encode_reference(data, fixed)) == data, name
-        own = DT.adaptive_table(*DT.histogram_reference(data))
-        assert int(own[288]) <= DT.HEADER_WORDS * 32 and all(0 < (int(e) >> 16) <= 15 for e in own[:288])
-        assert zlib.decompress(DT.encode_reference(data, own)) == data, name
-        assert zlib.decompress(DT.encode_reference(data, foreign)) == data, name + " (foreign table)"
-        # exact tables (cover_all=False: what Jpeg.deflate_batch builds -- codes only for the symbols the SAME data contains): valid, and never
+        tok = DT.greedy_tokens(data)
+        hist = DT.histogram_of(tok)
+        assert zlib.decompress(DT.encode_tokens(data, tok, fixed)) == data, name
+        own = DT.adaptive_table(hist[:286], hist[286:316])
+        assert int(own[DT.HDR_BITS_AT]) <= DT.HEADER_WORDS * 32 and all(0 < (int(e) >> 16) <= 15 for e in own[:316])
+        assert zlib.decompress(DT.encode_tokens(data, tok, own)) == data, name
+        if foreign is None:
+            foreign = own                       # (a cover-everything table counted on the first case: valid for every other one)
+        assert zlib.decompress(DT.encode_tokens(data, tok, foreign)) == data, name + " (foreign table)"
+        # exact tables (cover_all=False: what Jpeg.deflate_batch builds -- codes only for the symbols the SAME parse contains): valid, and never
         # larger than the cover-everything table
-        if data:
-            exact = DT.adaptive_table(*DT.histogram_reference(data), cover_all=False)
-            enc_exact = DT.encode_reference(data, exact)
-            assert zlib.decompress(enc_exact) == data, name + " (exact table)"
-            assert len(enc_exact) <= len(DT.encode_reference(data, own)) + 16, name       # (when nearly every symbol occurs the two are the same code)
-            if name in ("sparse", "zeros", "one coefficient"):
-                assert int(exact[288]) < int(own[288]) - 100, name              # few symbols: a shorter block header
-    # the adaptive code pays on coefficient-like data: well below the fixed code, within 1.5 x of zlib level 9
-    d = cases["dense"]
-    own = DT.adaptive_table(*DT.histogram_reference(d))
-    assert len(DT.encode_reference(d, own)) < 0.6 * len(DT.encode_reference(d, fixed))
-    assert len(DT.encode_reference(d, own)) < 1.5 * len(zlib.compress(d, 9))
+        exact = DT.adaptive_table(hist[:286], hist[286:316], cover_all=False)
+        enc_exact = DT.encode_tokens(data, tok, exact)
+        assert zlib.decompress(enc_exact) == data, name + " (exact table)"
+        assert len(enc_exact) <= len(DT.encode_tokens(data, tok, own)) + 16, name
+        if name in ("sparse", "zeros", "one coefficient", "empty"):
+            assert int(exact[DT.HDR_BITS_AT]) < int(own[DT.HDR_BITS_AT]) - 100, name      # few symbols: a shorter block header
+    # every distance class and the longest length, from a hand-made parse: 40 random bytes, a long zero run, the 40 bytes again from 32 000 back
+    far = bytes(rng.integers(1, 256, 40, dtype=np.uint8))
+    tok = [("lit", b) for b in far] + [("lit", 0)] + [("match", 258, 1)] * 123 + [("match", 225, 1)] + [("match", 40, 32000)]
+    data = far + bytes(32000 - 40) + far
+    for d in (1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 32040):
+        tok.append(("match", 3, d))
+        data += data[len(data) - d:len(data) - d + 3] if d >= 3 else (data[-d:] * 3)[:3]
+    hist = DT.histogram_of(tok)
+    assert (hist[286:316] > 0).all()
+    assert zlib.decompress(DT.encode_tokens(data, tok, DT.adaptive_table(hist[:286], hist[286:316], cover_all=False))) == data
+    assert zlib.decompress(DT.encode_tokens(data, tok, fixed)) == data
     # length-limited Huffman: Kraft equality for a skewed histogram that plain Huffman would give codes longer than 15 bits
     skew = [2 ** i for i in range(30)]
     ls = DT.huffman_lengths(skew, 15)
@@ -270,21 +280,27 @@ def test_bench_asks_for_more_hardware_queues_when_it_will_hold_a_process_group(m
 
 
 def test_library_builds_the_same_huffman_tables_as_the_python_restatement():
-    """aej_deflate_build_tables (host-only C++ in csrc/deflate.hip, what Jpeg.deflate_batch calls) against deflate_tables.adaptive_table
-    (the readable restatement the reference encoder and the CPU tests use): word for word, for skewed, flat, sparse and empty histograms,
-    in both cover modes -- including histograms whose plain Huffman code would be longer than 15 bits."""
-    import ctypes
-    from adaptive_edge_aware_jpeg_amd import deflate_tables as DT
+    """aej_deflate_build_tables (host-only C++ in csrc/deflate.hip, what Jpeg.deflate_batch calls) against tests/deflate_reference.py's
+    adaptive_table (the readable restatement): word for word, for skewed, flat, sparse and empty histograms, in both cover modes --
+    including histograms whose plain Huffman code would be longer than 15 bits."""
+    import deflate_reference as DT
+    from adaptive_edge_aware_jpeg_amd import deflate_tables as PKG
     from adaptive_edge_aware_jpeg_amd._lib import load_library
+    assert (PKG.HIST_BINS, PKG.TABLE_WORDS) == (DT.HIST_BINS, DT.TABLE_WORDS)
+    header = open(os.path.join(ROOT, "include", "aej.h")).read()
+    assert f"#define AEJ_DEFLATE_HIST_BINS {DT.HIST_BINS}" in header and f"#define AEJ_DEFLATE_TABLE_WORDS {DT.TABLE_WORDS}" in header
     lib = load_library()
     rng = np.random.default_rng(7)
-    hists = [np.zeros(288, np.int32), np.ones(288, np.int32)]
+    nb = DT.HIST_BINS
+    hists = [np.zeros(nb, np.int32), np.ones(nb, np.int32)]
     for trial in range(60):
-        h = (rng.random(288) ** int(rng.integers(1, 8)) * 10.0 ** int(rng.integers(1, 8))).astype(np.int64)
-        h[rng.random(288) < rng.random()] = 0                       # a random share of symbols never occurs
-        h[286:288] = rng.integers(0, 1000, 2)
+        h = (rng.random(nb) ** int(rng.integers(1, 8)) * 10.0 ** int(rng.integers(1, 8))).astype(np.int64)
+        h[rng.random(nb) < rng.random()] = 0                        # a random share of symbols never occurs
+        if trial % 5 == 0:
+            h[286:316] = 0                                          # a stream without a single match
         hists.append(np.minimum(h, 2 ** 31 - 1).astype(np.int32))
-    fib = np.zeros(288, np.int32); fib[:40] = [min(int(1.6 ** k), 2 ** 30) for k in range(40)]     # plain Huffman: depths far beyond 15
+    fib = np.zeros(nb, np.int32); fib[:40] = [min(int(1.6 ** k), 2 ** 30) for k in range(40)]      # plain Huffman: depths far beyond 15
+    fib[286:316] = fib[:30]
     hists.append(fib)
     for k in range(0, len(hists) - 2, 3):
         hist = np.ascontiguousarray(np.stack(hists[k:k + 3]), dtype=np.int32)
@@ -293,13 +309,13 @@ def test_library_builds_the_same_huffman_tables_as_the_python_restatement():
             tab = np.full((3, DT.TABLE_WORDS), 0xdeadbeef, np.uint32)
             assert lib.aej_deflate_build_tables(hist.ctypes.data, cov.ctypes.data, tab.ctypes.data) == 0
             for l in range(3):
-                want = DT.adaptive_table(hist[l, :286], hist[l, 286:288], cover_all=bool(cover[l]))
+                want = DT.adaptive_table(hist[l, :286], hist[l, 286:316], cover_all=bool(cover[l]))
                 assert np.array_equal(tab[l], want), (k, l, cover, np.flatnonzero(tab[l] != want)[:8])
     # NULL cover = every symbol gets a code
     tab = np.zeros((3, DT.TABLE_WORDS), np.uint32)
     hist = np.ascontiguousarray(np.stack(hists[2:5]), dtype=np.int32)
     assert lib.aej_deflate_build_tables(hist.ctypes.data, None, tab.ctypes.data) == 0
-    assert all(np.array_equal(tab[l], DT.adaptive_table(hist[l, :286], hist[l, 286:288])) for l in range(3))
+    assert all(np.array_equal(tab[l], DT.adaptive_table(hist[l, :286], hist[l, 286:316])) for l in range(3))
 
 
 def test_pack_u8_levels_host_helper():
