@@ -172,10 +172,7 @@ constexpr int kAIter = (kBAH + kASlots - 1) / kASlots;   // 6
 constexpr int kBRows = (kBGH + kASlots - 1) / kASlots;      // Gaussian output rows per thread: rows kBRows * (t / 34) .. + kBRows - 1
 static_assert(kASlots * kBRows >= kBGH && kASlots * kAIter >= kBAH, "thread -> row mapping must cover the tile");
 constexpr float kTwo24 = 16777216.0f, kTwo22 = 4194304.0f;
-#ifndef AEJ_X_BLUR_HIST
-#define AEJ_X_BLUR_HIST 6
-#endif
-constexpr int kHistCopies = AEJ_X_BLUR_HIST;             // (6 copies: 39.5 KiB per workgroup, so that three of them leave the colour kernel its 38 KiB --
+constexpr int kHistCopies = 6;                           // (6 copies: 39.5 KiB per workgroup, so that three of them leave the colour kernel its 38 KiB --
                                                         // with the tiled planes it stages four rows per half-wave; 8 and 16 copies measured the same speed)
 constexpr int kHistStride = 257;          // dwords per histogram copy: odd, so the same bin of different copies sits in different banks
 
@@ -197,22 +194,8 @@ struct __attribute__((aligned(16))) BlurLds {
     float4 P[2][256];                // packed LUTs: slot 0 = class 0 of both axes, slot 1 = class 1 of the ONE axis that changes
     unsigned int A[kBAH * kBAW4];    // CLAHE image, one byte per pixel
     unsigned int G[kBGH * kBGW2];    // Gaussian image, one halfword per pixel: the integer 4 * value = the float16 DENORMAL 4 * value * 2^-24
-#ifdef AEJ_X_BLUR_PAD
-    char pad[AEJ_X_BLUR_PAD];        // experiment (tools/profiling/variants.py): a larger footprint caps the workgroups per CU
-#endif
 };
-#ifndef AEJ_X_BLUR_PAD
 static_assert(3 * sizeof(BlurLds) <= 160 * 1024, "three workgroups per CU");
-#endif
-#ifndef AEJ_X_BLUR_DYNLDS
-#define AEJ_X_BLUR_DYNLDS 0            // experiment: dynamic LDS the compiler does not see (caps the workgroups per CU without changing its register budget)
-#endif
-#ifndef AEJ_X_BLUR_WAVES
-#define AEJ_X_BLUR_WAVES 3
-#endif
-#ifndef AEJ_X_BLUR_ATTR
-#define AEJ_X_BLUR_ATTR __attribute__((amdgpu_waves_per_eu(AEJ_X_BLUR_WAVES, AEJ_X_BLUR_WAVES)))
-#endif
 
 // 13 taps in row-major order (OpenCV bilateral_filter, d = 5 => circular mask of radius 2): (dy, dx) =
 // (-2,0) (-1,-1) (-1,0) (-1,1) (0,-2) (0,-1) (0,0) (0,1) (0,2) (1,-1) (1,0) (1,1) (2,0).  The weight of a tap is
@@ -299,24 +282,13 @@ __device__ __forceinline__ bool locate_blur_strip(const Geom &g, int strip, int 
     return false;
 }
 
-#ifdef AEJ_X_BLUR_STAMPS
-// diagnostic build only (tools/profiling/variants.py + blur_stamps.py): cycles per phase of the tile loop, per wave of the first 512 workgroups
-__device__ long long g_blur_stamps[512][4][10];
-#define AEJ_BSTAMP(i) { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
-extern "C" __attribute__((visibility("default"))) int aej_debug_read_blur_stamps(long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blur_stamps), sizeof(g_blur_stamps), 0, hipMemcpyDeviceToHost);
-}
-#else
-#define AEJ_BSTAMP(i)
-#endif
 
 // DUMP: the test hooks that copy the CLAHE / Gaussian intermediates out (aej_canny's stage outputs); the production instantiation does not
 // carry their pointers -- four scalar registers that, live across the tile loop, tipped the kernel into scalar-register spills, and a
 // spilled scalar lives in a lane of a VECTOR register (v144 held nothing else).  Without them the kernel needs 136 vector registers
 // instead of 145: a 136- instead of a 152-register allocation, 104 instead of 56 free registers per SIMD lane beside three workgroups
 template <bool DUMP>
-__global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD (136 VGPRs), 39.5 KiB LDS
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_clahe_blur(Geom g, CannyBuffers cb, int strip)      // 3 waves per SIMD (136 VGPRs), 39.5 KiB LDS
 {
     __shared__ BlurLds L;
     const int tid = threadIdx.x;
@@ -339,9 +311,6 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         return x0 >= 4 && y0 >= 3 && x0 + kBTW + 4 <= w && y0 + kBTH + 3 <= h && (w % 4) == 0;
     };
     unsigned int raw[kAIter];
-#ifdef AEJ_X_BLUR_STAMPS
-    long long st_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = __builtin_amdgcn_s_memtime();
-#endif
     blur_prefetch(src, w, h, tx_begin * kBTW, y0, is_aligned(tx_begin), raw);      // flies while the per-strip tables are built
 
     // ---- per-strip set-up (the two rounds of the table loop unrolled: their global loads overlap instead of following each other)
@@ -383,7 +352,6 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         if (tid == 0) L.cls[5] = n;            // read by every tile's prologue after its own barrier
     }
     unsigned char *dst = cb.u8b + pbase;
-    AEJ_BSTAMP(0)
 
     for (int tx = tx_begin; tx < tx_end; tx++) {
         const int x0 = tx * kBTW;
@@ -439,7 +407,6 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
         // Thread -> work mappings are re-derived per tile from a copy of the thread id the compiler cannot see through: otherwise
         // it hoists a few dozen per-thread LDS addresses out of the tile loop and, with stage C needing the whole register
         // budget, parks them in scratch memory.
-        AEJ_BSTAMP(1)
         int tq = tid;
         asm volatile("" : "+v"(tq));
         const int acol = tq % kBAW4, aslot = tq / kBAW4;      // stage A / B: this thread's column dword and row slot / row group
@@ -492,10 +459,8 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
             }
         }
         // raw[] is free again: the next tile's bytes fly while this tile runs stages B and C
-        AEJ_BSTAMP(2)
         if (tx + 1 < tx_end) blur_prefetch(src, w, h, (tx + 1) * kBTW, y0, is_aligned(tx + 1), raw);
         __syncthreads();
-        AEJ_BSTAMP(3)
         if (DUMP && cb.dump_clahe)
             for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
                 int j = idx / kBTW, i = idx - j * kBTW;
@@ -536,9 +501,7 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
                 }
             }
         }
-        AEJ_BSTAMP(4)
         __syncthreads();
-        AEJ_BSTAMP(5)
         if (DUMP && cb.dump_gauss)
             for (int idx = tid; idx < kBTH * kBTW; idx += kBT) {
                 int j = idx / kBTW, i = idx - j * kBTW;
@@ -708,17 +671,8 @@ __global__ __launch_bounds__(kBT) AEJ_X_BLUR_ATTR void k_clahe_blur(Geom g, Cann
                 }
             }
         }
-#ifdef AEJ_X_BLUR_STAMPS
-        AEJ_BSTAMP(6)
-        st_acc[7] += 1;
-#endif
     }
     __syncthreads();
-#ifdef AEJ_X_BLUR_STAMPS
-    AEJ_BSTAMP(8)
-    if ((tid & 63) == 0 && blockIdx.x < 512)
-        for (int i = 0; i < 10; i++) g_blur_stamps[blockIdx.x][tid >> 6][i] = st_acc[i];
-#endif
     if (tid < 256) {
         unsigned int c = 0;
 #pragma unroll
@@ -1015,9 +969,7 @@ constexpr int kDppRowShl1 = 0x101, kDppRowShr1 = 0x111, kDppRowShr2 = 0x112;
 
 struct NmsRowH { unsigned s[3], d[3]; };        // per source row: [1 2 1] sums and right-minus-left differences of the pixel pairs (-1, 2), (0, 3), (1, 4)
 
-#ifndef AEJ_X_SOBEL_DEPTH
-#define AEJ_X_SOBEL_DEPTH 4            // source rows in flight ahead of the row being worked on (round 4; 20 = all of them up front, as in round 3)
-#endif
+constexpr int kSobelDepth = 4;         // source rows in flight ahead of the row being worked on (round 4; 20 = all of them up front, as in round 3)
 // one 64 x 64 tile; EDGE = the tile touches the plane's border (clamped source coordinates, magnitudes outside the image are 0)
 template <bool L2, bool EDGE>
 __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__ src, int w, int h, int tx, int ty, int low, int high,
@@ -1055,7 +1007,7 @@ __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__
         }
     };
     // kDepth source rows are in flight ahead of the row being worked on: all twenty up front cost forty registers for the whole tile
-    constexpr int kDepth = AEJ_X_SOBEL_DEPTH < kRows ? AEJ_X_SOBEL_DEPTH : kRows;
+    constexpr int kDepth = kSobelDepth < kRows ? kSobelDepth : kRows;
 #pragma unroll
     for (int u = 0; u < kDepth; u++) fetch(u);
 
@@ -1163,17 +1115,14 @@ __device__ __forceinline__ void sobel_nms_tile(const unsigned char *__restrict__
     }
 }
 
-#ifndef AEJ_X_SOBEL_MINW
 // Waves per SIMD the register budget is cut for.  Round 3 loaded a tile's twenty source rows up front (forty registers for the whole tile):
-// 96 registers, five waves.  Round 4 keeps AEJ_X_SOBEL_DEPTH rows in flight instead, which frees the registers for more waves, and more
+// 96 registers, five waves.  Round 4 keeps 4 rows in flight instead, which frees the registers for more waves, and more
 // waves hide the latency the shorter look-ahead exposes (profiles/r04_ab_sobel_occupancy.txt, 64 x 4K, stage / step in ms):
 //   5 waves, all rows up front 0.77 / 5.84-5.93     6 waves, 8 rows 0.724 / 5.72-5.80     7 waves, 4 rows 0.70 / 5.73-5.83
 //   8 waves, 4 rows (64 registers, two spilled dwords) 0.69 / 5.75-5.80  <- this       8 waves, 5 rows: slower (36 bytes of spills)
 // (natural images: 0.905 -> 0.86 ms.)
-#define AEJ_X_SOBEL_MINW 8
-#endif
 template <bool L2>
-__global__ __launch_bounds__(256, AEJ_X_SOBEL_MINW) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int xcd_contiguous)
+__global__ __launch_bounds__(256, 8) void k_sobel_nms_reg(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int xcd_contiguous)
 {
     const int lane = threadIdx.x & 63;
     // the tile index as a 32-bit SCALAR (wave index through readfirstlane): the division by the tiles per image, the walk over the layers and
@@ -1435,10 +1384,7 @@ __device__ __forceinline__ void hyst_chase(const Geom &g, const CannyBuffers &cb
 // starts: the kernel boundary is the barrier -- no list, no counter, no polling), clears them and chases each flagged tile; what that
 // dirties is flagged in the other parity (k < last) or queued for the drain (k == last, de-duplicated by the other parity's flags, all
 // zero again by then).
-#ifndef AEJ_X_HYST_GROUP
-#define AEJ_X_HYST_GROUP 4
-#endif
-constexpr int kBulkGroup = AEJ_X_HYST_GROUP;
+constexpr int kBulkGroup = 4;
 template <bool RING>
 __global__ __launch_bounds__(256) void k_hyst_bulk(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int k, int ring_mask)
 {
@@ -1469,15 +1415,13 @@ __global__ __launch_bounds__(256) void k_hyst_bulk(Geom g, CannyBuffers cb, long
 // a running one to finish its tile, so the launch needs no co-residency.  Waiting waves poll two counters: the launch is kept small
 // (more waves measured slower: 64 x 4K hysteresis stage 0.48 / 0.53 / 0.66 / 0.83 ms with 256 / 512 / 1024 / 2048 workgroups draining
 // everything the first launch dirtied), which is why large batches run two bulk launches first.
-#ifndef AEJ_X_HYST_CHUNK
-#define AEJ_X_HYST_CHUNK 4             // tickets a wave claims at once: one claim, one round of slot reads and one round of flag clears per chunk
-#endif
+constexpr int kHystChunk = 4;          // tickets a wave claims at once: one claim, one round of slot reads and one round of flag clears per chunk
 // (Measured and dropped: the first look at every tile folded into this launch as "virtual" tickets, one launch in all for a single image --
 // 0.062 against 0.044 ms for the two launches: the first look then pays agent-scope loads and every wave of it polls at the end.)
 __global__ __launch_bounds__(256) void k_hyst_drain(Geom g, CannyBuffers cb, long long tiles_per_img, long long total_tiles, int parity, int ring_mask)
 {
     // tickets per claim: latency-sized problems (a few images) have a short queue and plenty of waves: one entry per wave at a time
-    const int K = total_tiles <= 8192 ? 1 : AEJ_X_HYST_CHUNK;
+    const int K = total_tiles <= 8192 ? 1 : kHystChunk;
     const int lane = threadIdx.x & 63;
     const HystOut q = hyst_out(cb, parity, true, total_tiles, ring_mask);
     int *head = cb.pass_count + kQHead, *done_p = cb.pass_count + kQDone;
@@ -1640,9 +1584,9 @@ void launch_clahe_blur(hipStream_t st, const Geom &g, const CannyBuffers &cb)
     }
     const int strip = pick_strip(g, kBTW, kBTH, best, 1024);             // 256 CUs x 2 resident workgroups x 2
     if (cb.dump_clahe || cb.dump_gauss)
-        hipLaunchKernelGGL(k_clahe_blur<true>, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), AEJ_X_BLUR_DYNLDS, st, g, cb, strip);
+        hipLaunchKernelGGL(k_clahe_blur<true>, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), 0, st, g, cb, strip);
     else
-        hipLaunchKernelGGL(k_clahe_blur<false>, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), AEJ_X_BLUR_DYNLDS, st, g, cb, strip);
+        hipLaunchKernelGGL(k_clahe_blur<false>, dim3((unsigned)(strips_per_image(g, kBTW, kBTH, strip) * g.B)), dim3(kBT), 0, st, g, cb, strip);
 }
 
 void launch_thresholds(hipStream_t st, const Geom &g, const CannyBuffers &cb)
@@ -1673,16 +1617,11 @@ void launch_sobel_nms(hipStream_t st, const Geom &g, const CannyBuffers &cb, con
 // The launches of the hysteresis: every tile once; for large batches two bulk launches over the tiles flagged by the launch before
 // (synthetic bench batch: a tenth of the tiles, then a fifth of that; natural images: three quarters, then a quarter); then the rest
 // drained to the fix-point on the device by one small persistent launch.
-#ifndef AEJ_X_HYST_DRAIN_WGS
-#define AEJ_X_HYST_DRAIN_WGS 64
-#endif
+constexpr int kHystDrainWgs = 64;
 
 int hyst_bulk_launches(const Geom &g)
 {
     const long long total = hyst_tiles_per_image(g) * g.B;
-#ifdef AEJ_X_HYST_BULK
-    return AEJ_X_HYST_BULK;
-#endif
     return total > 32768 ? 2 : total > 8192 ? 1 : 0;
 }
 void launch_hysteresis(hipStream_t st, const Geom &g, const CannyBuffers &cb)
@@ -1699,9 +1638,9 @@ void launch_hysteresis(hipStream_t st, const Geom &g, const CannyBuffers &cb)
         if (k == nbulk) hipLaunchKernelGGL(k_hyst_bulk<true>, dim3(bulk_blocks), dim3(256), 0, st, g, cb, t, total, k, ring_mask);
         else hipLaunchKernelGGL(k_hyst_bulk<false>, dim3(bulk_blocks), dim3(256), 0, st, g, cb, t, total, k, ring_mask);
     }
-    // consumers of the queue: a wave per 16 tiles (per 4 for latency-sized problems), at most 4 x AEJ_X_HYST_DRAIN_WGS waves
+    // consumers of the queue: a wave per 16 tiles (per 4 for latency-sized problems), at most 4 x kHystDrainWgs waves
     long long drain = total <= 8192 ? (total + 15) / 16 : (total + 63) / 64;
-    if (drain > AEJ_X_HYST_DRAIN_WGS) drain = AEJ_X_HYST_DRAIN_WGS;
+    if (drain > kHystDrainWgs) drain = kHystDrainWgs;
     hipLaunchKernelGGL(k_hyst_drain, dim3((unsigned)drain), dim3(256), 0, st, g, cb, t, total, nbulk & 1, ring_mask);
 }
 

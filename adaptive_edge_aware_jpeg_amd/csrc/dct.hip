@@ -751,17 +751,6 @@ __device__ __forceinline__ void dct_load_x(const float *src, int w, int h, int t
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmem_but() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-#ifdef AEJ_X_STAMPS
-// diagnostic build only (tools/profiling/variants.py): cycles spent per phase of the leaf loop, summed per workgroup (wave 0)
-__device__ long long g_stamps[2][512][12];
-#define AEJ_STAMP(i) { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
-extern "C" __attribute__((visibility("default"))) int aej_debug_read_stamps(long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps), 0, hipMemcpyDeviceToHost);
-}
-#else
-#define AEJ_STAMP(i)
-#endif
 
 template <int S, bool WANT_DCT>
 __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const LeafWork *__restrict__ work /* = a.work, read-only: scalar loads */)
@@ -848,14 +837,7 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
     float qf[TPW][16];
     int q_layer = -1;
     bool q_slow = false;               // some quantiser of the layer is too large for the float32 quantiser (never for the codec's own tables)
-#ifdef AEJ_X_STAMPS
-    long long st_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = __builtin_amdgcn_s_memtime();
-#endif
     for (; item < count; item += step) {
-        AEJ_STAMP(7)
-#ifdef AEJ_X_STAMPS
-        st_acc[6] += 1;
-#endif
         int b, layer, lw, lhh;
         const float *src;
         plane_of(cur, b, layer, lw, lhh, src);
@@ -888,7 +870,6 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
             wait_vmem_but<0>();
         }
         lds_barrier();                    // X of this leaf has landed: every wave waited for its own pieces before arriving
-        AEJ_STAMP(0)
         if (NXB == 2 && item + step < count) {
             // prefetch the next leaf into the other buffer: it lands under this leaf's MFMA chains
             int bn, ln, wn, hn;
@@ -896,17 +877,14 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
             plane_of(nxt, bn, ln, wn, hn, srcn);
             dct_load_x<S, NWAVES>(srcn, wn, hn, g.tiled, make_int4(nxt.plane, nxt.x, nxt.y, nxt.coef), sXb + (pb ^ 1) * SS, wave, lane, xo);
         }
-        AEJ_STAMP(11)
         // entering a chunk: the chunk before it is finished, its buffer takes the chunk after this one (needed 64 leaves from now)
         if ((k & (kDescChunk - 1)) == 0 && k > 0) load_chunk(k / kDescChunk + 1);
-        AEJ_STAMP(1)
         floatx16 acc[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
         mfma_chain<S, TPW, kMfmaPF>(sX, (NT / TPW) * 32, wi0 * 32 + li, lh, dreg, acc);
-        AEJ_STAMP(2)
         // accumulator layout: row = (r & 3) + 8 * (r >> 2) + 4 * lh, col = li
 #pragma unroll
         for (int t = 0; t < TPW; t++)
@@ -916,14 +894,12 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
                 sP[((wi0 + t * (NT / TPW)) * 32 + row) * S + J0 + li] = acc[t][r];
             }
         lds_barrier();
-        AEJ_STAMP(3)
 
 #pragma unroll
         for (int t = 0; t < TPW; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
         mfma_chain<S, TPW, kMfmaPF>(sP, (NT / TPW) * 32, wi0 * 32 + li, lh, dreg, acc);
-        AEJ_STAMP(4)
         int *sQ = reinterpret_cast<int *>(sX);   // every wave finished reading sX before the barrier above
         // one range test per leaf for the float32 quantiser (|y| < 2^17 and q >= 1 give |y / q| < 2^18, its proven range)
         float ymax = 0.f;
@@ -948,12 +924,9 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
                 if (!__all(__builtin_fabsf(y) < 0.499f * qq)) v = slow ? quantise_f64(y, (int)qq) : quantise_f32(y, qq);
                 sQ[zigzag_pos<S>(row, J0 + li)] = v;
             }
-        AEJ_STAMP(8)
         lds_barrier();
-        AEJ_STAMP(9)
         for (int idx = tid * 4; idx < SS; idx += NTHREADS * 4)
             *reinterpret_cast<int4 *>(a.coeffs + out_base + idx) = *reinterpret_cast<const int4 *>(sQ + idx);
-        AEJ_STAMP(10)
         if (NXB == 2) wait_vmem_but<NYOUNG>();   // all but this leaf's stores: in particular the next leaf's X has landed
         else lds_barrier();               // single buffer: the next leaf's DMA must not overwrite sQ before every wave has read it
         k++;
@@ -961,12 +934,7 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
         // the descriptor after next: written to LDS at least one barrier ago (chunk k / 64 + 1 is stored when leaf k's chunk starts)
         nxt = uniform(s_desc[(k + 1) & (2 * kDescChunk - 1)]);
         pb ^= (NXB - 1);
-        AEJ_STAMP(5)
     }
-#ifdef AEJ_X_STAMPS
-    if (tid == 0 && blockIdx.x < 512)
-        for (int i = 0; i < 12; i++) g_stamps[S == 32 ? 0 : 1][blockIdx.x][i] = st_acc[i];
-#endif
 }
 
 // the kernel proper is a shell around the leaf loop above: with the arguments reaching the loop by reference the compiler's schedule of the
@@ -998,10 +966,7 @@ __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_
 //     a leaf with a non-zero coefficient up there takes the same slab path once per quarter.
 // Two waves per SIMD (<= 256 registers): while one is in its epilogue or waiting for memory the other's MFMAs have the pipe.
 // ------------------------------------------------------------------------------------------------
-#ifndef AEJ_X_W64_WAVES
-#define AEJ_X_W64_WAVES 8
-#endif
-constexpr int kW64Waves = AEJ_X_W64_WAVES;
+constexpr int kW64Waves = 8;
 constexpr int kW64Stride = 68;          // elements per row of the transposed tables: 16-byte aligned rows, conflict-free 16-byte reads
 struct __attribute__((aligned(16))) Wave64Lds {
     float dop[2][32][64];               // D operands: [wj][s][lane] = D[32 wj + li][2 s + lh]
@@ -1033,9 +998,6 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
     constexpr int S = 64;
     __shared__ Wave64Lds L;
     extern __shared__ int s_pref[];      // [nplanes + 1]
-#ifdef AEJ_X_STAMPS
-    const long long st_t0 = __builtin_amdgcn_s_memtime();
-#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // (the wave index as a SCALAR: everything derived from it -- the
                                                                                      // item, the leaf, its geometry -- then stays in scalar registers)
@@ -1180,24 +1142,11 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
     LeafU cur = leaf_at(item);
     load_x(cur);
     int *slab = L.slab[wave];
-#ifdef AEJ_X_STAMPS
-    long long st_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = __builtin_amdgcn_s_memtime();
-    st_acc[7] = st_last - st_t0;        // table set-up
-#endif
     for (; item < count; item += step) {
         const LeafU nxt = leaf_at(item + step);
-        AEJ_STAMP(0)
-#ifdef AEJ_X_STAMPS
-        st_acc[6] += 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        AEJ_STAMP(2)
-#endif
         const int b = cur.plane / 3, layer = cur.plane - 3 * b;
         const long long coff = layer == 0 ? q.coeff_off[0] : layer == 1 ? q.coeff_off[1] : q.coeff_off[2];
         const long long out_base = (long long)b * q.coeff_stride + coff + cur.coef;
-#ifdef AEJ_X_W64_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         // ---- chain 1: P tiles [wi][wj]
         floatx16 P[2][2];
 #pragma unroll
@@ -1221,11 +1170,9 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
                 bc = bn;
             }
         }
-        AEJ_STAMP(3)
         // the registers of X are free: the next leaf's pixels fly while this one is finished
         if (item + step < count) load_x(nxt);
         __builtin_amdgcn_sched_barrier(0);
-        AEJ_STAMP(1)
         // (P[wi][wj][r] is chain 2's A operand of step 16 wi + r: see pli)
         // ---- chain 2: Y tiles [iu][jv]
         floatx16 Y[2][2];
@@ -1252,12 +1199,8 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
                 bc = bn;
             }
         }
-        AEJ_STAMP(4)
         // ---- epilogue.  Accumulator register 4 gq + j of tile (iu, jv): u = 32 iu + 8 gq + 4 lh + j, v = 32 jv + li.
         // A group (tile, gq) whose smallest diagonal 32 iu + 32 jv + 8 gq is 45 or more lies entirely beyond zigzag position 1 024.
-#ifdef AEJ_X_W64_PRIO
-        __builtin_amdgcn_s_setprio(AEJ_X_W64_PRIO);
-#endif
         const float (*qT)[kW64Stride] = L.qT[layer];
         const float (*qlo)[16] = L.qlo[layer];
         // One vote per group of four rows: "every lane's four coefficients quantise to 0" (|y| < 0.499 x the smallest of the four
@@ -1362,13 +1305,8 @@ __global__ __launch_bounds__(kW64Waves * 64, 1) void k_dct64_wave(Geom g, QtGeom
                 }
             }
         }
-        AEJ_STAMP(5)
         cur = nxt;
     }
-#ifdef AEJ_X_STAMPS
-    if (lane == 0 && blockIdx.x * kW64Waves + wave < 512)
-        for (int i = 0; i < 12; i++) g_stamps[1][blockIdx.x * kW64Waves + wave][i] = st_acc[i];
-#endif
 }
 
 template <bool WANT_DCT>
