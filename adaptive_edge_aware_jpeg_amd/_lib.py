@@ -69,24 +69,20 @@ def _look_at_hw_queues():
 
 
 def configure_hw_queues(want=16):
-    """Explicit opt-in, to be called before the process's first HIP call (before `import torch` to be sure): puts
-    GPU_MAX_HW_QUEUES=<want> into this process's environment so that every stream of the library gets a hardware queue of its own, and
-    tells the library.  If torch is already imported the variable may have been read already: it is still set (it cannot hurt) but the
-    library keeps assuming HIP's default unless torch says HIP is not up yet.  Returns the queue count the library will schedule for."""
+    """Explicit opt-in, to be called BEFORE `import torch` (the HIP runtime reads GPU_MAX_HW_QUEUES once, when it initialises, and
+    torch.cuda.is_available() / device_count() already initialise it): puts GPU_MAX_HW_QUEUES=<want> into this process's environment so
+    that every stream of the library gets a hardware queue of its own, and tells the library.  If torch is already imported nobody can
+    know whether the runtime has read the variable: it is still set (it cannot hurt) but the library keeps HIP's default of 4 -- told 16
+    while the runtime has 4 it would put four sub-batches on streams that serialise, measured slower than the conservative schedule --
+    unless the application states the real value through set_hw_queues().  Returns the queue count the library will schedule for."""
     global _hw_queues, _hw_queues_source
     import sys
     if os.environ.get("GPU_MAX_HW_QUEUES") is not None:
         return _look_at_hw_queues()
-    torch = sys.modules.get("torch")
-    trusted = torch is None
-    if torch is not None:
-        try:
-            trusted = not bool(torch.cuda.is_initialized())
-        except Exception:
-            trusted = False
+    trusted = "torch" not in sys.modules
     os.environ["GPU_MAX_HW_QUEUES"] = str(int(want))
     if trusted:
-        _hw_queues, _hw_queues_source = int(want), "configure_hw_queues() before HIP initialised"
+        _hw_queues, _hw_queues_source = int(want), "configure_hw_queues() before torch was imported"
         for ctx in _contexts.values():
             ctx.check(ctx.lib.aej_set_hw_queues(ctx.handle, _hw_queues))
     return _hw_queues
@@ -104,6 +100,26 @@ def set_hw_queues(n):
 def hw_queues():
     """-> (queues the library schedules for, where the number comes from)"""
     return _hw_queues, _hw_queues_source
+
+
+_warned_queue_limited = False
+
+
+def warn_if_queue_limited(ctx, batch, H, W):
+    """Once per process: a call large enough for the library to cut it into four overlapping sub-batches runs the conservative schedule
+    because the library was told the HIP runtime has fewer than 8 hardware queues (its default is 4) -- the drop-in then runs about 10 %
+    below what bench.py measures.  Says how to get the wide schedule."""
+    global _warned_queue_limited
+    if _warned_queue_limited:
+        return
+    sch = ctx.schedule(batch, H, W)
+    if sch["limited_by_hw_queues"]:
+        _warned_queue_limited = True
+        import warnings
+        warnings.warn(f"adaptive_edge_aware_jpeg_amd: this call ({batch} x {W}x{H}) would run as more overlapping sub-batches with more hardware "
+                      f"queues; the library schedules for {sch['hw_queues']} ({_hw_queues_source}).  Put GPU_MAX_HW_QUEUES=16 into the environment "
+                      "(or call adaptive_edge_aware_jpeg_amd.configure_hw_queues()) before `import torch`, or state the runtime's real value with "
+                      "set_hw_queues().", RuntimeWarning, stacklevel=3)
 
 
 # name -> (restype, argtypes); exactly the symbols declared in include/aej.h

@@ -1078,6 +1078,8 @@ static int encode_end_impl(aej_ctx *ctx, int rc_begin)
         if (e != hipSuccess && !rc) rc = hip_fail(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
         if (rc) continue;
         if (p.flag[0]) { rc = fail(ctx, AEJ_ERR_CAPACITY, "internal capacity exceeded in the quadtree emit pass"); continue; }
+        // (bit 30 of the queue's tail counter: a wave of the hysteresis work queue waited longer than any correct run can make it -- canny.hip kQPoison)
+        if (p.flag[1] & 0x40000000) { rc = fail(ctx, AEJ_ERR_STATE, "the hysteresis work queue did not drain (internal error): the edge maps of this call are not trustworthy"); continue; }
         queued += p.flag[1];
     }
     if (rc) return rc;

@@ -1199,6 +1199,9 @@ __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed,
 //   tail = entries pushed so far, head = tickets handed to consumers, done = entries completely processed.
 // A tile is in the queue at most once at a time, so at most `tiles` slots are ever occupied.
 constexpr int kQTail = 32, kQHead = 64, kQDone = 96;
+// Every wait of the queue is bounded: a wave that waits longer than any correct run can make it (about a second) sets this bit in `tail`,
+// which every other wait sees; the launch drains and the host reports AEJ_ERR_STATE (api.hip reads `tail` back as the queue statistic).
+constexpr int kQPoison = 0x40000000, kQSpinLimit = 1 << 20, kQIdleLimit = 1 << 19;
 constexpr int kChaseDepth = 32;
 struct HystOut { int *flags; int *ring; int *tail; int ring_mask; };      // ring == nullptr: flags only
 __device__ __forceinline__ HystOut hyst_out(const CannyBuffers &cb, int parity, bool ring, long long total_tiles, int ring_mask)
@@ -1224,11 +1227,19 @@ __device__ __forceinline__ void hyst_push(const HystOut &q, long long nT)
         q.flags[nT] = 1;
     } else {
         if (atomicExch(&q.flags[nT], 1) != 0) return;
-        const int t = atomicAdd(q.tail, 1);
+        const int t = atomicAdd(q.tail, 1) & ~kQPoison;
         int *slot = &q.ring[t & q.ring_mask];
         // (second lap of the ring: the slot of ticket t - ring size was handed out at least `tiles` entries ago, its consumer has long
-        // emptied it; wait if not)
-        if (t > q.ring_mask) while (ld_agent_lane(slot) != 0) __builtin_amdgcn_s_sleep(2);
+        // emptied it; wait if not -- bounded, so that a logic error, or the lapped-ring interlock ADVICE r4 describes, ends the call with
+        // AEJ_ERR_STATE instead of hanging the device)
+        if (t > q.ring_mask) {
+            int spins = 0;
+            while (ld_agent_lane(slot) != 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kQSpinLimit) { atomicOr(q.tail, kQPoison); return; }
+                if ((spins & 1023) == 0 && (ld_agent_lane(q.tail) & kQPoison)) return;      // somebody has given up: so does this push
+            }
+        }
         __hip_atomic_store(slot, (int)nT + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1430,15 +1441,18 @@ __global__ __launch_bounds__(256) void k_hyst_drain(Geom g, CannyBuffers cb, lon
         if (lane == 0) my = atomicAdd(head, K);
         my = __builtin_amdgcn_readfirstlane(my);
         int next = my;                         // first ticket of the chunk not served yet
+        int idle = 0;                          // (every wait of the queue is bounded: kQPoison)
         while (next - (my + K) < 0) {
             int tail = ld_agent(q.tail);
+            if (tail & kQPoison) return;
             const int avail = (tail - (my + K) < 0 ? tail : my + K) - next;
             if (avail <= 0) {
                 const int done = ld_agent(done_p);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // `done` is read before `tail`
                 tail = ld_agent(q.tail);
-                if (done == tail) return;                                  // quiescent: the rest of this chunk will never be served
+                if (done == tail || (tail & kQPoison)) return;             // quiescent: the rest of this chunk will never be served (or: given up)
                 if (tail - next <= 0) __builtin_amdgcn_s_sleep(100);
+                if (++idle > kQIdleLimit) { if (lane == 0) atomicOr(q.tail, kQPoison); return; }
                 continue;
             }
             // lanes 0 .. avail-1 fetch one entry each: the slot (written, or about to be: its producer holds the ticket), then the tile's
@@ -1446,12 +1460,21 @@ __global__ __launch_bounds__(256) void k_hyst_drain(Geom g, CannyBuffers cb, lon
             int e = 0;
             if (lane < avail) {
                 int *slot = &q.ring[(next + lane) & ring_mask];
-                while ((e = ld_agent_lane(slot)) == 0) __builtin_amdgcn_s_sleep(1);
-                __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                (void)atomicExch(&q.flags[e - 1], 0);
+                int spins = 0;
+                while ((e = ld_agent_lane(slot)) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kQSpinLimit) { atomicOr(q.tail, kQPoison); break; }
+                }
+                if (e) {
+                    __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)atomicExch(&q.flags[e - 1], 0);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // flags cleared (performed at the L2) before any of the tiles is read
-            for (int i = 0; i < avail; i++) hyst_chase<true>(g, cb, (long long)__shfl(e, i) - 1, tiles_per_img, lane, q);
+            for (int i = 0; i < avail; i++) {
+                const int ei = __shfl(e, i);
+                if (ei) hyst_chase<true>(g, cb, (long long)ei - 1, tiles_per_img, lane, q);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // these entries' pushes (tail tickets, slots) before they count as done
             if (lane == 0) atomicAdd(done_p, avail);
             next += avail;

@@ -16,7 +16,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import tables
-from ._lib import AejError, get_context
+from ._lib import AejError, get_context, warn_if_queue_limited
 from .image import Image
 from .settings import JpegCompressionSettings
 
@@ -115,6 +115,7 @@ class Jpeg:
             raise ValueError("Input batch must be [B, H, W, 3].")
         B, H, W, _ = x.shape
         plan = ctx.plan(B, H, W)
+        warn_if_queue_limited(ctx, B, H, W)
         coeffs = ctx.empty((B * plan.coeff_stride,), t.int32)
         leaves = ctx.empty((B * plan.leaf_stride, 4), t.int32)
         states = ctx.empty((B * plan.state_stride,), t.uint8)

@@ -183,6 +183,15 @@ static inline float pow_third_f32(float x)
     return (float)fma(c, u, c);
 }
 
+static int g_oklab_independent_pow = 0;
+ORC_API void orc_set_oklab_independent_pow(int on) { g_oklab_independent_pow = on; }
+/* x^(float)(1/3) both ways, for the test that pins the short sequence to the general pow */
+ORC_API void orc_pow_third_array(const float *x, float *out, int64_t n, int independent)
+{
+    const double third = (double)(float)(1.0 / 3.0);
+    for (int64_t i = 0; i < n; i++) out[i] = independent ? (x[i] == 0.0f ? 0.0f : (float)orc_pow((double)x[i], third)) : pow_third_f32(x[i]);
+}
+
 /* common.py:131-159 */
 static inline double pq_inverse_eotf(double v, double m2)
 {
@@ -228,7 +237,13 @@ static void color_px(int space, float r, float g, float b, float *o)
     if (space == SP_XYZ) { o[0] = X; o[1] = Y; o[2] = Z; return; } /* XYZ.srgb_to_xyz, xyz.py:63-64 */
     if (space == SP_OKLAB) { /* oklab.py:71-75 */
         float l = dot3(M_OK_LMS + 0, X, Y, Z), m = dot3(M_OK_LMS + 3, X, Y, Z), s = dot3(M_OK_LMS + 6, X, Y, Z);
-        float lp = pow_third_f32(l), mp = pow_third_f32(m), sp = pow_third_f32(s); /* np.power(f32, python float) -> powf(x, (float)(1/3)) */
+        /* np.power(f32, python float) -> powf(x, (float)(1/3)).  g_oklab_independent_pow (tests only): the general float64 pow of this
+         * file instead of the short sequence the HIP kernel shares -- a path with no code in common with the kernel */
+        float lp, mp, sp;
+        if (g_oklab_independent_pow) {
+            const double third = (double)(float)(1.0 / 3.0);
+            lp = (float)orc_pow((double)l, third); mp = (float)orc_pow((double)m, third); sp = (float)orc_pow((double)s, third);
+        } else { lp = pow_third_f32(l); mp = pow_third_f32(m); sp = pow_third_f32(s); }
         o[0] = dot3(M_OK_LAB + 0, lp, mp, sp); o[1] = dot3(M_OK_LAB + 3, lp, mp, sp); o[2] = dot3(M_OK_LAB + 6, lp, mp, sp);
         return;
     }

@@ -100,6 +100,19 @@ def color_forward(space, rgb):
     return out
 
 
+def pow_third_array(x, independent=False):
+    """x ** float32(1 / 3) in float32: the short sequence the OKLAB kernel shares, or (independent) the general float64 pow"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().orc_pow_third_array(_p(x), _p(out), ctypes.c_int64(x.size), ctypes.c_int(1 if independent else 0))
+    return out
+
+
+def set_oklab_independent_pow(on):
+    """tests only: OKLAB's cube root through the general float64 pow (no code in common with the HIP kernel)"""
+    lib().orc_set_oklab_independent_pow(ctypes.c_int(1 if on else 0))
+
+
 def pow_array(x, y):
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty_like(x)

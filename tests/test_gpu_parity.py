@@ -41,6 +41,20 @@ def test_colour_convert_bit_exact(A, oracle, space):
     assert np.array_equal(A.convert("sRGB", space, x), oracle.color_forward(space, x))
 
 
+def test_oklab_against_a_path_that_shares_no_code_with_the_kernel(A, oracle):
+    """the oracle's OKLAB cube root is the kernel's own operation sequence (bit-exact test above); here the GPU output is
+    compared with the oracle running its general float64 pow instead -- a checker with nothing in common with csrc/aej_devmath.h."""
+    rng = np.random.default_rng(8)
+    x = rng.integers(0, 256, size=(100000, 3)).astype(np.float32) / np.float32(255.0)
+    oracle.set_oklab_independent_pow(True)
+    try:
+        ref = oracle.color_forward("OKLAB", x)
+    finally:
+        oracle.set_oklab_independent_pow(False)
+    got = A.convert("sRGB", "OKLAB", x)
+    assert np.abs(got - ref).max() <= 3e-7 and (got != ref).mean() < 0.02
+
+
 def test_colour_against_reference_golden(A):
     c = np.load(os.path.join(GOLDEN, "color_forward.npz"))
     x = c["rgb_u8"].astype(np.float32) / np.float32(255.0)
@@ -224,6 +238,35 @@ def test_whole_path_hysteresis_completes_on_the_device(A, ctx, oracle):
             assert np.array_equal(got["states"], ref[l]["states"]) and np.array_equal(got["leaves"], ref[l]["leaves"])
             assert np.array_equal(got["coeffs"], ref[l]["coeffs"])
     assert ctx.hysteresis_stats()["calls"] >= 2
+
+
+def test_hysteresis_serpentine_across_one_tile_border(A, ctx, oracle):
+    """ADVICE r4 asked for a contour that re-dirties the same few tiles again and again: a serpentine that crosses the border between two
+    tile columns 72 times from a handful of seeds.  The fix-point must be the oracle's on the stand-alone entry and on the whole path.
+    (It does NOT lap the work queue's ring: a wave follows a contour through 32 tiles before it queues anything, so this pattern costs 16
+    queue entries on 22 tiles, a 448 x 448 maze 92 on 81, noise 18 on 24 -- the ring holds more than `tiles` entries, and no input we know
+    pushes more than about one entry per tile.  What a lapped ring could do -- ADVICE r4's interlock -- is bounded instead: every wait of
+    the queue gives up after about a second and the call returns AEJ_ERR_STATE, canny.hip kQPoison.)"""
+    H, W = 448, 128                                   # 7 x 2 luma tiles (+ 4 x 1 per chroma layer): a ring of 32 slots
+    plane = np.repeat(np.linspace(0.0, 0.2, H, dtype=np.float32)[:, None], W, axis=1).copy()
+    amp = 0.036 + (0.05 - 0.036) * np.arange(W, dtype=np.float32) / W
+    rows = list(range(8, H - 8, 6))
+    for k, y in enumerate(rows):                      # faint horizontal lines across the tile border x = 64, joined at alternating ends
+        plane[y, 6:W - 6] += amp[6:W - 6]
+        x = W - 7 if k % 2 == 0 else 6
+        plane[y:y + 6, x] += amp[x]
+    edge, stages, thr = oracle.edge_pipeline(plane, return_stages=True)
+    _, nms = oracle.canny(stages[3], thr[0], thr[1], return_nms=True)
+    assert int(edge.sum()) > int((nms == 2).sum()) + 3000, "the pattern must depend on hysteresis propagation"
+    assert np.array_equal(A.EdgeDetection.canny(plane).astype(np.uint8), edge)
+    img = np.ascontiguousarray(np.repeat(plane[:, :, None], 3, axis=2))
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    ref = oracle.encode_image(img, "YCbCr", (40, 80), (4, 64))
+    enc = codec.compress_batch(img[None])
+    for l in range(3):
+        got = enc.layer(0, l)
+        assert np.array_equal(got["states"], ref[l]["states"]) and np.array_equal(got["leaves"], ref[l]["leaves"]) and np.array_equal(got["coeffs"], ref[l]["coeffs"])
+    assert 0 < ctx.hysteresis_stats()["queued"] < (1 << 30)          # (bit 30 = a wait of the queue gave up: would have raised above)
 
 
 # ------------------------------------------------------------------ a-9/a-10 quadtree

@@ -202,6 +202,9 @@ def test_hardware_queue_policy_import_has_no_side_effect():
     opt_in = "import adaptive_edge_aware_jpeg_amd as A, os; A.configure_hw_queues(); print(A.hw_queues()[0], os.environ.get('GPU_MAX_HW_QUEUES'))"
     assert run(opt_in) == "16 16"                                                   # explicit opt-in before torch: set and trusted
     assert run(opt_in, {"GPU_MAX_HW_QUEUES": "8"}) == "8 8"                         # never overrides the launcher
+    # after `import torch` nobody can know whether the runtime has read the variable (device_count() / is_available() initialise HIP):
+    # the variable is set, the library keeps HIP's default
+    assert run("import torch\n" + opt_in) == "4 16"
     assert run("import adaptive_edge_aware_jpeg_amd as A; A.set_hw_queues(24); print(A.hw_queues()[0])") == "24"
 
 

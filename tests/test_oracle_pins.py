@@ -23,6 +23,43 @@ def test_pow_accuracy(oracle):
     assert np.isnan(oracle.pow_array(np.array([-1.0]), 2.4)[0])
 
 
+def test_oklab_cube_root_sequence_against_the_general_pow(oracle):
+    """the oracle's OKLAB cube root (pow_third_f32, aej_oracle.c) is the operation sequence the HIP kernel shares, so it is
+    pinned here against paths that share nothing with it: the file's general float64 pow rounded to float32, and NumPy's float64 power --
+    over every lms value 8-bit images can reach (sRGB -> linear -> XYZ -> LMS of all grey levels and of 200 000 random colours), a dense
+    sweep of the float32 range the seed is valid for, and the guards (0, tiny, huge, negative).  At most one float32 ulp anywhere, and the
+    results must agree with the correctly rounded value in all but a small share of the inputs."""
+    t = np.float64(np.float32(1.0 / 3.0))
+    rng = np.random.default_rng(12)
+    rgb = np.concatenate([np.repeat(np.arange(256, dtype=np.float32)[:, None], 3, 1), rng.integers(0, 256, (200000, 3)).astype(np.float32)]) / np.float32(255)
+    xyz = oracle.color_forward("XYZ", rgb)
+    M = np.array([[0.8189330101, 0.3618667424, -0.1288597137], [0.0329845436, 0.9293118715, 0.0361456387], [0.0482003018, 0.2643662691, 0.6338517070]], np.float32)
+    lms = (xyz.astype(np.float32) @ M.T).astype(np.float32).ravel()
+    lms = lms[lms > 0]
+    sweep = np.exp(rng.uniform(np.log(1e-30), np.log(1e30), 400000)).astype(np.float32)
+    for x in (lms, sweep):
+        fast = oracle.pow_third_array(x)
+        indep = oracle.pow_third_array(x, independent=True)
+        exact = np.power(x.astype(np.float64), t)
+        correctly_rounded = exact.astype(np.float32)
+        ulp = np.spacing(np.abs(correctly_rounded))
+        assert np.abs(fast.astype(np.float64) - exact).max() / np.abs(exact).max() < 1 and (np.abs(fast - correctly_rounded) <= ulp).all()
+        assert (np.abs(indep - correctly_rounded) <= ulp).all()
+        assert (fast != correctly_rounded).mean() < 0.01 and (indep != correctly_rounded).mean() < 1e-4
+        assert (np.abs(fast - indep) <= ulp).all()
+    guards = np.array([0.0, 1e-38, 3e-39, 1e-31, 1e31, 3e38, 1.0, 8.0, 27.0], np.float32)
+    f, i = oracle.pow_third_array(guards), oracle.pow_third_array(guards, independent=True)
+    assert f[0] == 0.0 and i[0] == 0.0 and (np.abs(f[1:] - i[1:]) <= np.spacing(np.abs(i[1:]))).all()
+    assert np.isnan(oracle.pow_third_array(np.array([-1.0], np.float32))[0])
+    # the whole OKLAB transform through the independent pow: within one ulp of the cube roots' effect on the outputs
+    oracle.set_oklab_independent_pow(True)
+    try:
+        ref = oracle.color_forward("OKLAB", rgb)
+    finally:
+        oracle.set_oklab_independent_pow(False)
+    assert np.abs(oracle.color_forward("OKLAB", rgb) - ref).max() <= 3e-7
+
+
 def test_uint8_scaling_wraps_like_numpy_on_x86(oracle):
     v = np.array([-102.0, -2.55, 306.0, 0.0, 254.999, 255.0, 1.0], dtype=np.float32) / np.float32(255.0)
     got = oracle.to_u8(v)
