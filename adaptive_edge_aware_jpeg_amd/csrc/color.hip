@@ -496,9 +496,13 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                 unsigned n_c = TILED ? (unsigned)(RH == 2 ? plane_elem(1, g.w[1], (ya >> 1) & ~3, x0 >> 1) : plane_elem(1, g.w[1], ya, x0 >> 2)) + 4u * (unsigned)(tq & 31) : o_c;
                 int c_lo = (ya >> 1) & 3;          // (RH == 2) first row of the current chroma block this half-wave produces: 0, or 2 when the band starts
                                                    // in the middle of a block (CLAHE tiles 4 (mod 8) rows high) -- the other rows are another half-wave's
+                // Rows in flight.  float32 input: a row is 48 bytes per lane, two rows ahead is what 56 registers allow, and at one workgroup
+                // per CU that is 24 KiB in flight per CU -- enough to stream 6.4 GB in 2.1 ms.  8-bit input is 12 bytes per lane: the same
+                // two rows are 6 KiB per CU, and the kernel took the same 2.1 ms for a quarter of the bytes (round 4: "the colour stage is no
+                // longer HBM-bound and nobody looked at why" -- it is bound by bytes in flight, Little's law).  So the 8-bit instantiation
+                // requests its whole band -- up to eight rows, 24 registers -- before it converts the first one.
                 RowRaw<IN> rowA = strip_load_row<IN>(img, ioff);
-                for (int y = ya; y < yb; y += 2) {
-                    const RowRaw<IN> rowB = strip_load_row<IN>(img, ioff + in_row_bytes);
+                auto row_pair = [&](const RowRaw<IN> &rowB, int y) {
                     float a1[2], a2[2], b1[2], b2[2];
                     const int rb = y & 3;                 // row of the block (0 or 2: ya is a multiple of 4)
                     // (the lane index once more from a copy the compiler cannot see through: hoisted out of the row loop, the dozen LDS addresses
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                     do_row(rowA, a1, a2, norm0, raw0, u80, o_l, TILED ? st0 + (unsigned)(rb * 128 + ((lane32 ^ (4 * rb)) << 2)) : n_l, hcopy);
                     // the next row A (the band's last step re-reads row B instead: an unconditional load keeps the registers of
                     // rowA out of a copy at the loop's back edge)
-                    rowA = strip_load_row<IN>(img, ioff + (y + 2 < yb ? 2u : 1u) * in_row_bytes);
+                    if constexpr (!kU8) rowA = strip_load_row<IN>(img, ioff + (y + 2 < yb ? 2u : 1u) * in_row_bytes);
                     do_row(rowB, b1, b2, norm0, raw0, u80, o_l + (unsigned)g.w[0],
                            TILED ? st0 + (unsigned)((rb + 1) * 128 + ((lane32 ^ (4 * (rb + 1))) << 2)) : n_l + (unsigned)g.w[0], hcopy);
                     // ---- layers 1, 2 (chroma): INTER_AREA box mean
@@ -602,6 +606,25 @@ __global__ __launch_bounds__(256) void k_color_planes_strip(const IN *__restrict
                     } else {
                         n_l = o_l;
                         n_c = o_c;
+                    }
+                };
+                if constexpr (kU8) {
+                    RowRaw<IN> pre[7];                    // rows ya + 1 .. ya + 7 (the band is at most eight rows: strips are at most 64 rows high)
+#pragma unroll
+                    for (int k = 0; k < 7; k++) pre[k] = strip_load_row<IN>(img, ioff + (unsigned)(ya + 1 + k < yb ? 1 + k : yb - ya - 1) * in_row_bytes);
+                    __builtin_amdgcn_sched_barrier(0);       // (the loads are issued HERE, all of them, not sunk to their first use)
+#pragma unroll
+                    for (int sp = 0; sp < 4; sp++) {
+                        const int y = ya + 2 * sp;
+                        if (y < yb) {
+                            row_pair(pre[2 * sp], y);
+                            if (sp < 3) rowA = pre[2 * sp + 1];
+                        }
+                    }
+                } else {
+                    for (int y = ya; y < yb; y += 2) {
+                        const RowRaw<IN> rowB = strip_load_row<IN>(img, ioff + in_row_bytes);
+                        row_pair(rowB, y);
                     }
                 }
             }
