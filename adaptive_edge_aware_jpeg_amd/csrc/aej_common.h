@@ -62,6 +62,7 @@ struct Tuning {
     int dct64_kernel = 0;          // "dct64_kernel": 0 = by company (DctArgs::crowded), 1 = one wave per leaf, 4 = four waves per leaf
     int dct_small_workgroups = 0;  // "dct_small_workgroups": cap on the grids of the 4 / 8 / 16 kernels, 0 = automatic
     int sobel_lds = 0;             // "sobel_lds": 1 = the LDS-tiled Sobel / NMS kernel of rounds 1-2 for every shape
+    int dct_multi = 1;             // "dct_multi": 1 = calls of at most 8 Mpx run the DCTs of sizes 4 .. 64 as one launch (0: one launch per size)
     int sobel_xcd = 1;             // "sobel_xcd": 1 = each XCD works on a contiguous range of the register Sobel kernel's tiles (0: round-robin, rounds 3-4)
 };
 

@@ -97,6 +97,8 @@ struct DctArgs {
     int crowded = 0;          // other kernels are expected beside this launch (sub-batches, calls in flight): prefer kernels that share a CU
 };
 int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const Tuning &t);   // 0, or -1 when no kernel serves the request
+// latency-sized calls: the sizes 4 .. 64 in one launch (args / max_items indexed by size index); 0 = launched, 1 = not a call for it
+int launch_dct_multi(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs *args, const long long *max_items);
 // builds a work list from a leaf table (stand-alone aej_dct_quant_zigzag)
 void launch_work_from_leaves(hipStream_t st, const int *leaves, long long n, int bmin, int plane, LeafWork *const *work, int *work_count);
 

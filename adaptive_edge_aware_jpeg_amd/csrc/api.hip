@@ -747,23 +747,33 @@ extern "C" int aej_encode_plan(aej_ctx *ctx, int batch, int H, int W, aej_plan *
 }
 
 // everything behind the hysteresis: quadtree, then one DCT launch per block size
+constexpr long long kGraphAutoPixels = 8LL << 20;      // latency-sized calls: at most 8 Mpx (automatic graph mode, the one-launch DCT)
+
 static int enqueue_back(aej_ctx *ctx, const Geom &g, const QtGeom &q, EncodeWs &w, int32_t *coeffs, float *dct_f32)
 {
     hipStream_t st = ctx->stream;
     int rc;
     if ((rc = run_quadtree(ctx, g, q, w.qt, w.canny.cb.strong))) return rc;
     mark(ctx, AEJ_STAGE_QUADTREE);
+    DctArgs args[kMaxSizes];
     int k = 0;
     for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
-        DctArgs a;
+        DctArgs &a = args[k];
         a.norm = w.norm; a.coeffs = coeffs; a.dct_f32 = dct_f32;
         a.work = w.qt.qb.work[k]; a.work_count = w.qt.qb.work_count; a.k = k; a.nplanes = g.B * 3;
         a.scratch = w.big;
         a.D = ctx->d_D[k]; a.zzinv = ctx->d_zzinv[k];
         a.crowded = ctx->dct_crowded;
         for (int l = 0; l < 3; l++) a.qm[l] = ctx->d_qm[l][k];
-        if (launch_dct(st, s, g, q, a, w.qt.qb.work_cap[k], ctx->tune)) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, a.nplanes);
-        mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
+    }
+    // latency-sized, unprofiled calls: every size in one launch (per-size stage times need per-size launches)
+    const bool one_launch = ctx->tune.dct_multi && !ctx->profiling && (long long)g.B * g.H * g.W <= kGraphAutoPixels;
+    if (!(one_launch && launch_dct_multi(st, g, q, args, w.qt.qb.work_cap) == 0)) {
+        k = 0;
+        for (int s = q.bmin; s <= q.bmax; s *= 2, k++) {
+            if (launch_dct(st, s, g, q, args[k], w.qt.qb.work_cap[k], ctx->tune)) return fail(ctx, AEJ_ERR_UNSUPPORTED, "no DCT kernel for block size %d with %d planes", s, args[k].nplanes);
+            mark(ctx, AEJ_STAGE_DCT_2 + ilog2(s) - 1);
+        }
     }
     AEJ_HIP_CHECK(hipGetLastError());
     return 0;
@@ -777,7 +787,6 @@ static int enqueue_readback(aej_ctx *ctx, EncodeWs &w)
     return 0;
 }
 
-constexpr long long kGraphAutoPixels = 8LL << 20;      // automatic graph mode: calls of at most 8 Mpx (launch latency matters there)
 constexpr size_t kMaxGraphs = 8;
 
 // Launch-latency path: the whole sequence (about 20 launches for 4-64 blocks) as ONE hipGraphLaunch.  The graph is captured
@@ -1689,6 +1698,7 @@ const OptionDef kOptions[] = {
     { "dct_small_workgroups", &aej::Tuning::dct_small_workgroups, nullptr, 0, 1 << 16, true },
     { "sobel_lds", &aej::Tuning::sobel_lds, nullptr, 0, 1, true },
     { "sobel_xcd", &aej::Tuning::sobel_xcd, nullptr, 0, 1, true },
+    { "dct_multi", &aej::Tuning::dct_multi, nullptr, 0, 1, true },
     { "sub_chain", nullptr, &aej_ctx::sub_chain, -1, 3, false },
 };
 const OptionDef *find_option(const char *name)

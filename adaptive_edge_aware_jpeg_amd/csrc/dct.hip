@@ -251,8 +251,9 @@ __device__ __forceinline__ int quantise_f32_rcp(float y, float qf, float rq)    
     return ki;
 }
 
+// (the body takes its block index and block count as arguments: k_dct_multi below runs it on a share of its grid)
 template <bool WANT_DCT>
-__global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long long max_items)
+__device__ __forceinline__ void dct4_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int LPB = 64;                   // leaves per workgroup and iteration
     __shared__ float sQf[3 * 16], sQr[3 * 16];
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
     for (int c = 0; c < 4; c++) zz[c] = zigzag_pos<4>(r, c);
     int *slab = sOut[wv] + (lane >> 2) * 16;
     // this workgroup's contiguous share of the items, a multiple of LPB
-    const long long per = ((count + gridDim.x - 1) / gridDim.x + LPB - 1) / LPB * LPB;
-    const long long first = (long long)blockIdx.x * per, last = first + per < count ? first + per : count;
+    const long long per = ((count + nb - 1) / nb + LPB - 1) / LPB * LPB;
+    const long long first = (long long)bid * per, last = first + per < count ? first + per : count;
     int p = 0;                                // plane of the lane's current item: largest p with s_pref[p] <= item
     if (first + slot < last) {
         int lo = 0, hi = a.nplanes;
@@ -361,6 +362,11 @@ __global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long 
         }
     }
 }
+template <bool WANT_DCT>
+__global__ __launch_bounds__(256) void k_dct4(Geom g, QtGeom q, DctArgs a, long long max_items)
+{
+    dct4_body<WANT_DCT>(g, q, a, max_items, blockIdx.x, gridDim.x);
+}
 
 // ------------------------------------------------------------------------------------------------
 // 8 x 8 blocks: eight LANES per leaf, registers and wavefront shuffles only -- no LDS transpose, no workgroup barrier.
@@ -398,8 +404,9 @@ __device__ __forceinline__ void transpose8_stage(float (&a)[8], bool upper)     
         }
 }
 
+// (the body takes its block index and block count as arguments: k_dct_multi below runs it on a share of its grid)
 template <bool WANT_DCT>
-__global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, long long max_items)
+__device__ __forceinline__ void dct8_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int S = 8, SS = 64, LPB = 32;
     __shared__ float sQf[3 * SS];
@@ -420,8 +427,8 @@ __global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, 
 #pragma unroll
     for (int c = 0; c < 8; c++) zz[c] = zigzag_pos<S>(j, c);                     // after the transpose this lane owns row j
     int *slab = sOut[wv] + ((lane >> 3) * SS);
-    const long long step = (long long)gridDim.x * LPB;
-    long long base = (long long)blockIdx.x * LPB;
+    const long long step = (long long)nb * LPB;
+    long long base = (long long)bid * LPB;
     int4 wk = make_int4(0, 0, 0, 0);
     if (base + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + slot);
     for (; base < count; base += step) {
@@ -493,6 +500,11 @@ __global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, 
         }
     }
 }
+template <bool WANT_DCT>
+__global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, long long max_items)
+{
+    dct8_body<WANT_DCT>(g, q, a, max_items, blockIdx.x, gridDim.x);
+}
 
 // ------------------------------------------------------------------------------------------------
 // 16 x 16 blocks on the matrix pipe: one WAVE per leaf, v_mfma_f32_16x16x4_f32, no LDS and no barrier between the products.
@@ -508,8 +520,9 @@ __global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, 
 // ------------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// (the body takes its block index and block count as arguments: k_dct_multi below runs it on a share of its grid)
 template <bool WANT_DCT>
-__global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
+__device__ __forceinline__ void dct16_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int S = 16, SS = 256;
     __shared__ float sQf[3 * SS];
@@ -530,8 +543,8 @@ __global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a,
 #pragma unroll
     for (int r = 0; r < 4; r++) zz[r] = zigzag_pos<S>(4 * gq + r, i);
     int *out_slab = sOut[wv];
-    const long long nw = (long long)gridDim.x * 4;
-    long long item = (long long)blockIdx.x * 4 + wv;
+    const long long nw = (long long)nb * 4;
+    long long item = (long long)bid * 4 + wv;
 
     // Everything about a leaf is wave-uniform, so descriptors live in SGPRs (readfirstlane) and the plane / clipping arithmetic is
     // scalar.  Items past the end are clamped to the last one (its loads are harmless and unused): no divergent branch, so no
@@ -612,6 +625,11 @@ __global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a,
 #pragma unroll
         for (int s = 0; s < 4; s++) x_cur[s] = x_nxt[s];
     }
+}
+template <bool WANT_DCT>
+__global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)
+{
+    dct16_body<WANT_DCT>(g, q, a, max_items, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -753,7 +771,8 @@ template <int N> __device__ __forceinline__ void wait_vmem_but() { asm volatile(
 
 
 template <int S, bool WANT_DCT>
-__device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const LeafWork *__restrict__ work /* = a.work, read-only: scalar loads */)
+__device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const LeafWork *__restrict__ work /* = a.work, read-only: scalar loads */,
+                                                unsigned bid, unsigned nb)
 {
     using C = MfmaCfg<S>;
     constexpr int NT = C::NT, TPW = C::TPW, NWAVES = C::NWAVES, NTHREADS = C::NTHREADS;
@@ -788,12 +807,12 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
     long long count = s_pref[a.nplanes];
     if (count > max_items) count = max_items;
     const long long wstride = q.work_stride[a.k];
-    const long long step = gridDim.x;
-    long long item = blockIdx.x;
-    // leaf k of this workgroup is work item blockIdx.x + k * gridDim.x; chunk c = leaves [c * kDescChunk, (c + 1) * kDescChunk)
+    const long long step = nb;
+    long long item = bid;
+    // leaf k of this workgroup is work item bid + k * nb; chunk c = leaves [c * kDescChunk, (c + 1) * kDescChunk)
     auto load_chunk = [&](long long c) {           // threads 0 .. kDescChunk - 1: one descriptor each, into s_desc[c & 1]
         if (tid < kDescChunk) {
-            const long long it = (long long)blockIdx.x + (c * kDescChunk + tid) * step;
+            const long long it = (long long)bid + (c * kDescChunk + tid) * step;
             int4 d = make_int4(0, 0, 0, 0);
             if (it < count) d = fetch_item(a, wstride, lt, s_pref, it);
             s_desc[(c & 1) * kDescChunk + tid] = d;
@@ -942,7 +961,7 @@ __device__ __forceinline__ void dct_mfma_leaves(const Geom &g, const QtGeom &q, 
 template <int S, bool WANT_DCT>
 __global__ __launch_bounds__(MfmaCfg<S>::NTHREADS, MfmaCfg<S>::MINW) void k_dct_mfma(Geom g, QtGeom q, DctArgs a, long long max_items, const LeafWork *__restrict__ work)
 {
-    dct_mfma_leaves<S, WANT_DCT>(g, q, a, max_items, work);
+    dct_mfma_leaves<S, WANT_DCT>(g, q, a, max_items, work, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1376,6 +1395,71 @@ static void launch_mfma_t(hipStream_t st, const Geom &g, const QtGeom &q, const 
     const int blocks = (int)(max_items < slots ? (max_items < 1 ? 1 : max_items) : slots);
     hipLaunchKernelGGL((k_dct_mfma<S, WANT_DCT>), dim3(blocks), dim3(MfmaCfg<S>::NTHREADS), lds, st, g, q, a, max_items,
                        a.work);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Latency-sized calls (one image: the GUI's use, src/gui/main_frame.py:145): the five block sizes 4 .. 64 in ONE launch.  Launched one
+// after the other their times add up -- 58 of the 204 us of a 1080p call, each kernel a short chain of dependent steps on a mostly idle
+// chip (profiles/r05_latency_chain.txt) -- while side by side they take as long as the longest.  The grid is the five kernels' grids end to
+// end; a workgroup runs the body of the size its index falls into (same code, same results: the bodies are shared with the per-size
+// kernels).  The 32 x 32 body is a one-wave workgroup: the other three waves of its workgroups leave at once.
+// ------------------------------------------------------------------------------------------------
+struct DctMulti {
+    DctArgs a[5];              // sizes 4, 8, 16, 32, 64
+    long long max_items[5];
+    int first[6];              // first workgroup of each size's share ([5] = grid size); an absent size has an empty share
+};
+
+__global__ __launch_bounds__(256) void k_dct_multi(Geom g, QtGeom q, DctMulti m)
+{
+    const unsigned b = blockIdx.x;
+    if (b < (unsigned)m.first[1]) dct4_body<false>(g, q, m.a[0], m.max_items[0], b - m.first[0], m.first[1] - m.first[0]);
+    else if (b < (unsigned)m.first[2]) dct8_body<false>(g, q, m.a[1], m.max_items[1], b - m.first[1], m.first[2] - m.first[1]);
+    else if (b < (unsigned)m.first[3]) dct16_body<false>(g, q, m.a[2], m.max_items[2], b - m.first[2], m.first[3] - m.first[2]);
+    else if (b < (unsigned)m.first[4]) {
+        if (threadIdx.x < MfmaCfg<32>::NTHREADS) dct_mfma_leaves<32, false>(g, q, m.a[3], m.max_items[3], m.a[3].work, b - m.first[3], m.first[4] - m.first[3]);
+    } else dct_mfma_leaves<64, false>(g, q, m.a[4], m.max_items[4], m.a[4].work, b - m.first[4], m.first[5] - m.first[4]);
+}
+
+// args[k] / max_items[k] for size bmin << k; returns 0 when the launch was made, 1 when this call is not one for it (the caller then
+// launches size by size)
+int launch_dct_multi(hipStream_t st, const Geom &g, const QtGeom &q, const DctArgs *args, const long long *max_items)
+{
+    if (q.bmin < 4 || q.bmax > 64 || args[0].dct_f32 || args[0].nplanes > kMaxPlanes) return 1;
+    DctMulti m;
+    int nb = 0;
+    size_t lds = 0;
+    for (int slot = 0; slot < 5; slot++) {
+        const int size = 4 << slot;
+        m.first[slot] = nb;
+        if (size < q.bmin || size > q.bmax) { m.a[slot] = args[0]; m.max_items[slot] = 0; continue; }
+        const int k = ilog2(size) - ilog2(q.bmin);
+        m.a[slot] = args[k];
+        m.max_items[slot] = max_items[k];
+        if (max_items[k] <= 0) continue;
+        auto cap = [&](long long per_block, int hi) { const long long bl = (max_items[k] + per_block - 1) / per_block; return (int)(bl < 1 ? 1 : bl > hi ? hi : bl); };
+        const size_t pref = (size_t)(args[k].nplanes + 1) * sizeof(int);
+        // (the merged kernel holds the registers and the LDS of its largest body -- two workgroups per CU: the shares are sized so that the
+        // whole grid is resident at once, 512 workgroups, roughly in proportion to the time the sizes take; every body walks its list with
+        // a grid stride)
+        if (size == 4) { nb += cap(64 * 8, 48); lds = std::max(lds, pref); }
+        else if (size == 8) { nb += cap(32, 64); lds = std::max(lds, pref); }
+        else if (size == 16) { nb += cap(4, 112); lds = std::max(lds, pref); }
+        else {
+            const size_t need = size == 32 ? (size_t)(MfmaCfg<32>::NXB + 1) * 32 * 32 * sizeof(float) : (size_t)(MfmaCfg<64>::NXB + 1) * 64 * 64 * sizeof(float);
+            lds = std::max(lds, need + 2 * kDescChunk * sizeof(int4) + sizeof(LayerTab) + 8 + pref);
+            nb += cap(1, size == 32 ? 96 : 192);
+        }
+    }
+    m.first[5] = nb;
+    if (nb == 0) return 0;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dct_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(k_dct_multi, dim3((unsigned)nb), dim3(256), lds, st, g, q, m);
+    return 0;
 }
 
 int launch_dct(hipStream_t st, int size, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, const Tuning &t)

@@ -124,6 +124,7 @@ AEJ_API int aej_get_schedule_host(aej_ctx *ctx, int batch, int H, int W, int32_t
  *   "dct64_kernel"          0 | 1 | 4 (0)      64 x 64 DCT: 0 = by company (one wave per leaf alone, four beside other work), 1 / 4 force
  *   "dct_small_workgroups"  0..65536 (0)       cap on the grids of the 4 / 8 / 16 DCT kernels; 0 = automatic
  *   "sobel_lds"             0 | 1 (0)          1: the LDS-tiled Sobel / NMS kernel for every shape (default: register kernel when w % 4 == 0)
+ *   "dct_multi"             0 | 1 (1)          1: calls of at most 8 Mpx run the DCTs of block sizes 4 .. 64 as ONE launch (latency), 0: one launch per size
  *   "sobel_xcd"             0 | 1 (1)          1: each XCD gets a contiguous range of the register Sobel kernel's tiles (0: round-robin)
  *   "sub_chain"             -1..3 (-1)         which stage of the previously enqueued part a part's colour stage waits for: 0 none, 1 colour,
  *                                              2 blur, 3 Sobel; -1 = 1 */
