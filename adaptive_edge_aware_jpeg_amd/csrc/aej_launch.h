@@ -138,7 +138,7 @@ void launch_metric_prep(hipStream_t st, const float *a, const float *b, int B, l
 void launch_metric_pool_grey(hipStream_t st, const unsigned char *ga, const unsigned char *gb, int B, int H, int W, int f, int hp, int wp, float *xa,
                              float *xb);
 void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const float *xb, int B, int C, int h, int w, const float *g11, double *acc,
-                       int slot);
+                       int slot, bool want_ss, float *pool_a = nullptr, float *pool_b = nullptr);   // pool_*: scale 0 of even-sized images also writes scale 1
 void launch_pool2_rgb(hipStream_t st, const float *ia, const float *ib, int B, int h, int w, int p, int h2, int w2, float *oa, float *ob);
 void launch_pool2(hipStream_t st, bool interleaved, const float *in, int B, int C, int h, int w, int p, int h2, int w2, float *out);
 void launch_metric_final(hipStream_t st, const double *acc, int B, long long npx, long long n_ssim, const long long *n_level, double *out);

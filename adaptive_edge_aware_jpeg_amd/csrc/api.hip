@@ -1614,7 +1614,7 @@ extern "C" int aej_metrics_batch(aej_ctx *ctx, const float *img_a, const float *
     long long n_ssim = 0, n_level[5] = { 0, 0, 0, 0, 0 };
     if (want_ssim) {
         launch_metric_pool_grey(st, w.ga, w.gb, batch, H, W, w.f, w.hp, w.wp, w.xa, w.xb);
-        launch_ssim_level(st, false, w.xa, w.xb, batch, 1, w.hp, w.wp, g11, w.acc, kMetricSlotGrey);
+        launch_ssim_level(st, false, w.xa, w.xb, batch, 1, w.hp, w.wp, g11, w.acc, kMetricSlotGrey, true);
         n_ssim = (long long)(w.hp - 10) * (w.wp - 10);
     }
     if (want_ms) {
@@ -1623,13 +1623,16 @@ extern "C" int aej_metrics_batch(aej_ctx *ctx, const float *img_a, const float *
             if (l > 0) {
                 const float *pa = l == 1 ? img_a : w.pyr[0][l - 2], *pb = l == 1 ? img_b : w.pyr[1][l - 2];
                 if (l == 1) {
-                    launch_pool2_rgb(st, pa, pb, batch, w.lh[0], w.lw[0], w.lp[1], w.lh[1], w.lw[1], w.pyr[0][0], w.pyr[1][0]);
+                    // even sizes: scale 0's SSIM kernel has written scale 1 on its way (no padding to replicate)
+                    if (w.lp[1] != 0) launch_pool2_rgb(st, pa, pb, batch, w.lh[0], w.lw[0], w.lp[1], w.lh[1], w.lw[1], w.pyr[0][0], w.pyr[1][0]);
                 } else {
                     launch_pool2(st, false, pa, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[0][l - 1]);
                     launch_pool2(st, false, pb, batch, 3, w.lh[l - 1], w.lw[l - 1], w.lp[l], w.lh[l], w.lw[l], w.pyr[1][l - 1]);
                 }
             }
-            launch_ssim_level(st, l == 0, xa, xb, batch, 3, w.lh[l], w.lw[l], g11, w.acc, kMetricSlotScales + l * 6);
+            const bool fused_pool = l == 0 && w.lp[1] == 0;
+            launch_ssim_level(st, l == 0, xa, xb, batch, 3, w.lh[l], w.lw[l], g11, w.acc, kMetricSlotScales + l * 6, l == 4, fused_pool ? w.pyr[0][0] : nullptr,
+                              fused_pool ? w.pyr[1][0] : nullptr);
             n_level[l] = (long long)(w.lh[l] - 10) * (w.lw[l] - 10);
         }
     }

@@ -16,7 +16,8 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
 # per-source additions.  canny.hip: the SLP vectoriser pairs the bilateral filter's float adds / fmas into v_pk_* instructions,
 # which issue at half rate on gfx950 (profiles/r02_valu_issue_ubench.txt) and cost register pairs: measured 20 % slower.
 # color.hip: the same for the 3 x 3 colour transforms (pairs formed through v_mov shuffles), and the strip kernel has to stay within 56 VGPRs.
-EXTRA_FLAGS = {"canny.hip": ["-fno-slp-vectorize", "-Wno-pass-failed"], "color.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"canny.hip": ["-fno-slp-vectorize", "-Wno-pass-failed"], "color.hip": ["-fno-slp-vectorize"],
+               "metrics.hip": ["-fno-slp-vectorize"]}      # the SSIM kernel's fma chains: v_pk_fma_f32 issues at half rate and its pairs cost moves
 
 
 def _hipcc():

@@ -104,107 +104,165 @@ __global__ __launch_bounds__(256) void k_metric_pool_grey(const unsigned char *_
     }
 }
 
-// ---- one SSIM scale: 'valid' Gaussian means of x, y, x^2, y^2, xy; cs and ss maps; their sums ----
-// INTERLEAVED: the images are [B][h][w][C] (the caller's float32 RGB); otherwise planar [B][C][h][w].
+// ---- one SSIM scale: 'valid' Gaussian means of x, y, x^2 + y^2, xy; the cs and ss maps; their sums ----
+// (the contrast term needs sigma_x^2 + sigma_y^2 only as a sum, so x^2 and y^2 share one filtered map: four maps, not piq's five)
+// INTERLEAVED: the images are [B][h][w][3] (the caller's float32 RGB); otherwise planar [B][C][h][w].
 struct SsimArgs {
     const float *xa, *xb;
     int h, w, C;
+    int strip_rows;           // output rows per strip
+    int want_ss;              // the luminance term too (the grey SSIM and the last MS-SSIM scale; the others use cs alone)
     float g[kSsimK];          // normalised 1-D Gaussian: g[i] * g[j] is piq's 2-D window
     float c1, c2;
     double *acc;              // [B][kMetricSlots]
     int slot;                 // first slot: channel c adds ss to slot + 2c, cs to slot + 2c + 1
+    float *pool_a, *pool_b;   // INTERLEAVED with even h, w: the next scale (2 x 2 means, planar [B][3][h / 2][w / 2]) written on the way, or null
 };
 
 // ---- one scale as a sliding window ----
-// One WAVE owns a strip of 64 output columns x kStripRows output rows and walks down the input rows: a row's 74 values of x and y
-// go through a wave-private LDS row (no workgroup barrier anywhere), every lane forms the five horizontal sums of its column and
-// keeps the last 11 rows of them in registers (a ring addressed at compile time: the row loop is unrolled 11-fold), and the
-// vertical sums complete one output row per input row.
-constexpr int kStripRows = 64;
+// One WAVE owns a strip of 128 output columns x strip_rows output rows of ONE channel and walks down the input rows.  A lane owns two
+// adjacent columns.  Per input row it loads its pixels of x and y (one row ahead: the latency hides under a row of arithmetic), forms
+// x, y, x^2 + y^2, xy once per pixel and puts the four maps' row through a wave-private LDS row (no workgroup barrier anywhere); the
+// 12-value window of its two columns comes back as six aligned 8-byte reads per map; the four horizontal sums of both columns go into a
+// ring of the last 11 rows held in registers (addressed at compile time: the row loop is unrolled 11-fold), and the vertical sums
+// complete one output row per input row.  Everything is explicit fmaf: this file is compiled with the library's -ffp-contract=off,
+// and a Gaussian mean needs no particular rounding (until round 5 every g * v + s was two instructions).
+// Planar scales: the four waves of a workgroup take four strips.  The interleaved RGB of scale 0: a workgroup is THREE waves on the same
+// strip, one per channel, so that the row segments the three read (each uses a third of every line) are fetched from HBM once and
+// served from the L1 / L2 the other two times -- as a channel loop inside one wave (round 4) every pass over the strip came from HBM
+// again: 3 x 6.4 GB for 32 x 4K.  The same kernel writes the 2 x 2 means that are the next scale's input from the rows it holds anyway
+// (each strip those of its own output columns / rows, the last strip of a row / column also its halo's): the separate pooling pass read both
+// images a second time, 1.46 ms of 7.8 for 32 x 4K.
+constexpr int kSsimCols = 128;                         // output columns per wave
+constexpr int kSsimIn = kSsimCols + kSsimK - 1;        // input columns per wave: 138
+constexpr int kSsimRow = kSsimIn + 2;                  // LDS row stride in floats (even: 8-byte aligned rows)
 
 template <bool INTERLEAVED>
 __global__ __launch_bounds__(256) void k_ssim_strip(SsimArgs A)
 {
-    __shared__ float rx[4][kSsimK + 64], ry[4][kSsimK + 64];
+    __shared__ __attribute__((aligned(8))) float rows[4][4][kSsimRow];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int img = blockIdx.z;
     const int oh = A.h - (kSsimK - 1), ow = A.w - (kSsimK - 1);
-    const int nsx = (ow + 63) / 64, nsy = (oh + kStripRows - 1) / kStripRows;
-    const int sidx = blockIdx.x * 4 + wave;
+    const int nsx = (ow + kSsimCols - 1) / kSsimCols, nsy = (oh + A.strip_rows - 1) / A.strip_rows;
+    const int sidx = INTERLEAVED ? blockIdx.x : blockIdx.x * 4 + wave;
     if (sidx >= nsx * nsy) return;                       // no workgroup-level synchronisation below
+    const int c = INTERLEAVED ? wave : blockIdx.y;
     const int sy_ = sidx / nsx, sx_ = sidx - sy_ * nsx;
-    const int x0 = sx_ * 64, y0 = sy_ * kStripRows;
-    const int rows_out = min(kStripRows, oh - y0), R = rows_out + kSsimK - 1;
-    const bool col_ok = x0 + lane < ow;
-    float *wx = rx[wave], *wy = ry[wave];
-    float g[kSsimK];
+    const int x0 = sx_ * kSsimCols, y0 = sy_ * A.strip_rows;
+    const int rows_out = min(A.strip_rows, oh - y0), R = rows_out + kSsimK - 1;
+    float (*wrow)[kSsimRow] = rows[wave];
+    // the pixels this lane loads per row: columns x0 + 2 lane, + 1 and (lanes 0..4) x0 + 128 + 2 lane, + 1
+    const int col[4] = { x0 + 2 * lane, x0 + 2 * lane + 1, x0 + kSsimCols + 2 * lane, x0 + kSsimCols + 2 * lane + 1 };
+    bool ok[4];
+    int off[4];
 #pragma unroll
-    for (int t = 0; t < kSsimK; t++) g[t] = A.g[t];
-    const int c_begin = INTERLEAVED ? 0 : blockIdx.y, c_end = INTERLEAVED ? A.C : c_begin + 1;
-    for (int c = c_begin; c < c_end; c++) {
-        float h[kSsimK][5];
-        float ss_acc = 0.f, cs_acc = 0.f;
-        const int cA = x0 + lane, cB = x0 + 64 + lane;
-        float pxa = 0.f, pya = 0.f, pxb = 0.f, pyb = 0.f;      // the NEXT input row, fetched one row ahead (its HBM / L2 latency hides under a row of arithmetic)
-        auto fetch = [&](int r) {
-            pxa = pya = pxb = pyb = 0.f;
-            if (r >= R) return;
-            const int gy = y0 + r;
-            auto at = [&](int col) -> long long {
-                return INTERLEAVED ? (((long long)img * A.h + gy) * A.w + col) * A.C + c : (((long long)img * A.C + c) * A.h + gy) * A.w + col;
-            };
-            if (cA < A.w) { pxa = A.xa[at(cA)]; pya = A.xb[at(cA)]; }
-            if (lane < kSsimK - 1 && cB < A.w) { pxb = A.xa[at(cB)]; pyb = A.xb[at(cB)]; }
-        };
-        fetch(0);
-        auto step = [&](auto ph, int r) {
-            constexpr int PH = decltype(ph)::value;
-            if (r >= R) return;
-            wx[lane] = pxa; wy[lane] = pya;
-            if (lane < kSsimK - 1) { wx[64 + lane] = pxb; wy[64 + lane] = pyb; }
-            fetch(r + 1);
-            __builtin_amdgcn_wave_barrier();
-            float mx = 0.f, my = 0.f, mxx = 0.f, myy = 0.f, mxy = 0.f;
+    for (int k = 0; k < 4; k++) {
+        ok[k] = col[k] < A.w && (k < 2 || lane < (kSsimK - 1) / 2);
+        off[k] = ok[k] ? (INTERLEAVED ? 3 * col[k] + c : col[k]) : 0;
+    }
+    const long long row_stride = INTERLEAVED ? (long long)A.w * 3 : A.w;
+    const long long first = INTERLEAVED ? ((long long)img * A.h + y0) * row_stride : (((long long)img * A.C + c) * A.h + y0) * row_stride;
+    const float *qx = A.xa + first, *qy = A.xb + first;
+    float px[4] = { 0.f, 0.f, 0.f, 0.f }, py[4] = { 0.f, 0.f, 0.f, 0.f };      // the NEXT input row
+    auto fetch = [&](int r) {
+        if (r >= R) return;
 #pragma unroll
-            for (int t = 0; t < kSsimK; t++) {
-                const float x = wx[lane + t], y = wy[lane + t];
-                mx += g[t] * x; my += g[t] * y; mxx += g[t] * (x * x); myy += g[t] * (y * y); mxy += g[t] * (x * y);
+        for (int k = 0; k < 4; k++)
+            if (ok[k]) { px[k] = qx[off[k]]; py[k] = qy[off[k]]; }
+        qx += row_stride; qy += row_stride;
+    };
+    fetch(0);
+    float h[kSsimK][4][2];
+    float ss_acc = 0.f, cs_acc = 0.f;
+    const bool out_ok[2] = { x0 + 2 * lane < ow, x0 + 2 * lane + 1 < ow };
+    // 2 x 2 means for the next scale: row pairs (y0 + r even, odd), column pairs = this lane's; the halo only where no other strip owns it
+    const bool pool = INTERLEAVED && A.pool_a != nullptr;
+    const bool pool_halo_x = sx_ == nsx - 1, pool_halo_y = sy_ == nsy - 1;
+    const int w2 = A.w >> 1;
+    float keep[4] = { 0.f, 0.f, 0.f, 0.f };
+    auto step = [&](auto ph, int r) {
+        constexpr int PH = decltype(ph)::value;
+        if (r >= R) return;
+        if (INTERLEAVED && pool && (r < rows_out || pool_halo_y)) {
+            const float hs[4] = { px[0] + px[1], py[0] + py[1], px[2] + px[3], py[2] + py[3] };
+            if (r & 1) {
+                const long long o = (((long long)img * 3 + c) * (A.h >> 1) + ((y0 + r) >> 1)) * w2;
+                if (ok[0]) { A.pool_a[o + (col[0] >> 1)] = (keep[0] + hs[0]) * 0.25f; A.pool_b[o + (col[0] >> 1)] = (keep[1] + hs[1]) * 0.25f; }
+                if (ok[2] && pool_halo_x) { A.pool_a[o + (col[2] >> 1)] = (keep[2] + hs[2]) * 0.25f; A.pool_b[o + (col[2] >> 1)] = (keep[3] + hs[3]) * 0.25f; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) keep[k] = hs[k];
             }
-            __builtin_amdgcn_wave_barrier();
-            h[PH][0] = mx; h[PH][1] = my; h[PH][2] = mxx; h[PH][3] = myy; h[PH][4] = mxy;
-            if (r >= kSsimK - 1) {                  // rows r - 10 .. r are in the ring: the oldest sits right after PH
-                float v[5];
+        }
+        {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const float s0 = fmaf(px[0], px[0], py[0] * py[0]), s1 = fmaf(px[1], px[1], py[1] * py[1]);
+            *reinterpret_cast<f32x2 *>(&wrow[0][2 * lane]) = f32x2{ px[0], px[1] };
+            *reinterpret_cast<f32x2 *>(&wrow[1][2 * lane]) = f32x2{ py[0], py[1] };
+            *reinterpret_cast<f32x2 *>(&wrow[2][2 * lane]) = f32x2{ s0, s1 };
+            *reinterpret_cast<f32x2 *>(&wrow[3][2 * lane]) = f32x2{ px[0] * py[0], px[1] * py[1] };
+            if (lane < (kSsimK - 1) / 2) {
+                const float s2 = fmaf(px[2], px[2], py[2] * py[2]), s3 = fmaf(px[3], px[3], py[3] * py[3]);
+                *reinterpret_cast<f32x2 *>(&wrow[0][kSsimCols + 2 * lane]) = f32x2{ px[2], px[3] };
+                *reinterpret_cast<f32x2 *>(&wrow[1][kSsimCols + 2 * lane]) = f32x2{ py[2], py[3] };
+                *reinterpret_cast<f32x2 *>(&wrow[2][kSsimCols + 2 * lane]) = f32x2{ s2, s3 };
+                *reinterpret_cast<f32x2 *>(&wrow[3][kSsimCols + 2 * lane]) = f32x2{ px[2] * py[2], px[3] * py[3] };
+            }
+        }
+        fetch(r + 1);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int m = 0; m < 5; m++) {
-                    float sacc = 0.f;
+        for (int m = 0; m < 4; m++) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            float v[kSsimK + 1];
 #pragma unroll
-                    for (int t = 0; t < kSsimK; t++) sacc += g[t] * h[(PH + 1 + t) % kSsimK][m];
+            for (int t = 0; t < (kSsimK + 1) / 2; t++) {
+                const f32x2 q = *reinterpret_cast<const f32x2 *>(&wrow[m][2 * lane + 2 * t]);
+                v[2 * t] = q.x; v[2 * t + 1] = q.y;
+            }
+            float a0 = A.g[0] * v[0], a1 = A.g[0] * v[1];
+#pragma unroll
+            for (int t = 1; t < kSsimK; t++) { a0 = fmaf(A.g[t], v[t], a0); a1 = fmaf(A.g[t], v[t + 1], a1); }
+            h[PH][m][0] = a0; h[PH][m][1] = a1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (r >= kSsimK - 1) {                  // rows r - 10 .. r are in the ring: the oldest sits right after PH
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                float v[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    float sacc = A.g[0] * h[(PH + 1) % kSsimK][m][k];
+#pragma unroll
+                    for (int t = 1; t < kSsimK; t++) sacc = fmaf(A.g[t], h[(PH + 1 + t) % kSsimK][m][k], sacc);
                     v[m] = sacc;
                 }
-                if (col_ok) {
+                if (out_ok[k]) {
+                    // 1 / d by the hardware reciprocal (1 ulp): these are float32 means compared at 1e-4, and the IEEE division is ten instructions
                     const float mu_xx = v[0] * v[0], mu_yy = v[1] * v[1], mu_xy = v[0] * v[1];
-                    const float s_xx = v[2] - mu_xx, s_yy = v[3] - mu_yy, s_xy = v[4] - mu_xy;
-                    const float cs = (2.f * s_xy + A.c2) / (s_xx + s_yy + A.c2);
-                    const float ss = (2.f * mu_xy + A.c1) / (mu_xx + mu_yy + A.c1) * cs;
-                    ss_acc += ss; cs_acc += cs;
+                    const float s_sum = (v[2] - mu_xx) - mu_yy, s_xy = v[3] - mu_xy;
+                    const float cs = fmaf(2.f, s_xy, A.c2) * __builtin_amdgcn_rcpf(s_sum + A.c2);
+                    cs_acc += cs;
+                    if (A.want_ss) ss_acc += fmaf(2.f, mu_xy, A.c1) * __builtin_amdgcn_rcpf(mu_xx + mu_yy + A.c1) * cs;
                 }
             }
-        };
-        for (int r0 = 0; r0 < R; r0 += kSsimK) {
-            step(std::integral_constant<int, 0>{}, r0);      step(std::integral_constant<int, 1>{}, r0 + 1);
-            step(std::integral_constant<int, 2>{}, r0 + 2);  step(std::integral_constant<int, 3>{}, r0 + 3);
-            step(std::integral_constant<int, 4>{}, r0 + 4);  step(std::integral_constant<int, 5>{}, r0 + 5);
-            step(std::integral_constant<int, 6>{}, r0 + 6);  step(std::integral_constant<int, 7>{}, r0 + 7);
-            step(std::integral_constant<int, 8>{}, r0 + 8);  step(std::integral_constant<int, 9>{}, r0 + 9);
-            step(std::integral_constant<int, 10>{}, r0 + 10);
         }
-        double ss_d = (double)ss_acc, cs_d = (double)cs_acc;
-        for (int o = 32; o > 0; o >>= 1) { ss_d += __shfl_down(ss_d, o); cs_d += __shfl_down(cs_d, o); }
-        if (lane == 0) {
-            double *acc = A.acc + (long long)img * kMetricSlots + A.slot + 2 * c;
-            atomicAdd(&acc[0], ss_d);
-            atomicAdd(&acc[1], cs_d);
-        }
+    };
+    for (int r0 = 0; r0 < R; r0 += kSsimK) {
+        step(std::integral_constant<int, 0>{}, r0);      step(std::integral_constant<int, 1>{}, r0 + 1);
+        step(std::integral_constant<int, 2>{}, r0 + 2);  step(std::integral_constant<int, 3>{}, r0 + 3);
+        step(std::integral_constant<int, 4>{}, r0 + 4);  step(std::integral_constant<int, 5>{}, r0 + 5);
+        step(std::integral_constant<int, 6>{}, r0 + 6);  step(std::integral_constant<int, 7>{}, r0 + 7);
+        step(std::integral_constant<int, 8>{}, r0 + 8);  step(std::integral_constant<int, 9>{}, r0 + 9);
+        step(std::integral_constant<int, 10>{}, r0 + 10);
+    }
+    double ss_d = (double)ss_acc, cs_d = (double)cs_acc;
+    for (int o = 32; o > 0; o >>= 1) { ss_d += __shfl_down(ss_d, o); cs_d += __shfl_down(cs_d, o); }
+    if (lane == 0) {
+        double *acc = A.acc + (long long)img * kMetricSlots + A.slot + 2 * c;
+        if (A.want_ss) atomicAdd(&acc[0], ss_d);
+        atomicAdd(&acc[1], cs_d);
     }
 }
 
@@ -307,18 +365,24 @@ void launch_metric_pool_grey(hipStream_t st, const unsigned char *ga, const unsi
     hipLaunchKernelGGL(k_metric_pool_grey, dim3(grid_for((long long)hp * wp), B), dim3(256), 0, st, ga, gb, H, W, f, hp, wp, xa, xb);
 }
 
-void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const float *xb, int B, int C, int h, int w, const float *g11, double *acc, int slot)
+void launch_ssim_level(hipStream_t st, bool interleaved, const float *xa, const float *xb, int B, int C, int h, int w, const float *g11, double *acc, int slot,
+                       bool want_ss, float *pool_a, float *pool_b)
 {
     SsimArgs A;
     A.xa = xa; A.xb = xb; A.h = h; A.w = w; A.C = C;
     for (int i = 0; i < kSsimK; i++) A.g[i] = g11[i];
     A.c1 = (float)(0.01 * 0.01); A.c2 = (float)(0.03 * 0.03);
-    A.acc = acc; A.slot = slot;
+    A.acc = acc; A.slot = slot; A.want_ss = want_ss ? 1 : 0;
+    A.pool_a = pool_a; A.pool_b = pool_b;
     const int oh = h - (kSsimK - 1), ow = w - (kSsimK - 1);
-    const int strips = ((ow + 63) / 64) * ((oh + kStripRows - 1) / kStripRows);
-    dim3 grid((strips + 3) / 4, interleaved ? 1 : C, B);
-    if (interleaved) hipLaunchKernelGGL(k_ssim_strip<true>, grid, dim3(256), 0, st, A);
-    else hipLaunchKernelGGL(k_ssim_strip<false>, grid, dim3(256), 0, st, A);
+    // strips of 128 output rows (138 input rows: 8 % of the horizontal sums are formed twice) while that still leaves eight waves per SIMD of the
+    // chip; 64 (16 %) below
+    const int nsx = (ow + kSsimCols - 1) / kSsimCols;
+    const long long waves128 = (long long)nsx * ((oh + 127) / 128) * C * B;
+    A.strip_rows = waves128 >= 8LL * 4 * 256 ? 128 : waves128 >= 2LL * 4 * 256 ? 64 : 32;
+    const int strips = nsx * ((oh + A.strip_rows - 1) / A.strip_rows);
+    if (interleaved) hipLaunchKernelGGL(k_ssim_strip<true>, dim3(strips, 1, B), dim3(64 * 3), 0, st, A);       // C == 3: one wave per channel
+    else hipLaunchKernelGGL(k_ssim_strip<false>, dim3((strips + 3) / 4, C, B), dim3(256), 0, st, A);
 }
 
 void launch_pool2(hipStream_t st, bool interleaved, const float *in, int B, int C, int h, int w, int p, int h2, int w2, float *out)

@@ -30,7 +30,8 @@ GROUPS = {
     "valu": [["SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"],
              ["SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAVES", "SQ_INSTS_SMEM"]],
     "mfma": [["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"],
-             ["SQ_INST_CYCLES_VMEM", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"]],
+             ["SQ_INST_CYCLES_VMEM", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"],
+             ["GRBM_GUI_ACTIVE"]],      # with the dispatch's duration: the clock the kernel really ran at (busy cycles are fractions of THAT, not of the 2.4 GHz peak)
 }
 
 
@@ -63,6 +64,8 @@ def one_pass(counters, bench_args, tag):
         if key not in seen:
             seen.add(key)
             launches[k] += 1
+            if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                acc[k]["duration_ns_with_" + counters[0]] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
     shutil.rmtree(out_dir, ignore_errors=True)
     return info, acc, launches
 
