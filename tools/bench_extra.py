@@ -64,7 +64,11 @@ def end_to_end(torch, bench, A, codec, args, dev, H, W):
     res["d2h_per_layer_copies"] = {"s": round(t_d2h, 3), "GB/s": round(raw / t_d2h / 1e9, 2)}
     workers = min(64, cores)
     t0 = time.perf_counter()
+    blobs_default = codec.compress_many(x, extension=".png")                  # the default worker count (round 5: the usable cores)
+    res["compress_many_default_workers"] = {"s": round(time.perf_counter() - t0, 3), "MP/s": round(mp / (time.perf_counter() - t0), 1)}
+    t0 = time.perf_counter()
     blobs = codec.compress_many(x, extension=".png", workers=workers)
+    assert blobs == blobs_default
     dt = time.perf_counter() - t0
     res["compress_many"] = {"s": round(dt, 3), "MP/s": round(mp / dt, 1), "workers": workers, "bytes_out": int(sum(len(b) for b in blobs)),
                             "bits_per_pixel": round(8.0 * sum(len(b) for b in blobs) / (n * H * W), 3)}
@@ -74,7 +78,7 @@ def end_to_end(torch, bench, A, codec, args, dev, H, W):
         dta = time.perf_counter() - t0
         res[f"compress_many_zlib_level_{level}"] = {"s": round(dta, 3), "MP/s": round(mp / dta, 1), "bytes_out": int(sum(len(b) for b in alt)),
                                                     "bits_per_pixel": round(8.0 * sum(len(b) for b in alt) / (n * H * W), 3)}
-    # opt-in GPU entropy stage: fixed-Huffman deflate on the device, only compressed bytes cross to the host
+    # opt-in GPU entropy stage: LZ77 (hash chains over the 32 KiB window) + per-layer dynamic Huffman on the device, only compressed bytes cross to the host
     import zlib as _z
     enc2 = codec.compress_batch(x)
     codec.deflate_batch(enc2)
@@ -92,14 +96,16 @@ def end_to_end(torch, bench, A, codec, args, dev, H, W):
     res["compress_many_gpu_entropy"] = {"s": round(dtg, 4), "MP/s": round(mp / dtg, 1), "s_of_five_calls": [round(r, 4) for r in runs],
                                         "bytes_out": int(sum(len(b) for b in gpu_blobs)),
                                         "bits_per_pixel": round(8.0 * sum(len(b) for b in gpu_blobs) / (n * H * W), 3),
-                                        "deflate_batch_s": round(t_def, 4), "note": "aej_deflate_batch + device-side compaction + one D2H of the compressed bytes"}
+                                        "deflate_batch_s": round(t_def, 4), "note": "aej_deflate_histogram + host table helper + aej_deflate_batch + device-side compaction + one D2H of the compressed bytes; every container below is read back by the decoder",
+                                        "vs_zlib9_bytes": round(sum(len(b) for b in gpu_blobs) / max(1, sum(len(b) for b in blobs)), 4)}
+    codec.decompress(gpu_blobs[0])                           # the GPU-written container through the decode path (zlib.decompress inside)
     img = A.Image.from_array(x[0].cpu().numpy(), (H, W, 3), ".png")
     codec.compress(img)
     t0 = time.perf_counter()
     one = codec.compress(img)
     dt1 = time.perf_counter() - t0
     assert one == blobs[0]
-    res["compress_one_image"] = {"s": round(dt1, 3), "MP/s": round(H * W / 1e6 / dt1, 1), "note": "Jpeg.compress(Image): host->device copy, GPU pass, D2H, three zlib-9 streams on one thread"}
+    res["compress_one_image"] = {"s": round(dt1, 3), "MP/s": round(H * W / 1e6 / dt1, 1), "note": "Jpeg.compress(Image): host->device copy, GPU pass, D2H, three zlib-9 streams on three threads (round 4: one thread, 3.54 s)"}
     z = res[f"zlib9_{workers}_threads"]["s"]
     res["share_of_compress_many"] = {"gpu_pass": round(t_gpu / dt, 3), "d2h": round(t_d2h / dt, 3), "zlib9": round(z / dt, 3)}
     return res
