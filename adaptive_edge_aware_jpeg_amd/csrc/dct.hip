@@ -256,7 +256,7 @@ template <bool WANT_DCT>
 __device__ __forceinline__ void dct4_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int LPB = 64;                   // leaves per workgroup and iteration
-    __shared__ float sQf[3 * 16], sQr[3 * 16];
+    __shared__ float sQf[3 * 16], sQr[3 * 16], sQh[3 * 16];
     __shared__ int sOut[4][16 * 16];          // per wave: 16 leaves x 16 coefficients
     __shared__ int sSlowQ;
     __shared__ LayerTab lt;
@@ -268,6 +268,7 @@ __device__ __forceinline__ void dct4_body(const Geom &g, const QtGeom &q, const 
         const int qi = a.qm[tid / 16] ? a.qm[tid / 16][tid % 16] : 1;
         sQf[tid] = (float)qi;
         sQr[tid] = __builtin_amdgcn_rcpf((float)qi);
+        sQh[tid] = 0.5f * (float)qi;
         if (qi > (1 << 22)) sSlowQ = 1;      // (never with the codec's own tables: quantise_f32 needs q <= 2^22)
     }
     dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
@@ -346,10 +347,30 @@ __device__ __forceinline__ void dct4_body(const Geom &g, const QtGeom &q, const 
         const float4 qf = *reinterpret_cast<const float4 *>(&sQf[layer * 16 + r * 4]), rq = *reinterpret_cast<const float4 *>(&sQr[layer * 16 + r * 4]);
         // one range test per wave for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
         if (!slow_q && !__any(!(ymax < 131072.0f))) {
-            slab[zz[0]] = quantise_f32_rcp(y[0], qf.x, rq.x);
-            slab[zz[1]] = quantise_f32_rcp(y[1], qf.y, rq.y);
-            slab[zz[2]] = quantise_f32_rcp(y[2], qf.z, rq.z);
-            slab[zz[3]] = quantise_f32_rcp(y[3], qf.w, rq.w);
+            // quantise_f32_rcp with q / 2 looked up too: only a remainder at or beyond q / 2 needs the correction -- one test per wave (round 5:
+            // the four corrections were four branches)
+            const float4 qh = *reinterpret_cast<const float4 *>(&sQh[layer * 16 + r * 4]);
+            const float qfa[4] = { qf.x, qf.y, qf.z, qf.w }, rqa[4] = { rq.x, rq.y, rq.z, rq.w }, qha[4] = { qh.x, qh.y, qh.z, qh.w };
+            float kf[4], rem[4];
+            unsigned long long fix = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                kf[c] = __builtin_rintf(y[c] * rqa[c]);
+                rem[c] = __builtin_fmaf(-kf[c], qfa[c], y[c]);
+                fix |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(rem[c]) >= qha[c]);
+            }
+            int ki[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) ki[c] = (int)kf[c];
+            if (fix != 0) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float ar = __builtin_fabsf(rem[c]);
+                    if (ar > qha[c] || (ar == qha[c] && (ki[c] & 1))) ki[c] += rem[c] > 0.f ? 1 : -1;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) slab[zz[c]] = ki[c];
         } else {
             slab[zz[0]] = quantise_f64(y[0], (int)qf.x);
             slab[zz[1]] = quantise_f64(y[1], (int)qf.y);
@@ -404,56 +425,122 @@ __device__ __forceinline__ void transpose8_stage(float (&a)[8], bool upper)     
         }
 }
 
+// Round 5 (PMC: the kernel was issue-bound at 0.86 with 69 vector instructions per pixel): the basis D is pinned in VECTOR registers (as 64
+// scalars it did not fit beside the rest, and the compiler parked it in the lanes of a vector register: 58 v_readlane per leaf); the plane
+// layout is a template parameter; a workgroup walks a contiguous range of the item list (plane by a comparison per leaf, not a binary
+// search); quantisers, reciprocals and halves come from tables (six 16-byte LDS reads per lane) and the quantiser's correction is one
+// rarely-taken branch per wave and leaf.
 // (the body takes its block index and block count as arguments: k_dct_multi below runs it on a share of its grid)
-template <bool WANT_DCT>
-__device__ __forceinline__ void dct8_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
+struct __attribute__((aligned(16))) Dct8Lds {      // (declared once, in dct8_body: as statics of the two layout instantiations it would be allocated twice)
+    float qf[3 * 64], qr[3 * 64], qh[3 * 64];
+    int out[4][8 * 64];                              // per wave: 8 leaves x 64 coefficients
+    int slow;
+    LayerTab lt;
+};
+template <bool WANT_DCT, bool TILED>
+__device__ __forceinline__ void dct8_impl(Dct8Lds &L, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int S = 8, SS = 64, LPB = 32;
-    __shared__ float sQf[3 * SS];
-    __shared__ int sOut[4][8 * SS];          // per wave: 8 leaves x 64 coefficients
-    __shared__ LayerTab lt;
+    float (&sQf)[3 * SS] = L.qf, (&sQr)[3 * SS] = L.qr, (&sQh)[3 * SS] = L.qh;
+    int (&sOut)[4][8 * SS] = L.out;
+    int &sSlowQ = L.slow;
+    LayerTab &lt = L.lt;
     extern __shared__ int s_pref[];
     const int tid = threadIdx.x;
-    if (tid < 3 * SS) sQf[tid] = (float)(a.qm[tid / SS] ? a.qm[tid / SS][tid % SS] : 1);
+    if (tid == 0) sSlowQ = 0;
+    __syncthreads();
+    if (tid < 3 * SS) {
+        const int qi = a.qm[tid / SS] ? a.qm[tid / SS][tid % SS] : 1;
+        sQf[tid] = (float)qi;
+        sQr[tid] = __builtin_amdgcn_rcpf((float)qi);
+        sQh[tid] = 0.5f * (float)qi;
+        if (qi > (1 << 22)) sSlowQ = 1;      // (never with the codec's own tables: quantise_f32 needs q <= 2^22)
+    }
     dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
-    long long count = s_pref[a.nplanes];
-    if (count > max_items) count = max_items;
+    int count = s_pref[a.nplanes];
+    if ((long long)count > max_items) count = (int)max_items;
+    const bool slow_q = sSlowQ != 0;
     const long long wstride = q.work_stride[a.k];
     const int lane = tid & 63, wv = tid >> 6, j = tid & 7, slot = tid >> 3;      // slot: leaf of this block iteration (0..31)
     float D[8][8];
 #pragma unroll
     for (int i = 0; i < 64; i++) D[i >> 3][i & 7] = a.D[i];
+#pragma unroll
+    for (int i = 0; i < 64; i++) asm volatile("" : "+v"(D[i >> 3][i & 7]));      // (after ALL the loads: a pin directly behind its load would wait for it, 64 round trips in a row)
     int zz[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) zz[c] = zigzag_pos<S>(j, c);                     // after the transpose this lane owns row j
     int *slab = sOut[wv] + ((lane >> 3) * SS);
-    const long long step = (long long)nb * LPB;
-    long long base = (long long)bid * LPB;
-    int4 wk = make_int4(0, 0, 0, 0);
-    if (base + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + slot);
-    for (; base < count; base += step) {
-        const bool active = base + slot < count;
-        const int4 cur = wk;
-        float x[8];
-        int layer = 0, b = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = 0.f;
-        if (active) {
-            b = cur.x / 3;
-            layer = cur.x - b * 3;
-            const int w = lt.w[layer], h = lt.h[layer];
-            const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
-            const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
-            const int col = cur.y + reflect_pad_idx(j, wc);
-            if (hc == S) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = src[plane_elem(g.tiled, w, cur.z + k, col)];      // (tiled: the leaf is two 128-byte lines)
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = src[plane_elem(g.tiled, w, cur.z + reflect_pad_idx(k, hc), col)];
-            }
-            if (base + step + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + step + slot);
+    // this workgroup's contiguous share of the items, a multiple of LPB
+    const int per = (int)((((unsigned)count + nb - 1) / nb + LPB - 1) / LPB * LPB);
+    const long long first64 = (long long)bid * per;
+    if (first64 >= count) return;
+    const int first = (int)first64, last = count - first > per ? first + per : count;
+    int p = 0;                                // plane of the lane's current item: largest p with s_pref[p] <= item
+    if (first + slot < last) {
+        int lo = 0, hi = a.nplanes;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= first + slot) lo = mid; else hi = mid;
         }
+        p = lo;
+    }
+    // a descriptor as it is fetched: plane | packed origin | coefficient offset.  NOT unpacked here -- arithmetic on the loaded words would make
+    // the wave wait for them (and for every pixel load issued before them) on the spot
+    auto fetch = [&](int item) -> int4 {
+        while (s_pref[p + 1] <= item) p++;                  // (item < count = s_pref[nplanes]: p + 1 <= nplanes)
+        const int b = p / 3, l = p - 3 * b;
+        const LeafWork *wp = a.work + ((long long)b * wstride + lt.woff[l] + (item - s_pref[p]));
+        return make_int4(p, (int)wp->xy, 0, wp->coef);
+    };
+    auto unpacked = [](const int4 &r) { return make_int4(r.x, (int)((unsigned)r.y & 0xffffu), (int)((unsigned)r.y >> 16), r.w); };
+    // the pixels of a leaf: column j of X, requested one leaf ahead (and its descriptor two ahead), so that no memory latency sits between two leaves
+    // Every lane loads (lanes without a leaf hold the descriptor of an earlier one or zeros = the leaf at the origin of plane 0: valid addresses,
+    // results unused), and the one branch -- does ANY lane's leaf stick out of its plane -- is uniform: loads under per-lane branches made the
+    // compiler wait for every outstanding load at each join.
+    auto load_x = [&](const int4 &raw, float (&x)[8]) {
+        const int4 d = unpacked(raw);
+        const int b = d.x / 3, layer = d.x - b * 3;
+        const int w = lt.w[layer], h = lt.h[layer];
+        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+        const int hc = min(S, h - d.z), wc = min(S, w - d.y);
+        if (!__any(hc != S || wc != S)) {
+            if (TILED) {                      // column j of an aligned leaf: block column j / 4, rows 0..3 of block row 0, then of block row 1
+                const float *c0 = src + (((long long)(d.z >> 2) * (w >> 2) + (d.y >> 2) + (j >> 2)) * 16 + (j & 3));
+                const float *c1 = c0 + (long long)(w >> 2) * 16;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { x[k] = c0[4 * k]; x[4 + k] = c1[4 * k]; }
+            } else {
+                const float *c0 = src + ((long long)d.z * w + d.y + j);
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = c0[(long long)k * w];
+            }
+        } else {
+            const int col = d.y + reflect_pad_idx(j, wc);
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = src[plane_elem(TILED ? 1 : 0, w, d.z + reflect_pad_idx(k, hc), col)];
+        }
+    };
+    // Bytes in flight bound this kernel (a leaf is 2 KiB per wave-round, and the basis costs the registers of five more waves): the pixels of the
+    // next TWO leaves and the descriptor of the third are in flight under a leaf's work.  Three buffers, the loop unrolled three-fold so that
+    // no register with a load outstanding is ever copied.
+    int4 d0 = make_int4(0, 0, 0, 0), d1 = d0, d2 = d0, dv = d0;
+    float x0[8], x1[8], x2[8];
+    if (first + slot < last) d0 = fetch(first + slot);
+    if (first + LPB + slot < last) d1 = fetch(first + LPB + slot);
+    if (first + 2 * LPB + slot < last) dv = fetch(first + 2 * LPB + slot);
+    load_x(d0, x0);
+    load_x(d1, x1);
+    int base = first;
+    auto step = [&](const float (&x)[8], const int4 &cur_raw, float (&x_fill)[8], int4 &d_fill) {
+        const int4 cur = unpacked(cur_raw);
+        const bool active = base + slot < last;
+        // (the descriptor load goes out BEFORE the pixel loads: the counter of outstanding loads retires in order, so waiting for a descriptor one
+        // leaf later must not imply waiting for pixels requested after it)
+        d_fill = dv;                                             // leaf base + 2 LPB: requested one leaf ago
+        if (base + 3 * LPB + slot < last) dv = fetch(base + 3 * LPB + slot);
+        load_x(d_fill, x_fill);
+        const int b = cur.x / 3, layer = cur.x - b * 3;
         // T[i][j] = sum_k D[i][k] X[k][j]: this lane's column
         float t[8];
 #pragma unroll
@@ -463,31 +550,57 @@ __device__ __forceinline__ void dct8_body(const Geom &g, const QtGeom &q, const 
             for (int k = 0; k < 8; k++) acc = __builtin_fmaf(D[i][k], x[k], acc);
             t[i] = acc;
         }
-        // (all 64 lanes take part in the shuffles; the groups of inactive leaves carry zeros)
+        // (all 64 lanes take part in the shuffles; the groups without a leaf carry finite pixels of some other leaf, their results are not stored)
         transpose8_stage<1>(t, (lane & 1) != 0);
         transpose8_stage<2>(t, (lane & 2) != 0);
         transpose8_stage<4>(t, (lane & 4) != 0);
         // now t[k] = T[j][k]: Y[j][c] = sum_k T[j][k] D[c][k]
-        float y[8], ymax = 0.f, qmax = 0.f, qf[8];
+        float y[8], ymax = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; k++) acc = __builtin_fmaf(t[k], D[c][k], acc);
             y[c] = acc;
-            qf[c] = sQf[layer * SS + j * S + c];
             ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
-            qmax = __builtin_fmaxf(qmax, qf[c]);
         }
         const long long out_base = active ? (long long)b * q.coeff_stride + lt.coff[layer] + cur.w : 0;
         if (WANT_DCT && active) {
 #pragma unroll
             for (int c = 0; c < 8; c++) a.dct_f32[out_base + j * S + c] = y[c];
         }
-        // one range test per wave for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
-        if (!__any(qmax > 4194304.0f || !(ymax < 131072.0f))) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int qo = layer * SS + j * S;
+        const f32x4 qf0 = *reinterpret_cast<const f32x4 *>(&sQf[qo]), qf1 = *reinterpret_cast<const f32x4 *>(&sQf[qo + 4]);
+        const float qf[8] = { qf0[0], qf0[1], qf0[2], qf0[3], qf1[0], qf1[1], qf1[2], qf1[3] };
+        // one range test per wave for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18)
+        if (!slow_q && !__any(!(ymax < 131072.0f))) {
+            const f32x4 rq0 = *reinterpret_cast<const f32x4 *>(&sQr[qo]), rq1 = *reinterpret_cast<const f32x4 *>(&sQr[qo + 4]);
+            const f32x4 qh0 = *reinterpret_cast<const f32x4 *>(&sQh[qo]), qh1 = *reinterpret_cast<const f32x4 *>(&sQh[qo + 4]);
+            const float rq[8] = { rq0[0], rq0[1], rq0[2], rq0[3], rq1[0], rq1[1], rq1[2], rq1[3] };
+            const float qh[8] = { qh0[0], qh0[1], qh0[2], qh0[3], qh1[0], qh1[1], qh1[2], qh1[3] };
+            // quantise_f32 with the reciprocal and q / 2 looked up: k = rint(y / q) is at most one off, the remainder y - k q is exact, and only
+            // |remainder| >= q / 2 needs the correction -- one test per wave and leaf
+            float kf[8], rem[8];
+            unsigned long long fix = 0;           // lanes with a remainder at or beyond q / 2 (ballots: the comparisons write scalar masks, the scalar unit ors them)
 #pragma unroll
-            for (int c = 0; c < 8; c++) slab[zz[c]] = quantise_f32(y[c], qf[c]);
+            for (int c = 0; c < 8; c++) {
+                kf[c] = __builtin_rintf(y[c] * rq[c]);
+                rem[c] = __builtin_fmaf(-kf[c], qf[c], y[c]);
+                fix |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(rem[c]) >= qh[c]);
+            }
+            int ki[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) ki[c] = (int)kf[c];
+            if (fix != 0) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float ar = __builtin_fabsf(rem[c]);
+                    if (ar > qh[c] || (ar == qh[c] && (ki[c] & 1))) ki[c] += rem[c] > 0.f ? 1 : -1;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) slab[zz[c]] = ki[c];
         } else {
 #pragma unroll
             for (int c = 0; c < 8; c++) slab[zz[c]] = quantise_f64(y[c], (int)qf[c]);
@@ -498,7 +611,19 @@ __device__ __forceinline__ void dct8_body(const Geom &g, const QtGeom &q, const 
             dst[2 * j] = o0;
             dst[2 * j + 1] = o1;
         }
+    };
+    while (true) {
+        step(x0, d0, x2, d2); base += LPB; if (base >= last) break;
+        step(x1, d1, x0, d0); base += LPB; if (base >= last) break;
+        step(x2, d2, x1, d1); base += LPB; if (base >= last) break;
     }
+}
+template <bool WANT_DCT>
+__device__ __forceinline__ void dct8_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
+{
+    __shared__ Dct8Lds L;
+    if (g.tiled) dct8_impl<WANT_DCT, true>(L, g, q, a, max_items, bid, nb);
+    else dct8_impl<WANT_DCT, false>(L, g, q, a, max_items, bid, nb);
 }
 template <bool WANT_DCT>
 __global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, long long max_items)
@@ -520,22 +645,49 @@ __global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, 
 // ------------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Round 5: what the wave does per leaf besides the eight MFMAs was 224 vector instructions (PMC: the kernel issue-bound at 0.69, not
+// HBM-bound).  Now: the plane layout is a template parameter (as a run-time flag every element address carried a branch); a workgroup
+// walks a CONTIGUOUS range of the item list, so the plane of an item is tracked by a scalar comparison instead of a binary search through
+// LDS with a readfirstlane per probe; descriptors and everything derived from them are scalar (the work list is read by scalar loads);
+// the four pixel loads of an unclipped leaf are scalar base + per-lane constant; quantisers, their reciprocals and their halves come
+// from per-lane tables (three 16-byte LDS reads), and the quantiser's correction is one rarely-taken branch per leaf.
 // (the body takes its block index and block count as arguments: k_dct_multi below runs it on a share of its grid)
-template <bool WANT_DCT>
-__device__ __forceinline__ void dct16_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
+struct __attribute__((aligned(16))) Dct16Lds {     // (declared once, in dct16_body: as statics of the two layout instantiations it would be allocated twice)
+    float qf[3 * 256], qr[3 * 256], qh[3 * 256];     // [layer][lane][r]: what a lane reads for its four outputs
+    int out[4][256];
+    int slow;
+    LayerTab lt;
+};
+template <bool WANT_DCT, bool TILED>
+__device__ __forceinline__ void dct16_impl(Dct16Lds &L, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int S = 16, SS = 256;
-    __shared__ float sQf[3 * SS];
-    __shared__ int sOut[4][SS];
-    __shared__ LayerTab lt;
+    float (&sQf)[3 * SS] = L.qf, (&sQr)[3 * SS] = L.qr, (&sQh)[3 * SS] = L.qh;
+    int (&sOut)[4][SS] = L.out;
+    int &sSlowQ = L.slow;
+    LayerTab &lt = L.lt;
     extern __shared__ int s_pref[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * SS; i += 256) sQf[i] = (float)(a.qm[i / SS] ? a.qm[i / SS][i % SS] : 1);
+    if (tid == 0) sSlowQ = 0;
+    __syncthreads();
+    for (int e = tid; e < 3 * SS; e += 256) {
+        const int layer = e / SS, ln = (e >> 2) & 63, r = e & 3;
+        const int ridx = (4 * (ln >> 4) + r) * S + (ln & 15);
+        const int qi = a.qm[layer] ? a.qm[layer][ridx] : 1;
+        sQf[e] = (float)qi;
+        sQr[e] = __builtin_amdgcn_rcpf((float)qi);
+        sQh[e] = 0.5f * (float)qi;
+        if (qi > (1 << 22)) sSlowQ = 1;      // (never with the codec's own tables: quantise_f32 needs q <= 2^22)
+    }
     dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
-    long long count = s_pref[a.nplanes];
-    if (count > max_items) count = max_items;
+    // (LDS values are per-lane to the compiler, and so is everything compared as 64-bit integers -- the scalar unit has no such comparison: item
+    // indices are ints, as the prefix sums are)
+    int count = __builtin_amdgcn_readfirstlane(s_pref[a.nplanes]);
+    if ((long long)count > max_items) count = (int)max_items;
+    const bool slow_q = __builtin_amdgcn_readfirstlane(sSlowQ) != 0;
     const long long wstride = q.work_stride[a.k];
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), gq = lane >> 4, i = lane & 15;
+    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     float dB[4];
     int zz[4];
 #pragma unroll
@@ -543,54 +695,101 @@ __device__ __forceinline__ void dct16_body(const Geom &g, const QtGeom &q, const
 #pragma unroll
     for (int r = 0; r < 4; r++) zz[r] = zigzag_pos<S>(4 * gq + r, i);
     int *out_slab = sOut[wv];
-    const long long nw = (long long)nb * 4;
-    long long item = (long long)bid * 4 + wv;
-
-    // Everything about a leaf is wave-uniform, so descriptors live in SGPRs (readfirstlane) and the plane / clipping arithmetic is
-    // scalar.  Items past the end are clamped to the last one (its loads are harmless and unused): no divergent branch, so no
-    // wait sits between a load and the work it is meant to overlap.
-    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    auto fetch = [&](long long it) {                       // -> descriptor in VECTOR registers, load still in flight
-        if (it > count - 1) it = count - 1;
-        int lo = 0, hi = a.nplanes;                        // largest p with s_pref[p] <= it (scalar search on LDS values)
+    // per-layer geometry in scalar registers
+    int lw[3], lh[3];
+    long long lpoff[3], lcoff[3], lwoff[3];
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        lw[l] = rfl(lt.w[l]); lh[l] = rfl(lt.h[l]);
+        lpoff[l] = ((long long)rfl((int)(lt.poff[l] >> 32)) << 32) | (unsigned)rfl((int)lt.poff[l]);
+        lcoff[l] = ((long long)rfl((int)(lt.coff[l] >> 32)) << 32) | (unsigned)rfl((int)lt.coff[l]);
+        lwoff[l] = ((long long)rfl((int)(lt.woff[l] >> 32)) << 32) | (unsigned)rfl((int)lt.woff[l]);
+    }
+    auto sel = [](int l, auto v0, auto v1, auto v2) { return l == 0 ? v0 : l == 1 ? v1 : v2; };
+    // this workgroup's contiguous share of the items (a multiple of 4: one leaf per wave and round)
+    const int per = (int)((((unsigned)count + nb - 1) / nb + 3) / 4 * 4);
+    const long long first64 = (long long)bid * per;
+    if (first64 >= count) return;
+    const int first = (int)first64, last = count - first > per ? first + per : count;
+    int item = first + wv;
+    if (item >= last) return;
+    // plane of the item whose descriptor is fetched next: [pbeg, pend) = its item range (scalar; items only move forward)
+    int p = 0;
+    {
+        int lo = 0, hi = a.nplanes;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if ((long long)rfl(s_pref[mid]) <= it) lo = mid; else hi = mid;
+            if (rfl(s_pref[mid]) <= item) lo = mid; else hi = mid;
         }
-        const int b = lo / 3, l = lo - 3 * b;
-        return unpack_work(lo, a.work[(long long)b * wstride + lt.woff[l] + (it - rfl(s_pref[lo]))]);
+        p = lo;
+    }
+    int pbeg = rfl(s_pref[p]), pend = rfl(s_pref[p + 1]);
+    struct Desc { int plane; unsigned xy; int coef; };
+    auto fetch = [&](int it) -> Desc {               // scalar: the work list through the scalar cache
+        if (it > last - 1) it = last - 1;                  // (clamped: the loads past the end are harmless and unused; still >= every earlier item of this wave)
+        while (it >= pend) { p++; pbeg = pend; pend = rfl(s_pref[p + 1]); }
+        int ps = p;                                        // (p also addresses LDS, which parks it in a vector register: pin a scalar copy for the arithmetic)
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ps) : "v"(p));
+        const int b = ps / 3, l = ps - 3 * b;
+        const LeafWork *wp = a.work + ((long long)b * wstride + sel(l, lwoff[0], lwoff[1], lwoff[2]) + (long long)(it - pbeg));
+        // The work list is constant for the life of this kernel: read through the constant address space, a uniform address makes it a SCALAR load
+        // -- the words arrive in scalar registers, and the load is counted on the scalar counter, so that waiting for a descriptor never means
+        // waiting for the pixel loads issued around it (vector loads retire in order on one counter).
+        typedef const __attribute__((address_space(4))) LeafWork *ConstWork;
+        ConstWork cw = (ConstWork)(unsigned long long)wp;
+        Desc d;
+        d.plane = ps;
+        d.xy = cw->xy;
+        d.coef = cw->coef;
+        return d;
     };
-    auto load_x = [&](const int4 &d, float (&x)[4]) {      // d scalar
-        const int b = d.x / 3, layer = d.x - b * 3;
-        const int w = rfl(lt.w[layer]), h = rfl(lt.h[layer]);
-        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
-        if (d.z + S <= h && d.y + S <= w) {
+    auto landed = [&](const Desc &d) { return d; };
+    const unsigned lane_tiled = (unsigned)((i >> 2) * 16 + gq * 4 + (i & 3));
+    auto load_x = [&](const Desc &d, float (&x)[4]) {      // d scalar
+        const int b = d.plane / 3, layer = d.plane - b * 3;
+        const int w = sel(layer, lw[0], lw[1], lw[2]), h = sel(layer, lh[0], lh[1], lh[2]);
+        const int dy = (int)(d.xy & 0xffffu), dz = (int)(d.xy >> 16);
+        const float *src = a.norm + ((long long)b * g.pstride + sel(layer, lpoff[0], lpoff[1], lpoff[2]));
+        if (dz + S <= h && dy + S <= w) {
+            if (TILED) {                                   // rows 4 s + gq: block row dz / 4 + s, row gq of the block; column dy + i
+                const float *row0 = src + ((long long)(dz >> 2) * (w >> 2) + (dy >> 2)) * 16;
 #pragma unroll
-            for (int s = 0; s < 4; s++) x[s] = src[plane_elem(g.tiled, w, d.z + 4 * s + gq, d.y + i)];
+                for (int s = 0; s < 4; s++) x[s] = (row0 + (long long)s * (w >> 2) * 16)[lane_tiled];
+            } else {
+                const float *row0 = src + ((long long)dz * w + dy);
+                const unsigned lane_rm = (unsigned)(gq * w + i);
+#pragma unroll
+                for (int s = 0; s < 4; s++) x[s] = (row0 + (long long)s * 4 * w)[lane_rm];
+            }
         } else {                                           // clipped at the plane border: np.pad(reflect) indices
-            const int hc = min(S, h - d.z), wc = min(S, w - d.y);
-            const int col = d.y + reflect_pad_idx(i, wc);
+            const int hc = min(S, h - dz), wc = min(S, w - dy);
+            const int col = dy + reflect_pad_idx(i, wc);
 #pragma unroll
-            for (int s = 0; s < 4; s++) x[s] = src[plane_elem(g.tiled, w, d.z + reflect_pad_idx(4 * s + gq, hc), col)];
+            for (int s = 0; s < 4; s++) x[s] = src[plane_elem(TILED ? 1 : 0, w, dz + reflect_pad_idx(4 * s + gq, hc), col)];
         }
     };
-    auto rfl4 = [&](const int4 &v) { return make_int4(rfl(v.x), rfl(v.y), rfl(v.z), rfl(v.w)); };
-    if (item >= count) return;
-    int4 d_cur = rfl4(fetch(item));
-    int4 dv_nxt = fetch(item + nw);
-    float x_cur[4], x_nxt[4];
-    load_x(d_cur, x_cur);
-    for (; item < count; item += nw) {
-        const int4 d_nxt = rfl4(dv_nxt);                       // requested one leaf ago
-        load_x(d_nxt, x_nxt);                                  // next leaf's pixels ...
-        dv_nxt = fetch(item + 2 * nw);                         // ... and the descriptor after it: both in flight under this leaf's work
-        const int b = d_cur.x / 3, layer = d_cur.x - b * 3;
-        floatx4 p = { 0.f, 0.f, 0.f, 0.f };
+    // Bytes in flight are what bounds this kernel once the instruction count is down (a leaf is 1 KiB per wave; with one leaf of look-ahead
+    // the kernel ran at 3.7 TB/s): the pixels of the next TWO leaves and the descriptor of the third are in flight under a leaf's work.  Three
+    // buffers, the loop unrolled three-fold so that no register with a load outstanding is ever copied.
+    Desc d0 = landed(fetch(item)), d1, d2;
+    float x0[4], x1[4], x2[4];
+    load_x(d0, x0);
+    d1 = landed(fetch(item + 4));
+    Desc dv = fetch(item + 8);
+    load_x(d1, x1);
+    auto step = [&](const float (&x_cur)[4], const Desc &d_cur, float (&x_fill)[4], Desc &d_fill) {
+        // (the descriptor load goes out BEFORE the pixel loads: the counter of outstanding loads retires in order, so waiting for a descriptor
+        // one leaf later must not imply waiting for pixels requested after it)
+        d_fill = landed(dv);                                   // leaf item + 8: requested one leaf ago
+        dv = fetch(item + 12);
+        load_x(d_fill, x_fill);
+        const int b = d_cur.plane / 3, layer = d_cur.plane - b * 3;
+        floatx4 pacc = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-        for (int s = 0; s < 4; s++) p = __builtin_amdgcn_mfma_f32_16x16x4f32(x_cur[s], dB[s], p, 0, 0, 0);
+        for (int s = 0; s < 4; s++) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x_cur[s], dB[s], pacc, 0, 0, 0);
         // (__float_as_uint, not __builtin_bit_cast: hipcc 7.2 folds a bit_cast of an ext-vector ELEMENT to element 0)
-        const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[0]), __float_as_uint(p[2]), false, false);
-        const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[1]), __float_as_uint(p[3]), false, false);
+        const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(pacc[0]), __float_as_uint(pacc[2]), false, false);
+        const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(pacc[1]), __float_as_uint(pacc[3]), false, false);
         const unsigned p02a = p02[0], p02b = p02[1], p13a = p13[0], p13b = p13[1];
         const auto q01 = __builtin_amdgcn_permlane16_swap(p02a, p13a, false, false);
         const auto q23 = __builtin_amdgcn_permlane16_swap(p02b, p13b, false, false);
@@ -599,20 +798,38 @@ __device__ __forceinline__ void dct16_body(const Geom &g, const QtGeom &q, const
         floatx4 y = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
         for (int s = 0; s < 4; s++) y = __builtin_amdgcn_mfma_f32_16x16x4f32(t[s], dB[s], y, 0, 0, 0);
-        const long long out_base = (long long)b * q.coeff_stride + lt.coff[layer] + d_cur.w;
-        float qf[4], ymax = 0.f, qmax = 0.f;
+        const long long out_base = (long long)b * q.coeff_stride + sel(layer, lcoff[0], lcoff[1], lcoff[2]) + d_cur.coef;
+        if (WANT_DCT) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int ridx = (4 * gq + r) * S + i;
-            if (WANT_DCT) a.dct_f32[out_base + ridx] = y[r];
-            qf[r] = sQf[layer * SS + ridx];
-            ymax = __builtin_fmaxf(ymax, __builtin_fabsf(y[r]));
-            qmax = __builtin_fmaxf(qmax, qf[r]);
+            for (int r = 0; r < 4; r++) a.dct_f32[out_base + (4 * gq + r) * S + i] = y[r];
         }
-        // one range test per leaf for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
-        if (!__any(qmax > 4194304.0f || !(ymax < 131072.0f))) {
+        const floatx4 qf = *reinterpret_cast<const floatx4 *>(&sQf[layer * SS + lane * 4]), rq = *reinterpret_cast<const floatx4 *>(&sQr[layer * SS + lane * 4]),
+                      qh = *reinterpret_cast<const floatx4 *>(&sQh[layer * SS + lane * 4]);
+        const float ymax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(y[0]), __builtin_fabsf(y[1])), __builtin_fmaxf(__builtin_fabsf(y[2]), __builtin_fabsf(y[3])));
+        // one range test per leaf for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18)
+        if (!slow_q && !__any(!(ymax < 131072.0f))) {
+            // quantise_f32 with the reciprocal and q / 2 looked up: k = rint(y / q) is at most one off, the remainder r = y - k q is exact, and
+            // only |r| >= q / 2 needs the correction -- one test per leaf
+            float kf[4], rem[4];
+            unsigned long long fix = 0;           // lanes with a remainder at or beyond q / 2 (ballots: the comparisons write scalar masks, the scalar unit ors them)
 #pragma unroll
-            for (int r = 0; r < 4; r++) out_slab[zz[r]] = quantise_f32(y[r], qf[r]);
+            for (int r = 0; r < 4; r++) {
+                kf[r] = __builtin_rintf(y[r] * rq[r]);
+                rem[r] = __builtin_fmaf(-kf[r], qf[r], y[r]);
+                fix |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(rem[r]) >= qh[r]);
+            }
+            int ki[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) ki[r] = (int)kf[r];
+            if (fix != 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float ar = __builtin_fabsf(rem[r]);
+                    if (ar > qh[r] || (ar == qh[r] && (ki[r] & 1))) ki[r] += rem[r] > 0.f ? 1 : -1;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) out_slab[zz[r]] = ki[r];
         } else {
 #pragma unroll
             for (int r = 0; r < 4; r++) out_slab[zz[r]] = quantise_f64(y[r], (int)qf[r]);
@@ -621,10 +838,19 @@ __device__ __forceinline__ void dct16_body(const Geom &g, const QtGeom &q, const
         // come after these reads)
         const int4 o = reinterpret_cast<const int4 *>(out_slab)[lane];
         reinterpret_cast<int4 *>(a.coeffs + out_base)[lane] = o;
-        d_cur = d_nxt;
-#pragma unroll
-        for (int s = 0; s < 4; s++) x_cur[s] = x_nxt[s];
+    };
+    while (true) {
+        step(x0, d0, x2, d2); item += 4; if (item >= last) break;
+        step(x1, d1, x0, d0); item += 4; if (item >= last) break;
+        step(x2, d2, x1, d1); item += 4; if (item >= last) break;
     }
+}
+template <bool WANT_DCT>
+__device__ __forceinline__ void dct16_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
+{
+    __shared__ Dct16Lds L;
+    if (g.tiled) dct16_impl<WANT_DCT, true>(L, g, q, a, max_items, bid, nb);
+    else dct16_impl<WANT_DCT, false>(L, g, q, a, max_items, bid, nb);
 }
 template <bool WANT_DCT>
 __global__ __launch_bounds__(256) void k_dct16_mfma(Geom g, QtGeom q, DctArgs a, long long max_items)

@@ -537,3 +537,32 @@ def test_both_64x64_dct_kernels_and_both_plane_layouts_match_the_oracle(env, ora
         ctx.set_option("dct64_kernel", 2)
     with pytest.raises(ValueError):
         ctx.set_option("no_such_option", 1)
+
+
+def test_merged_dct_launch_and_xcd_tile_order_change_no_result(env, oracle):
+    """Round 5's launch shapes: calls of at most 8 Mpx run the DCTs of sizes 4 .. 64 as one launch (k_dct_multi, option "dct_multi"), and the Sobel /
+    NMS kernel walks its tiles in XCD-contiguous runs (option "sobel_xcd").  Every pairing, and the merged launch on both plane layouts, against the
+    ORACLE; a call above 8 Mpx (per-size launches whatever the option says) must agree with the small calls image by image."""
+    torch, A, bench = env
+    B, H, W = 3, 1080, 1920
+    x = bench.synth_batch(torch, B, H, W, 23, torch.device("cuda", 0))
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    refs = {b: oracle.encode_image(x[b].cpu().numpy(), "YCbCr", (40, 80), (4, 64)) for b in (0, 2)}
+    sizes = np.concatenate([refs[b][l]["leaves"][:, 2] for b in refs for l in range(3)])
+    assert all((sizes == s).any() for s in (4, 8, 16, 32, 64)), "every block size must occur"
+    ctx = codec._bind()
+    try:
+        for multi in (1, 0):
+            for xcd in (1, 0):
+                for row_major in ((0, 1) if multi else (0,)):
+                    ctx.set_option("dct_multi", multi); ctx.set_option("sobel_xcd", xcd); ctx.set_option("planes_row_major", row_major)
+                    enc = codec.compress_batch(x)
+                    for b in refs:
+                        check_image(enc, b, refs[b], f"dct_multi={multi} sobel_xcd={xcd} planes_row_major={row_major} image {b}")
+        ctx.set_option("dct_multi", 1); ctx.set_option("sobel_xcd", 1); ctx.set_option("planes_row_major", 0)
+        big = codec.compress_batch(torch.cat([x, x]))                      # 12.4 Mpx: above the merged launch's limit
+        for b in refs:
+            check_image(big, b + B, refs[b], f"call above 8 Mpx, image {b + B}")
+    finally:
+        ctx.set_option("dct_multi", 1); ctx.set_option("sobel_xcd", 1); ctx.set_option("planes_row_major", 0)
+
