@@ -425,122 +425,60 @@ __device__ __forceinline__ void transpose8_stage(float (&a)[8], bool upper)     
         }
 }
 
-// Round 5 (PMC: the kernel was issue-bound at 0.86 with 69 vector instructions per pixel): the basis D is pinned in VECTOR registers (as 64
-// scalars it did not fit beside the rest, and the compiler parked it in the lanes of a vector register: 58 v_readlane per leaf); the plane
-// layout is a template parameter; a workgroup walks a contiguous range of the item list (plane by a comparison per leaf, not a binary
-// search); quantisers, reciprocals and halves come from tables (six 16-byte LDS reads per lane) and the quantiser's correction is one
-// rarely-taken branch per wave and leaf.
+// (Round 5 rebuilt this kernel the way the 16 x 16 one was -- compile-time plane layout, contiguous item ranges, tabulated quantiser, the basis
+// pinned in 64 vector registers, two leaves of pixel look-ahead: half the instructions, 0.165 -> 0.160 ms alone at 164 registers, and a pipelined
+// step that did not move: it runs in the 104-register gap beside three blur workgroups, and bounded to 96 registers the rebuilt form spills.  The
+// round-4 form below stays: 58 registers, 9 KiB.)
 // (the body takes its block index and block count as arguments: k_dct_multi below runs it on a share of its grid)
-struct __attribute__((aligned(16))) Dct8Lds {      // (declared once, in dct8_body: as statics of the two layout instantiations it would be allocated twice)
-    float qf[3 * 64], qr[3 * 64], qh[3 * 64];
-    int out[4][8 * 64];                              // per wave: 8 leaves x 64 coefficients
-    int slow;
-    LayerTab lt;
-};
-template <bool WANT_DCT, bool TILED>
-__device__ __forceinline__ void dct8_impl(Dct8Lds &L, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
+template <bool WANT_DCT>
+__device__ __forceinline__ void dct8_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int S = 8, SS = 64, LPB = 32;
-    float (&sQf)[3 * SS] = L.qf, (&sQr)[3 * SS] = L.qr, (&sQh)[3 * SS] = L.qh;
-    int (&sOut)[4][8 * SS] = L.out;
-    int &sSlowQ = L.slow;
-    LayerTab &lt = L.lt;
+    __shared__ float sQf[3 * SS];
+    __shared__ int sOut[4][8 * SS];          // per wave: 8 leaves x 64 coefficients
+    __shared__ LayerTab lt;
     extern __shared__ int s_pref[];
     const int tid = threadIdx.x;
-    if (tid == 0) sSlowQ = 0;
-    __syncthreads();
-    if (tid < 3 * SS) {
-        const int qi = a.qm[tid / SS] ? a.qm[tid / SS][tid % SS] : 1;
-        sQf[tid] = (float)qi;
-        sQr[tid] = __builtin_amdgcn_rcpf((float)qi);
-        sQh[tid] = 0.5f * (float)qi;
-        if (qi > (1 << 22)) sSlowQ = 1;      // (never with the codec's own tables: quantise_f32 needs q <= 2^22)
-    }
+    if (tid < 3 * SS) sQf[tid] = (float)(a.qm[tid / SS] ? a.qm[tid / SS][tid % SS] : 1);
     dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
-    int count = s_pref[a.nplanes];
-    if ((long long)count > max_items) count = (int)max_items;
-    const bool slow_q = sSlowQ != 0;
+    long long count = s_pref[a.nplanes];
+    if (count > max_items) count = max_items;
     const long long wstride = q.work_stride[a.k];
     const int lane = tid & 63, wv = tid >> 6, j = tid & 7, slot = tid >> 3;      // slot: leaf of this block iteration (0..31)
     float D[8][8];
 #pragma unroll
     for (int i = 0; i < 64; i++) D[i >> 3][i & 7] = a.D[i];
-#pragma unroll
-    for (int i = 0; i < 64; i++) asm volatile("" : "+v"(D[i >> 3][i & 7]));      // (after ALL the loads: a pin directly behind its load would wait for it, 64 round trips in a row)
     int zz[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) zz[c] = zigzag_pos<S>(j, c);                     // after the transpose this lane owns row j
     int *slab = sOut[wv] + ((lane >> 3) * SS);
-    // this workgroup's contiguous share of the items, a multiple of LPB
-    const int per = (int)((((unsigned)count + nb - 1) / nb + LPB - 1) / LPB * LPB);
-    const long long first64 = (long long)bid * per;
-    if (first64 >= count) return;
-    const int first = (int)first64, last = count - first > per ? first + per : count;
-    int p = 0;                                // plane of the lane's current item: largest p with s_pref[p] <= item
-    if (first + slot < last) {
-        int lo = 0, hi = a.nplanes;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pref[mid] <= first + slot) lo = mid; else hi = mid;
-        }
-        p = lo;
-    }
-    // a descriptor as it is fetched: plane | packed origin | coefficient offset.  NOT unpacked here -- arithmetic on the loaded words would make
-    // the wave wait for them (and for every pixel load issued before them) on the spot
-    auto fetch = [&](int item) -> int4 {
-        while (s_pref[p + 1] <= item) p++;                  // (item < count = s_pref[nplanes]: p + 1 <= nplanes)
-        const int b = p / 3, l = p - 3 * b;
-        const LeafWork *wp = a.work + ((long long)b * wstride + lt.woff[l] + (item - s_pref[p]));
-        return make_int4(p, (int)wp->xy, 0, wp->coef);
-    };
-    auto unpacked = [](const int4 &r) { return make_int4(r.x, (int)((unsigned)r.y & 0xffffu), (int)((unsigned)r.y >> 16), r.w); };
-    // the pixels of a leaf: column j of X, requested one leaf ahead (and its descriptor two ahead), so that no memory latency sits between two leaves
-    // Every lane loads (lanes without a leaf hold the descriptor of an earlier one or zeros = the leaf at the origin of plane 0: valid addresses,
-    // results unused), and the one branch -- does ANY lane's leaf stick out of its plane -- is uniform: loads under per-lane branches made the
-    // compiler wait for every outstanding load at each join.
-    auto load_x = [&](const int4 &raw, float (&x)[8]) {
-        const int4 d = unpacked(raw);
-        const int b = d.x / 3, layer = d.x - b * 3;
-        const int w = lt.w[layer], h = lt.h[layer];
-        const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
-        const int hc = min(S, h - d.z), wc = min(S, w - d.y);
-        if (!__any(hc != S || wc != S)) {
-            if (TILED) {                      // column j of an aligned leaf: block column j / 4, rows 0..3 of block row 0, then of block row 1
-                const float *c0 = src + (((long long)(d.z >> 2) * (w >> 2) + (d.y >> 2) + (j >> 2)) * 16 + (j & 3));
-                const float *c1 = c0 + (long long)(w >> 2) * 16;
+    const long long step = (long long)nb * LPB;
+    long long base = (long long)bid * LPB;
+    int4 wk = make_int4(0, 0, 0, 0);
+    if (base + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + slot);
+    for (; base < count; base += step) {
+        const bool active = base + slot < count;
+        const int4 cur = wk;
+        float x[8];
+        int layer = 0, b = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { x[k] = c0[4 * k]; x[4 + k] = c1[4 * k]; }
+        for (int k = 0; k < 8; k++) x[k] = 0.f;
+        if (active) {
+            b = cur.x / 3;
+            layer = cur.x - b * 3;
+            const int w = lt.w[layer], h = lt.h[layer];
+            const float *src = a.norm + (long long)b * g.pstride + lt.poff[layer];
+            const int hc = min(S, h - cur.z), wc = min(S, w - cur.y);
+            const int col = cur.y + reflect_pad_idx(j, wc);
+            if (hc == S) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = src[plane_elem(g.tiled, w, cur.z + k, col)];      // (tiled: the leaf is two 128-byte lines)
             } else {
-                const float *c0 = src + ((long long)d.z * w + d.y + j);
 #pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = c0[(long long)k * w];
+                for (int k = 0; k < 8; k++) x[k] = src[plane_elem(g.tiled, w, cur.z + reflect_pad_idx(k, hc), col)];
             }
-        } else {
-            const int col = d.y + reflect_pad_idx(j, wc);
-#pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = src[plane_elem(TILED ? 1 : 0, w, d.z + reflect_pad_idx(k, hc), col)];
+            if (base + step + slot < count) wk = fetch_item(a, wstride, lt, s_pref, base + step + slot);
         }
-    };
-    // Bytes in flight bound this kernel (a leaf is 2 KiB per wave-round, and the basis costs the registers of five more waves): the pixels of the
-    // next TWO leaves and the descriptor of the third are in flight under a leaf's work.  Three buffers, the loop unrolled three-fold so that
-    // no register with a load outstanding is ever copied.
-    int4 d0 = make_int4(0, 0, 0, 0), d1 = d0, d2 = d0, dv = d0;
-    float x0[8], x1[8], x2[8];
-    if (first + slot < last) d0 = fetch(first + slot);
-    if (first + LPB + slot < last) d1 = fetch(first + LPB + slot);
-    if (first + 2 * LPB + slot < last) dv = fetch(first + 2 * LPB + slot);
-    load_x(d0, x0);
-    load_x(d1, x1);
-    int base = first;
-    auto step = [&](const float (&x)[8], const int4 &cur_raw, float (&x_fill)[8], int4 &d_fill) {
-        const int4 cur = unpacked(cur_raw);
-        const bool active = base + slot < last;
-        // (the descriptor load goes out BEFORE the pixel loads: the counter of outstanding loads retires in order, so waiting for a descriptor one
-        // leaf later must not imply waiting for pixels requested after it)
-        d_fill = dv;                                             // leaf base + 2 LPB: requested one leaf ago
-        if (base + 3 * LPB + slot < last) dv = fetch(base + 3 * LPB + slot);
-        load_x(d_fill, x_fill);
-        const int b = cur.x / 3, layer = cur.x - b * 3;
         // T[i][j] = sum_k D[i][k] X[k][j]: this lane's column
         float t[8];
 #pragma unroll
@@ -550,57 +488,31 @@ __device__ __forceinline__ void dct8_impl(Dct8Lds &L, const Geom &g, const QtGeo
             for (int k = 0; k < 8; k++) acc = __builtin_fmaf(D[i][k], x[k], acc);
             t[i] = acc;
         }
-        // (all 64 lanes take part in the shuffles; the groups without a leaf carry finite pixels of some other leaf, their results are not stored)
+        // (all 64 lanes take part in the shuffles; the groups of inactive leaves carry zeros)
         transpose8_stage<1>(t, (lane & 1) != 0);
         transpose8_stage<2>(t, (lane & 2) != 0);
         transpose8_stage<4>(t, (lane & 4) != 0);
         // now t[k] = T[j][k]: Y[j][c] = sum_k T[j][k] D[c][k]
-        float y[8], ymax = 0.f;
+        float y[8], ymax = 0.f, qmax = 0.f, qf[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; k++) acc = __builtin_fmaf(t[k], D[c][k], acc);
             y[c] = acc;
+            qf[c] = sQf[layer * SS + j * S + c];
             ymax = __builtin_fmaxf(ymax, __builtin_fabsf(acc));
+            qmax = __builtin_fmaxf(qmax, qf[c]);
         }
         const long long out_base = active ? (long long)b * q.coeff_stride + lt.coff[layer] + cur.w : 0;
         if (WANT_DCT && active) {
 #pragma unroll
             for (int c = 0; c < 8; c++) a.dct_f32[out_base + j * S + c] = y[c];
         }
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int qo = layer * SS + j * S;
-        const f32x4 qf0 = *reinterpret_cast<const f32x4 *>(&sQf[qo]), qf1 = *reinterpret_cast<const f32x4 *>(&sQf[qo + 4]);
-        const float qf[8] = { qf0[0], qf0[1], qf0[2], qf0[3], qf1[0], qf1[1], qf1[2], qf1[3] };
-        // one range test per wave for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18)
-        if (!slow_q && !__any(!(ymax < 131072.0f))) {
-            const f32x4 rq0 = *reinterpret_cast<const f32x4 *>(&sQr[qo]), rq1 = *reinterpret_cast<const f32x4 *>(&sQr[qo + 4]);
-            const f32x4 qh0 = *reinterpret_cast<const f32x4 *>(&sQh[qo]), qh1 = *reinterpret_cast<const f32x4 *>(&sQh[qo + 4]);
-            const float rq[8] = { rq0[0], rq0[1], rq0[2], rq0[3], rq1[0], rq1[1], rq1[2], rq1[3] };
-            const float qh[8] = { qh0[0], qh0[1], qh0[2], qh0[3], qh1[0], qh1[1], qh1[2], qh1[3] };
-            // quantise_f32 with the reciprocal and q / 2 looked up: k = rint(y / q) is at most one off, the remainder y - k q is exact, and only
-            // |remainder| >= q / 2 needs the correction -- one test per wave and leaf
-            float kf[8], rem[8];
-            unsigned long long fix = 0;           // lanes with a remainder at or beyond q / 2 (ballots: the comparisons write scalar masks, the scalar unit ors them)
+        // one range test per wave for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18), then branch-free
+        if (!__any(qmax > 4194304.0f || !(ymax < 131072.0f))) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                kf[c] = __builtin_rintf(y[c] * rq[c]);
-                rem[c] = __builtin_fmaf(-kf[c], qf[c], y[c]);
-                fix |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(rem[c]) >= qh[c]);
-            }
-            int ki[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) ki[c] = (int)kf[c];
-            if (fix != 0) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const float ar = __builtin_fabsf(rem[c]);
-                    if (ar > qh[c] || (ar == qh[c] && (ki[c] & 1))) ki[c] += rem[c] > 0.f ? 1 : -1;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 8; c++) slab[zz[c]] = ki[c];
+            for (int c = 0; c < 8; c++) slab[zz[c]] = quantise_f32(y[c], qf[c]);
         } else {
 #pragma unroll
             for (int c = 0; c < 8; c++) slab[zz[c]] = quantise_f64(y[c], (int)qf[c]);
@@ -611,19 +523,7 @@ __device__ __forceinline__ void dct8_impl(Dct8Lds &L, const Geom &g, const QtGeo
             dst[2 * j] = o0;
             dst[2 * j + 1] = o1;
         }
-    };
-    while (true) {
-        step(x0, d0, x2, d2); base += LPB; if (base >= last) break;
-        step(x1, d1, x0, d0); base += LPB; if (base >= last) break;
-        step(x2, d2, x1, d1); base += LPB; if (base >= last) break;
     }
-}
-template <bool WANT_DCT>
-__device__ __forceinline__ void dct8_body(const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
-{
-    __shared__ Dct8Lds L;
-    if (g.tiled) dct8_impl<WANT_DCT, true>(L, g, q, a, max_items, bid, nb);
-    else dct8_impl<WANT_DCT, false>(L, g, q, a, max_items, bid, nb);
 }
 template <bool WANT_DCT>
 __global__ __launch_bounds__(256) void k_dct8_shfl(Geom g, QtGeom q, DctArgs a, long long max_items)
@@ -649,11 +549,11 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // HBM-bound).  Now: the plane layout is a template parameter (as a run-time flag every element address carried a branch); a workgroup
 // walks a CONTIGUOUS range of the item list, so the plane of an item is tracked by a scalar comparison instead of a binary search through
 // LDS with a readfirstlane per probe; descriptors and everything derived from them are scalar (the work list is read by scalar loads);
-// the four pixel loads of an unclipped leaf are scalar base + per-lane constant; quantisers, their reciprocals and their halves come
-// from per-lane tables (three 16-byte LDS reads), and the quantiser's correction is one rarely-taken branch per leaf.
+// the four pixel loads of an unclipped leaf are scalar base + per-lane constant; quantisers and their reciprocals come from per-lane
+// tables (two 16-byte LDS reads), and the quantiser's correction is one rarely-taken branch per leaf.
 // (the body takes its block index and block count as arguments: k_dct_multi below runs it on a share of its grid)
 struct __attribute__((aligned(16))) Dct16Lds {     // (declared once, in dct16_body: as statics of the two layout instantiations it would be allocated twice)
-    float qf[3 * 256], qr[3 * 256], qh[3 * 256];     // [layer][lane][r]: what a lane reads for its four outputs
+    float qf[3 * 256], qr[3 * 256];                  // [layer][lane][r]: what a lane reads for its four outputs
     int out[4][256];
     int slow;
     LayerTab lt;
@@ -662,7 +562,7 @@ template <bool WANT_DCT, bool TILED>
 __device__ __forceinline__ void dct16_impl(Dct16Lds &L, const Geom &g, const QtGeom &q, const DctArgs &a, long long max_items, unsigned bid, unsigned nb)
 {
     constexpr int S = 16, SS = 256;
-    float (&sQf)[3 * SS] = L.qf, (&sQr)[3 * SS] = L.qr, (&sQh)[3 * SS] = L.qh;
+    float (&sQf)[3 * SS] = L.qf, (&sQr)[3 * SS] = L.qr;
     int (&sOut)[4][SS] = L.out;
     int &sSlowQ = L.slow;
     LayerTab &lt = L.lt;
@@ -676,7 +576,6 @@ __device__ __forceinline__ void dct16_impl(Dct16Lds &L, const Geom &g, const QtG
         const int qi = a.qm[layer] ? a.qm[layer][ridx] : 1;
         sQf[e] = (float)qi;
         sQr[e] = __builtin_amdgcn_rcpf((float)qi);
-        sQh[e] = 0.5f * (float)qi;
         if (qi > (1 << 22)) sSlowQ = 1;      // (never with the codec's own tables: quantise_f32 needs q <= 2^22)
     }
     dct_prologue(g, q, a, s_pref, lt);       // ends with a barrier
@@ -803,20 +702,20 @@ __device__ __forceinline__ void dct16_impl(Dct16Lds &L, const Geom &g, const QtG
 #pragma unroll
             for (int r = 0; r < 4; r++) a.dct_f32[out_base + (4 * gq + r) * S + i] = y[r];
         }
-        const floatx4 qf = *reinterpret_cast<const floatx4 *>(&sQf[layer * SS + lane * 4]), rq = *reinterpret_cast<const floatx4 *>(&sQr[layer * SS + lane * 4]),
-                      qh = *reinterpret_cast<const floatx4 *>(&sQh[layer * SS + lane * 4]);
+        const floatx4 qf = *reinterpret_cast<const floatx4 *>(&sQf[layer * SS + lane * 4]), rq = *reinterpret_cast<const floatx4 *>(&sQr[layer * SS + lane * 4]);
         const float ymax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(y[0]), __builtin_fabsf(y[1])), __builtin_fmaxf(__builtin_fabsf(y[2]), __builtin_fabsf(y[3])));
         // one range test per leaf for the float32 quantiser (quantise_f32: q <= 2^22, |y / q| < 2^18)
         if (!slow_q && !__any(!(ymax < 131072.0f))) {
-            // quantise_f32 with the reciprocal and q / 2 looked up: k = rint(y / q) is at most one off, the remainder r = y - k q is exact, and
-            // only |r| >= q / 2 needs the correction -- one test per leaf
+            // quantise_f32 with the reciprocal looked up: k = rint(y / q) is at most one off, the remainder r = y - k q is exact, and
+            // only 2 |r| >= q needs the correction -- one test per leaf
             float kf[4], rem[4];
             unsigned long long fix = 0;           // lanes with a remainder at or beyond q / 2 (ballots: the comparisons write scalar masks, the scalar unit ors them)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 kf[r] = __builtin_rintf(y[r] * rq[r]);
                 rem[r] = __builtin_fmaf(-kf[r], qf[r], y[r]);
-                fix |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(rem[r]) >= qh[r]);
+                const float ar = __builtin_fabsf(rem[r]);
+                fix |= __builtin_amdgcn_ballot_w64(ar + ar >= qf[r]);
             }
             int ki[4];
 #pragma unroll
@@ -824,8 +723,8 @@ __device__ __forceinline__ void dct16_impl(Dct16Lds &L, const Geom &g, const QtG
             if (fix != 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float ar = __builtin_fabsf(rem[r]);
-                    if (ar > qh[r] || (ar == qh[r] && (ki[r] & 1))) ki[r] += rem[r] > 0.f ? 1 : -1;
+                    const float ar = __builtin_fabsf(rem[r]), h = 0.5f * qf[r];
+                    if (ar > h || (ar == h && (ki[r] & 1))) ki[r] += rem[r] > 0.f ? 1 : -1;
                 }
             }
 #pragma unroll
