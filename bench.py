@@ -66,8 +66,12 @@ def parse_args(argv=None):
     ap.add_argument("--graph", type=int, choices=[0, 1, 2], default=0,
                     help="aej_set_graph_mode: 0 never replay a captured hipGraph (the library default), 1 automatic (calls of at most 8 Mpx), 2 whenever possible")
     ap.add_argument("--sub-batches", type=int, default=0,
-                    help="aej_set_sub_batches: 0 automatic (the library default: 4 sub-batches on private streams for calls of at least 64 Mpx), 1 never, 2..8")
-    ap.add_argument("--pipeline", type=int, choices=[1, 2, 3, 4], default=3,
+                    help="aej_set_sub_batches: 0 automatic (the library default: 4 sub-batches on private streams for calls of at least 64 Mpx), 1 never, 2..8. "
+                         "Applies to the blocking calls; the pipelined steps take --pipelined-sub-batches")
+    ap.add_argument("--pipelined-sub-batches", type=int, default=-1,
+                    help="aej_set_sub_batches for the steps that rotate over the contexts: -1 = 2 for calls of at least 384 Mpx on four or more contexts "
+                         "(with four calls in flight two parts per call fill the chip best: profiles/r05_sched_sweep.txt), otherwise --sub-batches")
+    ap.add_argument("--pipeline", type=int, choices=[1, 2, 3, 4, 5, 6, 8], default=4,
                     help="contexts (each on its own stream, with its own output buffers and workspace) the timed steps rotate over; 1 = blocking calls")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aej_set_option on every context (include/aej.h has the table), e.g. --option dct64_kernel=1; A / B runs only")
@@ -224,24 +228,35 @@ _REAL_STDOUT = sys.stdout
 
 
 # BASELINE.json's other configurations on one GPU (the per-GPU share of the multi-GPU ones) and the two labelled variants of the headline
-# workload.  `steps`: timed steps (enough for the timed region to be tens of milliseconds); `check`: the image compared with the oracle.
+# workload.  `steps`: timed steps (enough for the timed region to be tens of milliseconds); `check`: the image compared with the oracle;
+# `contexts`: calls in flight where that is not the headline's (three contexts x the library's automatic sub-batches measured best for the smaller
+# calls and for 8-bit ingest, four contexts x two sub-batches for 64 x 4K float32: profiles/r05_sched_sweep.txt).
 OTHER_CONFIGS = [
     {"name": "BASELINE configs[1]: single 1920x1080 image, adaptive 4-64 blocks, YCbCr", "batch": 1, "H": 1080, "W": 1920, "space": "YCbCr",
-     "blocks": (4, 64), "data": "synthetic", "ingest": "f32", "steps": 200, "blocking_steps": 100, "check": 0},
+     "blocks": (4, 64), "data": "synthetic", "ingest": "f32", "steps": 200, "blocking_steps": 100, "check": 0, "contexts": 3},
     {"name": "BASELINE configs[2]: batch of 64 1080p images, adaptive 4-64 blocks", "batch": 64, "H": 1080, "W": 1920, "space": "YCbCr",
-     "blocks": (4, 64), "data": "synthetic", "ingest": "f32", "steps": 8, "blocking_steps": 4, "check": 63},
+     "blocks": (4, 64), "data": "synthetic", "ingest": "f32", "steps": 8, "blocking_steps": 4, "check": 63, "contexts": 3},
     {"name": "BASELINE configs[4] per-GPU share: 8 x 8K (7680x4320), full 4-128 block range, OKLAB", "batch": 8, "H": 4320, "W": 7680, "space": "OKLAB",
-     "blocks": (4, 128), "data": "synthetic", "ingest": "f32", "steps": 8, "blocking_steps": 4, "check": 7},
+     "blocks": (4, 128), "data": "synthetic", "ingest": "f32", "steps": 8, "blocking_steps": 4, "check": 7, "contexts": 3},
     {"name": "headline workload on natural images (the reference's test images mirror-tiled to 4K)", "batch": 64, "H": H4K, "W": W4K, "space": "YCbCr",
      "blocks": (4, 64), "data": "natural", "ingest": "f32", "steps": 8, "blocking_steps": 4, "check": 17},
     {"name": "headline workload with 8-bit ingest (uint8 RGB in, 3 B/px: how real inputs arrive, image.py:80)", "batch": 64, "H": H4K, "W": W4K,
-     "space": "YCbCr", "blocks": (4, 64), "data": "synthetic", "ingest": "u8", "steps": 8, "blocking_steps": 4, "check": 31},
+     "space": "YCbCr", "blocks": (4, 64), "data": "synthetic", "ingest": "u8", "steps": 8, "blocking_steps": 4, "check": 31, "contexts": 3},
 ]
+
+
+def pipelined_sub_batches(args, n_pipe, B, H, W):
+    """aej_set_sub_batches of the pipelined steps (see --pipelined-sub-batches)"""
+    if args.pipelined_sub_batches >= 0:
+        return args.pipelined_sub_batches
+    if args.sub_batches == 0 and n_pipe >= 4 and B * H * W >= 384_000_000:
+        return 2
+    return args.sub_batches
 
 
 def run_other_configs(torch, A, dev, args, O, qrange, time_budget_s=150.0):
     """After the headline measurement, in the same process: every entry of OTHER_CONFIGS timed like the headline (warm-up, then exactly
-    `steps` steps between two synchronisations, three contexts in flight) plus the same steps as blocking calls, one image of the last
+    `steps` steps between two synchronisations, three or four contexts in flight) plus the same steps as blocking calls, one image of the last
     timed step checked against the CPU oracle.  Single GPU only (they are per-GPU shares; the multi-GPU line carries the headline)."""
     from benchlib.workload import Workload
     out, t_start = [], time.perf_counter()
@@ -252,8 +267,9 @@ def run_other_configs(torch, A, dev, args, O, qrange, time_budget_s=150.0):
         B, H, W = cfg["batch"], cfg["H"], cfg["W"]
         make = synth_batch if cfg["data"] == "synthetic" else natural_batch
         batches = [make(torch, B, H, W, 20250718, dev), make(torch, B, H, W, 20250718 + 1_000_000, dev)]
-        wl = Workload(torch, A, dev, batches, space=cfg["space"], qrange=qrange, brange=cfg["blocks"], ingest=cfg["ingest"], n_pipe=3,
-                      graph=args.graph, sub_batches=args.sub_batches, options=args.option)
+        n_pipe = cfg.get("contexts", args.pipeline)
+        wl = Workload(torch, A, dev, batches, space=cfg["space"], qrange=qrange, brange=cfg["blocks"], ingest=cfg["ingest"], n_pipe=n_pipe,
+                      graph=args.graph, sub_batches=args.sub_batches, pipelined_sub_batches=pipelined_sub_batches(args, n_pipe, B, H, W), options=args.option)
         wl.warm(6)
         dt = timed_loop(torch, None, wl.step, cfg["steps"], wl.sync)
         verified = None
@@ -263,7 +279,8 @@ def run_other_configs(torch, A, dev, args, O, qrange, time_budget_s=150.0):
         dt_s = timed_loop(torch, None, wl.serial_step, cfg["blocking_steps"], wl.sync)
         ms, ms_s = dt / cfg["steps"] * 1e3, dt_s / cfg["blocking_steps"] * 1e3
         out.append({"workload": cfg["name"], "images": B, "height": H, "width": W, "color_space": cfg["space"], "block_size_range": list(cfg["blocks"]),
-                    "data": cfg["data"], "ingest": cfg["ingest"], "steps": cfg["steps"], "ms_per_step": round(ms, 4), "MP/s": round(B * H * W / ms / 1e3, 1),
+                    "data": cfg["data"], "ingest": cfg["ingest"], "steps": cfg["steps"], "contexts": n_pipe, "pipelined_sub_batches": wl.pipelined_sub_batches,
+                    "ms_per_step": round(ms, 4), "MP/s": round(B * H * W / ms / 1e3, 1),
                     "blocking_ms_per_call": round(ms_s, 4), "blocking_MP/s": round(B * H * W / ms_s / 1e3, 1), "verified": verified})
         wl.close()
         del wl, batches
@@ -313,7 +330,8 @@ def main():
     coll_dev = dev if backend == "nccl" else None
     make_batch = synth_batch if args.data == "synthetic" else natural_batch
     wl = Workload(torch, A, dev, [make_batch(torch, B, H, W, seed_a, dev), make_batch(torch, B, H, W, seed_b, dev)], space=space, qrange=qrange,
-                  brange=brange, ingest=args.ingest, n_pipe=args.pipeline, graph=args.graph, sub_batches=args.sub_batches, options=args.option)
+                  brange=brange, ingest=args.ingest, n_pipe=args.pipeline, graph=args.graph, sub_batches=args.sub_batches,
+                  pipelined_sub_batches=pipelined_sub_batches(args, args.pipeline, B, H, W), options=args.option)
     n_pipe = wl.n_pipe
 
     # ---- the measurement: W warm-up steps, then exactly K timed steps on alternating inputs, profiling off ----
@@ -415,7 +433,8 @@ def main():
         "pipeline": {"contexts": n_pipe, "serial_ms_per_step": round(dt_s / args.steps * 1e3, 3),
                      "serial_note": "the same K steps as blocking aej_encode_batch calls on one context (nothing in flight between calls)"},
         "graph": dict(wl.ctx.graph_stats(), mode=args.graph),
-        "sub_batches": {"mode": args.sub_batches, "split_calls": sum(p.ctx.split_calls() for p in wl.pipes)},
+        "sub_batches": {"mode": args.sub_batches, "pipelined_steps": wl.pipelined_sub_batches, "split_calls": sum(p.ctx.split_calls() for p in wl.pipes),
+                        "note": "aej_set_sub_batches: mode (0 = the library's automatic choice, 4 here) for the blocking calls, pipelined_steps for the timed steps"},
         "stages": per_stage,
         "stage_ms_source": f"4 separate profiled blocking steps after the timed region (sum {sum(stage_ms.values()):.3f} ms); stages of different "
                            "sub-batches overlap in the timed region, so they add up to more than ms_per_step",

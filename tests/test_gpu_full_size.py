@@ -352,17 +352,17 @@ def test_randomised_parity_sweep(env, oracle):
         assert np.array_equal(dec, want, equal_nan=True), tag + " decode"
 
 
-def test_bench_configuration_64x4k_three_contexts(env, oracle):
-    """The exact configuration bench.py times (BASELINE config 4's per-GPU share): B = 64 x 3840x2160, THREE contexts on three streams
-    with aej_encode_batch_begin / _end (bench.py --pipeline 3), automatic sub-batching, two different input batches rotated with the
-    bench's own input_of(); images 0, B/2 and B-1 of EACH context's last call are compared with the oracle, and every image's counters
-    are checked for consistency."""
+def test_bench_configuration_64x4k_four_contexts(env, oracle):
+    """The exact configuration bench.py times (BASELINE config 4's per-GPU share): B = 64 x 3840x2160, FOUR contexts on four streams
+    with aej_encode_batch_begin / _end (bench.py --pipeline 4), every call cut into two sub-batches (bench.pipelined_sub_batches), two
+    different input batches rotated with the bench's own input_of(); images 0, B/2 and B-1 of EACH context's last call are compared with
+    the oracle, and every image's counters are checked for consistency."""
     torch, A, bench = env
     from adaptive_edge_aware_jpeg_amd.jpeg import EncodedBatch
     dev = torch.device("cuda", 0)
     space, qr, br = "YCbCr", (40, 80), (4, 64)
     B, H, W = 64, 2160, 3840
-    n_pipe, n_steps = 3, 9
+    n_pipe, n_steps = 4, 12
     codec = A.Jpeg(A.JpegCompressionSettings(space, qr, br))
     xs = [bench.synth_batch(torch, B, H, W, seed, dev) for seed in (20250718, 20250718 + 1_000_000)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
@@ -370,7 +370,7 @@ def test_bench_configuration_64x4k_three_contexts(env, oracle):
     for s in streams:
         with torch.cuda.stream(s):
             c = codec._bind()
-            c.set_sub_batches(0)
+            c.set_sub_batches(2)
             plan = c.plan(B, H, W)
             ctxs.append(c)
             outs.append((c.empty((B * plan.coeff_stride,), torch.int32), c.empty((B * plan.leaf_stride, 4), torch.int32),
@@ -380,7 +380,7 @@ def test_bench_configuration_64x4k_three_contexts(env, oracle):
     # process was started otherwise -- with fewer real queues the streams share queues, which is slower but equally correct
     for c in ctxs:
         c.check(c.lib.aej_set_hw_queues(c.handle, 16))
-    assert ctxs[0].schedule(B, H, W)["sub_batches"] == 4
+    assert ctxs[0].schedule(B, H, W)["sub_batches"] == 2
 
     def input_of(i):                              # bench.py's rotation
         return (i // n_pipe + i) & 1
@@ -402,7 +402,7 @@ def test_bench_configuration_64x4k_three_contexts(env, oracle):
             with torch.cuda.stream(streams[k]):
                 codec.encode_end(ctxs[k])
         torch.cuda.synchronize()
-        assert sorted(last.values()) in ([0, 0, 1], [0, 1, 1]), "both input batches must be among the contexts' last calls"
+        assert 0 < sum(last.values()) < n_pipe, "both input batches must be among the contexts' last calls"
         assert all(c.split_calls() - s0 == n_steps // n_pipe for c, s0 in zip(ctxs, split0)), "the calls were expected to run as sub-batches"
         for k in range(n_pipe):
             enc = EncodedBatch(plan, *outs[k])

@@ -17,7 +17,7 @@ class Pipe:
         with torch.cuda.stream(stream):
             self.ctx = jpeg._bind()
             self.ctx.set_graph_mode(wl.graph)
-            self.ctx.set_sub_batches(wl.sub_batches)
+            self.ctx.set_sub_batches(wl.pipelined_sub_batches)
             for kv in wl.options:
                 self.ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
             self.plan = self.ctx.plan(wl.B, wl.H, wl.W)
@@ -41,13 +41,17 @@ class Pipe:
 
 
 class Workload:
-    def __init__(self, torch, A, dev, batches_f32, *, space, qrange, brange, ingest="f32", n_pipe=3, graph=0, sub_batches=0, options=()):
+    def __init__(self, torch, A, dev, batches_f32, *, space, qrange, brange, ingest="f32", n_pipe=3, graph=0, sub_batches=0, pipelined_sub_batches=None,
+                 options=()):
         from .data import to_u8
         self.torch, self.dev = torch, dev
         self.batches_f32 = batches_f32
         self.B, self.H, self.W = (int(v) for v in batches_f32[0].shape[:3])
         self.space, self.qrange, self.brange, self.ingest = space, tuple(qrange), tuple(brange), ingest
+        # aej_set_sub_batches: `sub_batches` for the blocking calls (0 = the library's automatic choice), `pipelined_sub_batches` for the steps
+        # that rotate over the contexts (a caller that keeps four calls in flight wants each cut in two, a lone blocking call in four)
         self.graph, self.sub_batches, self.options = graph, sub_batches, list(options)
+        self.pipelined_sub_batches = sub_batches if pipelined_sub_batches is None else pipelined_sub_batches
         self.batches = batches_f32 if ingest == "f32" else [to_u8(torch, x) for x in batches_f32]
         self.jpeg = A.Jpeg(A.JpegCompressionSettings(space, self.qrange, self.brange), device=dev.index)
         # every context on a stream of its own, none on the legacy null stream: once other streams exist, launches on the null stream shift
@@ -73,7 +77,11 @@ class Workload:
         """one blocking call at a time on context 0"""
         p = self.pipes[0]
         with self.torch.cuda.stream(p.stream):
+            if self.sub_batches != self.pipelined_sub_batches:
+                p.ctx.set_sub_batches(self.sub_batches)
             self.jpeg.encode_into(p.ctx, self.batches[i & 1], p.plan, *p.out)
+            if self.sub_batches != self.pipelined_sub_batches:
+                p.ctx.set_sub_batches(self.pipelined_sub_batches)
 
     def sync(self):
         for p in self.pipes:
