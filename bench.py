@@ -44,8 +44,8 @@ METRIC = "megapixels/sec encode (Canny+quadtree+DCT+quant), 4K batch"
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("AEJ_BENCH_BATCH", "64")), help="images per GPU (weak scaling)")
     ap.add_argument("--total-images", type=int, default=0,
                     help="strong-scaling variant: this many images in total, cut into contiguous shards by image index (sharding.shard_bounds)")
