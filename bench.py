@@ -229,8 +229,8 @@ _REAL_STDOUT = sys.stdout
 
 # BASELINE.json's other configurations on one GPU (the per-GPU share of the multi-GPU ones) and the two labelled variants of the headline
 # workload.  `steps`: timed steps (enough for the timed region to be tens of milliseconds); `check`: the image compared with the oracle;
-# `contexts`: calls in flight where that is not the headline's (three contexts x the library's automatic sub-batches measured best for the smaller
-# calls and for 8-bit ingest, four contexts x two sub-batches for 64 x 4K float32: profiles/r05_sched_sweep.txt).
+# `contexts`: calls in flight where that is not the headline's (three contexts x the library's automatic sub-batches for the smaller calls, four
+# contexts x two sub-batches for the 64 x 4K ones: profiles/r05_sched_sweep.txt).
 OTHER_CONFIGS = [
     {"name": "BASELINE configs[1]: single 1920x1080 image, adaptive 4-64 blocks, YCbCr", "batch": 1, "H": 1080, "W": 1920, "space": "YCbCr",
      "blocks": (4, 64), "data": "synthetic", "ingest": "f32", "steps": 200, "blocking_steps": 100, "check": 0, "contexts": 3},
@@ -241,7 +241,7 @@ OTHER_CONFIGS = [
     {"name": "headline workload on natural images (the reference's test images mirror-tiled to 4K)", "batch": 64, "H": H4K, "W": W4K, "space": "YCbCr",
      "blocks": (4, 64), "data": "natural", "ingest": "f32", "steps": 8, "blocking_steps": 4, "check": 17},
     {"name": "headline workload with 8-bit ingest (uint8 RGB in, 3 B/px: how real inputs arrive, image.py:80)", "batch": 64, "H": H4K, "W": W4K,
-     "space": "YCbCr", "blocks": (4, 64), "data": "synthetic", "ingest": "u8", "steps": 8, "blocking_steps": 4, "check": 31, "contexts": 3},
+     "space": "YCbCr", "blocks": (4, 64), "data": "synthetic", "ingest": "u8", "steps": 8, "blocking_steps": 4, "check": 31},
 ]
 
 

@@ -60,6 +60,11 @@ class Workload:
         torch.cuda.synchronize()
         self.n_pipe = n_pipe
         self.ctx, self.plan = self.pipes[0].ctx, self.pipes[0].plan
+        if self.sub_batches != self.pipelined_sub_batches:
+            # the blocking calls split differently from the pipelined steps: let context 0 create the sub-batch streams of BOTH shapes now.  Streams
+            # created after every other stream of the process exists measured 0.3-0.4 ms per blocking call slower (profiles/r05_sched_sweep.txt)
+            self.serial_step(0)
+            torch.cuda.synchronize()
 
     @property
     def pixels_per_step(self):
