@@ -152,8 +152,9 @@ def group_barrier(dist):
 
 def hw_queue_default(world):
     """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue run one after the other.  This
-    process uses one stream per context plus the library's sub-batch streams: 16 with the null stream, so 16 queues give every stream its
-    own -- until somebody else creates streams first.  A live RCCL communicator does (measured on one GPU, one rank, profiles/
+    process uses one stream per context plus the library's sub-batch streams: 15 with the null stream (four contexts x (1 + 2), two more for the
+    blocking-call shape; round 4: three x (1 + 4) + 1 = 16), so 16 queues give every stream its own (tools/profiling/queue_map.py shows the mapping)
+    -- until somebody else creates streams first.  A live RCCL communicator does (measured on one GPU, one rank, profiles/
     r04_rccl_hw_queues.txt: 6.85-6.96 ms per step against 5.96-5.98 with the same blocking-call time, back to 5.95-5.99 with 24 queues or
     with the communicator created after our streams), so a process that will hold a process group asks for 24 AND creates its
     communicator last."""
