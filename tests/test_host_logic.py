@@ -344,3 +344,22 @@ def test_pack_u8_levels_host_helper():
     assert lib.aej_pack_u8_levels_host(r.ctypes.data, r.size, out.ctypes.data, 2) == 0
     assert lib.aej_pack_u8_levels_host(f.ctypes.data, 0, out.ctypes.data, 2) == 1      # an empty batch is trivially all levels
     assert lib.aej_pack_u8_levels_host(None, 4, out.ctypes.data, 2) < 0
+
+
+def test_bench_sub_batch_policy_for_pipelined_steps():
+    """bench.py asks for two sub-batches per call only where it keeps four or more 64 x 4K-sized calls in flight; everywhere else (and for the
+    blocking calls always) the library's automatic choice or the explicit --sub-batches stands (profiles/r05_sched_sweep.txt)."""
+    import types
+    import bench
+    a = types.SimpleNamespace(pipelined_sub_batches=-1, sub_batches=0)
+    assert bench.pipelined_sub_batches(a, 4, 64, 2160, 3840) == 2
+    assert bench.pipelined_sub_batches(a, 6, 64, 2160, 3840) == 2
+    assert bench.pipelined_sub_batches(a, 3, 64, 2160, 3840) == 0          # three contexts: automatic (four)
+    assert bench.pipelined_sub_batches(a, 4, 64, 1080, 1920) == 0          # smaller calls: automatic
+    assert bench.pipelined_sub_batches(a, 4, 8, 4320, 7680) == 0
+    a.sub_batches = 4
+    assert bench.pipelined_sub_batches(a, 4, 64, 2160, 3840) == 4          # an explicit --sub-batches applies to both kinds of call
+    a.pipelined_sub_batches = 3
+    assert bench.pipelined_sub_batches(a, 4, 64, 2160, 3840) == 3
+    assert bench.parse_args(["--gpus", "1"]).pipeline == 4 and bench.parse_args([]).steps == 20
+
