@@ -688,3 +688,38 @@ def test_sides_above_65535_pixels_are_refused_not_wrapped():
             ctx.plan(1, H, W)
     p = ctx.plan(1, 16, 65535 // 4 * 4)
     assert p.W == 65535 // 4 * 4 and p.workspace_bytes > 0
+
+
+def test_compress_batches_keeps_calls_in_flight_and_yields_in_order(A, oracle):
+    """Jpeg.compress_batches: a sequence of batches through up to `in_flight` calls on private streams (aej_encode_batch_begin / _end) -- every
+    result equals compress_batch of the same input, results come in input order, inputs of different shapes and kinds (device tensor, numpy,
+    uint8) mix, a consumer that stops early leaves nothing in flight, and a second pass reuses the streams and contexts of the first."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    imgs = [oracle.synth_image(160, 224, s, k).astype(np.float32) / np.float32(255.0) for s, k in ((1, "mixed"), (2, "noise"), (3, "flat"), (4, "mixed"))]
+    batches = [np.stack(imgs[:2]), torch.from_numpy(np.stack(imgs[1:4])).to(dev), (np.stack(imgs[2:]) * 255).astype(np.uint8),
+               torch.from_numpy(rng.random((1, 96, 128, 3), dtype=np.float32)).to(dev), np.stack(imgs[:1]), torch.from_numpy(np.stack(imgs)).to(dev)]
+    codec = A.Jpeg(A.JpegCompressionSettings("YCbCr", (40, 80), (4, 64)))
+    want = [codec.compress_batch(b) for b in batches]
+    for in_flight in (3, 1, 4):
+        got = list(codec.compress_batches(iter(batches), in_flight=in_flight))
+        assert len(got) == len(want)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g.counts, w.counts), (in_flight, i)
+            for b in range(batches[i].shape[0]):
+                for l in range(3):
+                    a, c = g.layer(b, l), w.layer(b, l)
+                    assert a["root_size"] == c["root_size"] and all(np.array_equal(a[k], c[k]) for k in ("states", "leaves", "coeffs")), (in_flight, i, b, l)
+    n_streams = len(codec._pipe_streams)
+    gen = codec.compress_batches(iter(batches), in_flight=3)
+    first = next(gen)
+    gen.close()                                            # the consumer stops: the calls in flight are ended, not abandoned
+    assert torch.equal(first.counts, want[0].counts)
+    assert len(codec._pipe_streams) == n_streams == 4
+    again = list(codec.compress_batches(batches[:2], in_flight=2))
+    assert torch.equal(again[1].coeffs[: want[1].coeffs.numel()], want[1].coeffs)
+    with pytest.raises(ValueError):
+        list(codec.compress_batches(batches, in_flight=0))
+    with pytest.raises(ValueError):
+        list(codec.compress_batches([np.zeros((2, 8, 8), np.float32)]))
