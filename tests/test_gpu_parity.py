@@ -718,7 +718,9 @@ def test_compress_batches_keeps_calls_in_flight_and_yields_in_order(A, oracle):
     assert torch.equal(first.counts, want[0].counts)
     assert len(codec._pipe_streams) == n_streams == 4
     again = list(codec.compress_batches(batches[:2], in_flight=2))
-    assert torch.equal(again[1].coeffs[: want[1].coeffs.numel()], want[1].coeffs)
+    for b in range(batches[1].shape[0]):                   # (whole buffers are not comparable: capacity beyond a layer's count is uninitialised)
+        for l in range(3):
+            assert np.array_equal(again[1].layer(b, l)["coeffs"], want[1].layer(b, l)["coeffs"])
     with pytest.raises(ValueError):
         list(codec.compress_batches(batches, in_flight=0))
     with pytest.raises(ValueError):
